@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator: runs the *reference itself* (imported from /root/reference,
+CPU PyTorch path) and writes small input/output fixtures to tests/golden/*.npz.
+
+Runs ONLY in the build container (where /root/reference exists); the fixtures it writes
+are data (inputs + the reference's outputs) and are committed.  Nothing here is imported
+by the product or by tests at run time.
+
+Weights come from ``oracle.shgan_oracle.init_state_dict(seed)`` (numpy RandomState, bit
+stable) and are loaded into the reference modules with ``load_state_dict(strict=True)``,
+so fixtures record only the seed -- and the strict load pins the state_dict key schema
+(SURVEY.md appendix E).
+
+Usage:  python tools/gen_golden.py [--only NAME ...]
+"""
+import argparse
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('SHGAN_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+# --- import shim: stub modules the reference imports but never uses here
+for _name in ['torchvision', 'torchvision.models', 'torchvision.transforms', 'pyspng', 'cv2']:
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+sys.modules['torchvision'].models = sys.modules['torchvision.models']
+sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from lib.model_zoo import comodgan, shgan, stylegan  # noqa: E402,F401
+from lib.model_zoo.common import utils as ref_utils  # noqa: E402
+from lib.model_zoo.stylegan_utils import conv2d_resample as ref_c2r  # noqa: E402
+from lib.model_zoo.stylegan_utils import upfirdn2d as ref_ufd  # noqa: E402
+from oracle import shgan_oracle as orc  # noqa: E402  (only for init_state_dict / input synthesis)
+
+ACT = 'lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)'
+
+
+def rs(seed):
+    return np.random.RandomState(seed)
+
+
+def f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def tn(a):
+    return torch.from_numpy(f32(a))
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+# ---------------------------------------------------------------------------------------------
+
+
+def gen_upfirdn2d():
+    """A10: the three generator configurations + the edge cases the CUDA op accepts."""
+    g = rs(100)
+    f4 = ref_ufd.setup_filter([1, 3, 3, 1])
+    fasym = tn(g.standard_normal((3, 5)))       # asymmetric, non-square: catches flips/transposes
+    f1d = ref_ufd.setup_filter([1, 2, 3, 4, 5, 4, 3, 2, 1])   # >= 8 taps -> separable 1-D
+    cases = [
+        # name, shape, filter, up, down, padding, flip, gain
+        ('enc_down_prefilter', (2, 3, 16, 16), f4, 1, 1, [2, 2, 2, 2], False, 1.0),
+        ('syn_up_postfilter', (1, 6, 17, 17), f4, 1, 1, [1, 1, 1, 1], False, 4.0),
+        ('rgb_upsample', (2, 3, 8, 8), f4, 2, 1, [2, 1, 2, 1], False, 4.0),
+        ('down2', (2, 2, 16, 16), f4, 1, 2, [1, 1, 1, 1], False, 1.0),
+        ('asym_flip', (1, 2, 9, 11), fasym, 1, 1, [2, 1, 0, 3], True, 0.5),
+        ('asym_noflip', (1, 2, 9, 11), fasym, 1, 1, [2, 1, 0, 3], False, 0.5),
+        ('asym_up2_down3', (1, 2, 7, 6), fasym, [2, 3], [3, 2], [3, 2, 4, 1], False, 2.0),
+        ('negative_pad_crop', (1, 2, 12, 12), f4, 1, 1, [-1, 0, -2, 1], False, 1.0),
+        ('separable_1d', (1, 2, 20, 20), f1d, 2, 1, [5, 4, 5, 4], False, 4.0),
+        ('identity_none', (1, 2, 5, 5), None, 1, 1, [0, 0, 0, 0], False, 1.0),
+        ('odd_513', (1, 1, 33, 33), f4, 1, 1, [1, 1, 1, 1], False, 4.0),
+    ]
+    out = {}
+    names = []
+    for name, shape, f, up, down, pad, flip, gain in cases:
+        x = tn(g.standard_normal(shape))
+        y = ref_ufd.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+        names.append(name)
+        out[name + '__x'] = x.numpy()
+        out[name + '__f'] = f.numpy() if f is not None else np.zeros((0,), np.float32)
+        up2 = [up, up] if isinstance(up, int) else list(up)          # [x, y]
+        dn2 = [down, down] if isinstance(down, int) else list(down)
+        out[name + '__cfg'] = np.array(up2 + dn2 + list(pad) + [int(flip)], dtype=np.int64)
+        out[name + '__gain'] = np.float64(gain)
+        out[name + '__y'] = y.numpy()
+    # helpers: upsample2d / downsample2d / filter2d / setup_filter
+    x = tn(g.standard_normal((2, 3, 10, 10)))
+    out['helpers__x'] = x.numpy()
+    out['helpers__f'] = f4.numpy()
+    out['helpers__up'] = ref_ufd.upsample2d(x, f4).numpy()
+    out['helpers__down'] = ref_ufd.downsample2d(x, f4).numpy()
+    out['helpers__filt'] = ref_ufd.filter2d(x, f4).numpy()
+    out['setup_filter_1331'] = f4.numpy()
+    out['setup_filter_sep'] = f1d.numpy()
+    out['setup_filter_gain_flip'] = ref_ufd.setup_filter([[1, 2], [3, 4]], flip_filter=True, gain=4).numpy()
+    out['names'] = np.array(names)
+    save('upfirdn2d', **out)
+
+
+def gen_conv2d_resample():
+    """A8/A9: every branch the generator (and D's skip path) can take, groups 1 and N."""
+    g = rs(200)
+    f4 = ref_ufd.setup_filter([1, 3, 3, 1])
+    cases = [
+        # name, x shape, w shape, up, down, padding, groups, flip_weight
+        ('plain_3x3', (2, 5, 12, 12), (7, 5, 3, 3), 1, 1, 1, 1, True),
+        ('plain_3x3_noflip', (2, 5, 12, 12), (7, 5, 3, 3), 1, 1, 1, 1, False),
+        ('plain_1x1', (2, 4, 9, 9), (6, 4, 1, 1), 1, 1, 0, 1, True),
+        ('down2_3x3', (2, 5, 16, 16), (6, 5, 3, 3), 1, 2, 1, 1, True),
+        ('up2_3x3', (2, 5, 8, 8), (6, 5, 3, 3), 2, 1, 1, 1, False),
+        ('up2_3x3_grouped', (1, 10, 8, 8), (12, 5, 3, 3), 2, 1, 1, 2, False),
+        ('plain_3x3_grouped', (1, 10, 8, 8), (12, 5, 3, 3), 1, 1, 1, 2, True),
+        ('down2_1x1', (2, 4, 16, 16), (6, 4, 1, 1), 1, 2, 0, 1, True),
+        ('up2_1x1', (2, 4, 8, 8), (6, 4, 1, 1), 2, 1, 0, 1, True),
+        ('up2_4x4_small', (1, 3, 4, 4), (2, 3, 3, 3), 2, 1, 1, 1, False),
+    ]
+    out = {}
+    names = []
+    for name, xs, ws, up, down, pad, groups, flipw in cases:
+        x = tn(g.standard_normal(xs))
+        w = tn(g.standard_normal(ws))
+        f = f4 if (up > 1 or down > 1) else None
+        y = ref_c2r.conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=pad, groups=groups,
+                                    flip_weight=flipw)
+        names.append(name)
+        out[name + '__x'] = x.numpy()
+        out[name + '__w'] = w.numpy()
+        out[name + '__cfg'] = np.array([up, down, pad, groups, int(flipw), int(f is not None)], dtype=np.int64)
+        out[name + '__y'] = y.numpy()
+    out['f'] = f4.numpy()
+    out['names'] = np.array(names)
+    save('conv2d_resample', **out)
+
+
+def gen_modconv():
+    """A4: fused / non-fused x up{1,2} x demod{T,F}, with and without noise; 1x1 torgb form."""
+    g = rs(300)
+    f4 = ref_ufd.setup_filter([1, 3, 3, 1])
+    out = {}
+    names = []
+    for up in (1, 2):
+        for demod in (True, False):
+            for fused in (True, False):
+                for k in (3, 1):
+                    if k == 1 and up == 2:
+                        continue
+                    name = f'up{up}_demod{int(demod)}_fused{int(fused)}_k{k}'
+                    n, ci, co, r = 3, 6, 5, 8
+                    x = tn(g.standard_normal((n, ci, r, r)))
+                    w = tn(g.standard_normal((co, ci, k, k)))
+                    s = tn(g.standard_normal((n, ci)) + 1.0)
+                    ro = r * up
+                    noise = tn(g.standard_normal((n, 1, ro, ro)) * 0.3)
+                    y = stylegan.modulated_conv2d(
+                        x=x.clone(), weight=w, styles=s, noise=noise.clone(), up=up, padding=k // 2,
+                        resample_filter=(f4 if up > 1 else None), demodulate=demod,
+                        flip_weight=(up == 1), fused_modconv=fused)
+                    names.append(name)
+                    out[name + '__x'] = x.numpy()
+                    out[name + '__w'] = w.numpy()
+                    out[name + '__s'] = s.numpy()
+                    out[name + '__noise'] = noise.numpy()
+                    out[name + '__cfg'] = np.array([up, int(demod), int(fused), k], dtype=np.int64)
+                    out[name + '__y'] = y.numpy()
+    out['f'] = f4.numpy()
+    out['names'] = np.array(names)
+    save('modulated_conv2d', **out)
+
+
+def gen_small_ops():
+    """A3 dense, A11 lrelu_agc, A12 get_unit, fma."""
+    g = rs(400)
+    out = {}
+    x = tn(np.concatenate([g.standard_normal(2000) * 3, [0.0, -0.0, 1e30, -1e30, 200.0, -1500.0]]))
+    act = ref_utils.get_unit()(ACT)()
+    out['lrelu__x'] = x.numpy()
+    out['lrelu__y_gain1'] = act(x.clone(), gain=1).numpy()
+    out['lrelu__y_gain_sqrt_half'] = act(x.clone(), gain=np.sqrt(0.5)).numpy()
+    act2 = ref_utils.get_unit()('lrelu_agc(alpha=0.1, gain=1)')()
+    out['lrelu__y_noclamp'] = act2(x.clone()).numpy()
+    for tag, (n, i, o, lr, bias_init, use_act) in {
+            'mapping': (4, 64, 48, 0.01, 0.0, True),
+            'affine': (3, 96, 40, 1.0, 1.0, False),
+            'fc': (2, 512, 33, 1.0, 0.0, True)}.items():
+        torch.manual_seed(7)
+        m = stylegan.dense(i, o, bias=True, bias_init=bias_init, activation=(ACT if use_act else None), lr_multi=lr)
+        with torch.no_grad():
+            m.weight.copy_(tn(g.standard_normal((o, i))) / lr)
+            m.bias.copy_(tn(g.standard_normal(o)) + bias_init)
+        xx = tn(g.standard_normal((n, i)))
+        with torch.no_grad():
+            yy = m(xx)
+        out[f'dense_{tag}__x'] = xx.numpy()
+        out[f'dense_{tag}__w'] = m.weight.detach().numpy()
+        out[f'dense_{tag}__b'] = m.bias.detach().numpy()
+        out[f'dense_{tag}__cfg'] = np.array([lr, float(use_act)], dtype=np.float64)
+        out[f'dense_{tag}__y'] = yy.numpy()
+    from lib.model_zoo.stylegan_utils import fma as ref_fma
+    a, b, c = (tn(g.standard_normal((2, 3, 4, 4))), tn(g.standard_normal((2, 3, 1, 1))),
+               tn(g.standard_normal((2, 1, 4, 4))))
+    out['fma__a'], out['fma__b'], out['fma__c'] = a.numpy(), b.numpy(), c.numpy()
+    out['fma__y'] = ref_fma.fma(a, b, c).numpy()
+    save('small_ops', **out)
+
+
+def gen_shu():
+    """A16-A19: constant tables + SHU end to end (N=2) + heterogeneous filter alone."""
+    g = rs(500)
+    out = {}
+    out['cweight_2x3_64x33'] = shgan.make_cweight([2, 3], (64, 33)).numpy()
+    torch.manual_seed(0)
+    shu = shgan.SHU(32, 32, [2, 3], 'piecewise_linear', input_res=64, lowest_res=4,
+                    tail_sigma_mult=3, gaussian_at_input_res=False).eval()
+    for r, t in shu.gaussian_weight_map.items():
+        out[f'gauss_{r}'] = t.numpy()
+    sd = orc.init_state_dict(256, seed=11, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128,
+                             bias_std=0.2)
+    sub = {k[len('encoder.shu.'):]: v for k, v in sd.items() if k.startswith('encoder.shu.')}
+    shu.load_state_dict(sub, strict=True)
+    x = tn(g.standard_normal((2, 32, 64, 64)))
+    with torch.no_grad():
+        y = shu(x)
+    out['shu__x'] = x.numpy()
+    out['shu__seed'] = np.int64(11)
+    for r, t in y.items():
+        out[f'shu__y{r}'] = t.numpy()
+    # heterogeneous filter alone
+    hf = shu.df1
+    t = tn(g.standard_normal((1, 64, 64, 33)))
+    with torch.no_grad():
+        out['hf__y'] = hf(t).numpy()
+    out['hf__x'] = t.numpy()
+    save('shu', **out)
+
+
+def build_reference_generator(resolution, ch_base, ch_max, w_dim, z_dim, w0_dim):
+    num_ws = {256: 14, 512: 16, 1024: 18}[resolution]
+    mp = comodgan.Mapping(z_dim=z_dim, c_dim=0, w_dim=w_dim, num_ws=num_ws, num_layers=8,
+                          embed_features=None, layer_features=None, activation=ACT,
+                          lr_multiplier=0.01, w_avg_beta=0.995)
+    enc = shgan.Encoder(resolution=resolution, ic_n=4, oc_n=w0_dim, ch_base=ch_base, ch_max=ch_max,
+                        use_fp16_before_res=None, resample_filter=[1, 3, 3, 1], activation=ACT,
+                        mbstd_group_size=0, mbstd_c_n=0, c_dim=None, cmap_dim=None, use_dropout=True,
+                        has_extra_final_layer=False, shu_channels=32, shu_df_freedom=[2, 3],
+                        shu_df_type='piecewise_linear', shu_input_res=64, shu_lowest_res=4,
+                        shu_tail_sigma_mult=3, shu_gaussian_at_input_res=False)
+    syn = comodgan.Synthesis(w_dim=w_dim, w0_dim=w0_dim, resolution=resolution, rgb_n=3, ch_base=ch_base,
+                             ch_max=ch_max, use_fp16_after_res=None, resample_filter=[1, 3, 3, 1],
+                             activation=ACT)
+    return comodgan.Generator(mp, enc, syn).eval().requires_grad_(False)
+
+
+def synth_inputs(n, resolution, z_dim, seed):
+    """Synthetic masked inputs: real ~ U(-1,1) quantised to u8 levels, freeform
+    mask from the reference's RandomMask, x = cat([mask-0.5, real*mask]), z ~ N(0,1)."""
+    from lib.data_factory.ds_ffhq import RandomMask
+    g = rs(seed)
+    real_u8 = g.randint(0, 256, size=(n, 3, resolution, resolution)).astype(np.uint8)
+    np.random.seed(seed)
+    mask = np.stack([RandomMask(resolution, [0, 1]) for _ in range(n)]).astype(np.uint8)  # [n,1,R,R]
+    z = f32(g.standard_normal((n, z_dim)))
+    return real_u8, mask, z
+
+
+def assemble_x(real_u8, mask):
+    real = torch.from_numpy(real_u8.astype(np.float32)) / 127.5 - 1.0
+    m = torch.from_numpy(mask.astype(np.float32))
+    return torch.cat([m - 0.5, real * m], dim=1)
+
+
+def gen_generator_small():
+    """A1,A2,A13-A15,A20-A24: full generator at reduced width (R=256, <=32 ch), N=2,
+    noise_mode const/none, with intermediates + the uint8 eval composite."""
+    cfg = dict(resolution=256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = build_reference_generator(**cfg)
+    sd = orc.init_state_dict(256, seed=21, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128,
+                             noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    real_u8, mask, z = synth_inputs(2, 256, 64, seed=22)
+    x = assemble_x(real_u8, mask)
+    zt = torch.from_numpy(z)
+    c = torch.zeros(2, 0)
+    out = dict(real_u8=real_u8, mask_bits=np.packbits(mask), z=z, seed=np.int64(21),
+               cfg=np.array([256, 2048, 32, 64, 64, 128], dtype=np.int64))
+    with torch.no_grad():
+        ws = G.mapping(zt, c)
+        xg, feats = G.encoder(x)
+        img = G(x=x, z=zt, c=c, noise_mode='const')
+        img_none = G(x=x, z=zt, c=c, noise_mode='none')
+    out['ws'] = ws.numpy()
+    out['xg'] = xg.numpy()
+    for r in (4, 8, 16, 32, 64):
+        out[f'feat{r}'] = feats[r].numpy()
+    for r in (128, 256):
+        out[f'feat{r}_stats'] = np.array([feats[r].mean().item(), feats[r].std().item(),
+                                          feats[r].min().item(), feats[r].max().item()])
+    out['img_const'] = img.numpy()
+    out['img_none_ds'] = img_none[:, :, ::4, ::4].numpy()
+    m = x[:, 0:1] + 0.5
+    comb = x[:, 1:4] * m + img * (1 - m)
+    out['comb_u8'] = (comb * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).numpy()
+    # 'random' noise mode with externally supplied noise: emulate by patching torch.randn order
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        img_rand = G(x=x, z=zt, c=c, noise_mode='random')
+    out['img_random_seed1234_ds'] = img_rand[:, :, ::4, ::4].numpy()
+    save('generator_small', **out)
+
+
+def gen_generator_full_stats():
+    """Full-width G (79.2 M params) at 256x256, N=2 (BASELINE config 1): statistics + sampled
+    pixels + a strided slice; weights are re-creatable from the seed."""
+    G = build_reference_generator(256, 32768, 512, 512, 512, 1024)
+    sd = orc.init_state_dict(256, seed=31)
+    G.load_state_dict(sd, strict=True)
+    nparam = sum(p.numel() for p in G.parameters())
+    real_u8, mask, z = synth_inputs(2, 256, 512, seed=32)
+    x = assemble_x(real_u8, mask)
+    with torch.no_grad():
+        img = G(x=x, z=torch.from_numpy(z), c=torch.zeros(2, 0), noise_mode='const')
+    g = rs(33)
+    idx = g.randint(0, img.numel(), size=256)
+    m = x[:, 0:1] + 0.5
+    comb_u8 = ((x[:, 1:4] * m + img * (1 - m)) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8)
+    save('generator_full256_stats', seed=np.int64(31), input_seed=np.int64(32), nparam=np.int64(nparam),
+         stats=np.array([img.mean().item(), img.std().item(), img.min().item(), img.max().item()]),
+         sample_idx=idx, sample_val=img.flatten()[idx].numpy(), img_ds=img[:, :, ::8, ::8].numpy(),
+         known_sha256=np.array(hashlib.sha256(
+             (comb_u8 * torch.from_numpy(mask)).numpy().tobytes()).hexdigest()),
+         state_dict_keys=np.array(sorted(G.state_dict().keys())),
+         state_dict_shapes=np.array([str(tuple(G.state_dict()[k].shape)) for k in sorted(G.state_dict().keys())]))
+
+
+def gen_masks():
+    """A25-A27: integer paths -- golden freeform masks (bit-packed), sampler indices, zipzap."""
+    from lib.data_factory.ds_ffhq import RandomMask
+    from lib.data_factory.common.ds_sampler import DistributedSampler
+    from lib.evaluator.eva_base import base_evaluator
+    out = {}
+    for s in (64, 256, 512):
+        np.random.seed(0)
+        ms = [RandomMask(s, [0, 1]) for _ in range(4)]
+        out[f'mask{s}_bits'] = np.stack([np.packbits(m.astype(np.uint8)) for m in ms])
+        out[f'mask{s}_sha'] = np.array([hashlib.sha256(np.packbits(m.astype(np.uint8)).tobytes()).hexdigest()[:16]
+                                        for m in ms])
+    import lib.data_factory.common.ds_sampler as dss
+    dss.print_log = lambda *a, **k: None
+    rows = []
+    for n_items, world in [(10, 4), (16, 8), (7, 2), (1000, 8), (3, 8)]:
+        for rank in range(world):
+            smp = DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)
+            rows.append(np.array([n_items, world, rank] + list(iter(smp)), dtype=np.int64))
+    out['sampler_rows'] = np.array(rows, dtype=object)
+    ev = base_evaluator.__new__(base_evaluator)
+    out['zipzap_in'] = np.array([[0, 2, 4, 6], [1, 3, 5, 7]])
+    out['zipzap_out'] = np.array(ev.zipzap_arrange([[0, 2, 4, 6], [1, 3, 5, 7]]))
+    out['zipzap_out_ragged'] = np.array(ev.zipzap_arrange([[0, 3, 6], [1, 4, 7], [2, 5]]))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, 'integer_paths.npz')
+    np.savez_compressed(path, **out, allow_pickle=True)
+    print('  wrote', path)
+
+
+GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modconv=gen_modconv,
+            small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
+            generator_full_stats=gen_generator_full_stats, masks=gen_masks)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*', default=None)
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    for k, fn in GENS.items():
+        if a.only and k not in a.only:
+            continue
+        print('[gen]', k)
+        fn()
