@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): SH-GAN generator forward, images/s at 512x512 batch 16 per GPU.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic masked inputs already resident in
+HBM: Generator.forward (mapping -> SHU encoder -> co-modulated synthesis, noise_mode='random' as in the
+reference eval loop) + the uint8 composite.  Weights: the reference's random initialisers (seeded);
+data: synthetic.  Multi-GPU = batch sharding, one process per GPU, no collective on the data path
+(weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+Rank 0 prints ONE JSON line with `roofline` (the dominant kernel class, conv_mfma: algorithmic flops /
+HIP-event time measured live over the timed steps, vs the dense fp32-MFMA peak of
+/opt/skills/guides/MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle timed on this host on a
+bounded sample -- a reported baseline, not the target)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # dense fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MAC), whole forward
+CONV_GFLOP_PER_IMAGE = {256: 180.3, 512: 238.3}   # the 3x3 convolutions alone
+
+
+def cpu_baseline(resolution, n_images, seed):
+    """Time the CPU oracle (torch fp32 CPU ops, all host threads) on a bounded sample."""
+    import torch
+    from oracle import shgan_oracle as orc
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = orc.init_state_dict(resolution, seed=seed)
+    x, z, _, _ = orc.synthetic_batch(n_images, resolution, 512, seed=seed + 1)
+    with torch.no_grad():
+        orc.generator_forward(sd, x[:1], z[:1], resolution, noise_mode='none')      # page-in / warm-up
+        t0 = time.perf_counter()
+        orc.run_generator(sd, x, z, resolution, noise_mode='const')
+        dt = time.perf_counter() - t0
+    return dict(value=round(n_images / dt, 4), unit='images/s', cores=threads, kind='port',
+                sample=f'{n_images} images {resolution}x{resolution}, 1 forward + composite after 1-image warm-up, '
+                       f'oracle/shgan_oracle.py (torch CPU fp32), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--resolution', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 16 @512, 32 @256)')
+    ap.add_argument('--noise-mode', default='random')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=4)
+    a = ap.parse_args()
+    res = a.resolution
+    batch = a.batch or {256: 32, 512: 16}.get(res, 8)
+
+    import torch
+    import torch.distributed as dist
+    import shgan_amd  # noqa: F401
+    from shgan_amd import eval_harness, kernels
+    from test_host_logic import build_generator
+    from oracle import shgan_oracle as orc      # weights only (the reference's initialisers, seeded)
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    G = build_generator(res)
+    G.load_state_dict(orc.init_state_dict(res, seed=0), strict=True)   # every rank initialises identically: no broadcast needed
+    G = G.eval().requires_grad_(False).to(dev)
+    # rank r holds its own shard of the global batch (rank-strided ids, ds_sampler.py:67)
+    x, z, _, _ = eval_harness.synthetic_batch(batch, res, G.z_dim, seed=1000 + rank, device=dev, masks='bernoulli')
+
+    def step():
+        return eval_harness.run_generator(G, x, z, noise_mode=a.noise_mode)
+
+    for _ in range(a.warmup):
+        step()
+    timer = kernels.KernelTimer()
+    kernels.set_timer(timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernels.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        ips = world * batch * a.steps / dt
+        summ = timer.summary().get('conv_mfma', dict(calls=0, ms=0.0, work=0.0))
+        ach = summ['work'] / (summ['ms'] * 1e-3) / 1e12 if summ['ms'] > 0 else 0.0
+        line = {
+            'metric': 'generator images/sec', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU',
+                       'resolution': res, 'batch_per_gpu': batch, 'global_batch': batch * world, 'noise_mode': a.noise_mode,
+                       'parallelism': f'batch-shard x{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all 3x3/1x1 implicit-GEMM launches)',
+                         'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'launches_per_step': summ['calls'] // max(a.steps, 1),
+                         'kernel_ms_per_step': round(summ['ms'] / max(a.steps, 1), 3),
+                         'gflop_per_step': round(summ['work'] / max(a.steps, 1) / 1e9, 1),
+                         'whole_forward_frac_of_fp32_mfma_peak': round(
+                             ips / world * GFLOP_PER_IMAGE.get(res, 0) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                line['cpu_baseline'] = cpu_baseline(res, a.cpu_images, seed=0)
+            except Exception as e:   # the baseline is informational; never lose the GPU number over it
+                line['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                        'sample': f'failed: {e!r}'}
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,106 @@
+/*
+ * libshgan_hip.so -- C ABI of the MI355X-native SH-GAN generator-forward kernels.
+ *
+ * Drop-in boundary: everything the reference reaches through its native plugin
+ * (`upfirdn2d_plugin.upfirdn2d`, lib/model_zoo/stylegan_utils/upfirdn2d.cpp:16,98-101) or through
+ * ATen/cuDNN from the Python ops of lib/model_zoo/{stylegan,shgan}.py is exported here with plain
+ * pointers and sizes.  Conventions:
+ *   - all tensors are dense NCHW fp32 device buffers owned by the caller (outputs and workspaces
+ *     included); no hidden allocation, no synchronisation; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), like at::cuda::getCurrentCUDAStream() in upfirdn2d.cpp:91;
+ *   - return value 0 = ok, <0 = error (SHG_ERR_*); shg_last_error() gives the message
+ *     (the reference raises RuntimeError from TORCH_CHECK / AT_CUDA_CHECK, upfirdn2d.cpp:19-36,92);
+ *   - thread-safe for distinct streams; the error string is thread-local.
+ */
+#ifndef SHGAN_HIP_H
+#define SHGAN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHG_OK 0
+#define SHG_ERR_ARG (-1)
+#define SHG_ERR_LAUNCH (-2)
+#define SHG_ERR_UNSUPPORTED (-3)
+
+int shg_abi_version(void);
+const char* shg_last_error(void);
+/* gcnArchName of device `dev` into buf; returns the CU count (256 on MI355X) or <0. */
+int shg_device_info(int dev, char* buf, int buflen);
+
+/* ---- A10: upfirdn2d -- replaces upfirdn2d.cpp:16 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
+ * x [N,C,H,W], f [fh,fw], y [N,C,OH,OW] with OH/OW from shg_upfirdn2d_out_size (rule of upfirdn2d.cpp:32-33). */
+int shg_upfirdn2d_out_size(int H, int W, int fh, int fw, int upx, int upy, int downx, int downy, int padx0, int padx1,
+                           int pady0, int pady1, int* OH, int* OW);
+int shg_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx, int upy,
+                      int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
+/* upfirdn2d fused with the tail of an up-sampling synthesis layer (stylegan.py:295-304, comodgan.py:326-327):
+ * y = lrelu_agc(FIR(x)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.
+ * noise_mode 0 none, 1 noise [OH,OW], 2 noise [N,OH,OW]; act 0 none / 1 lrelu_agc; clamp < 0 = no clamp. */
+int shg_upfirdn2d_epilogue_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
+                               int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                               const float* scale, const float* bias, const float* noise, int noise_mode, float noise_strength,
+                               int act, float alpha, float act_gain, float clamp, const float* residual, void* stream);
+
+/* ---- A11: bias + activation -- the `x + bias -> lrelu_agc(gain)` of stylegan.py:232-238 / common/utils.py:135-143,
+ * with the optional demodulation scale [N*C], noise and residual of the non-fused modconv path (stylegan.py:175-180). */
+int shg_bias_act_f32(const float* x, float* y, const float* scale, const float* bias, const float* noise, int noise_mode,
+                     float noise_strength, const float* residual, int N, int C, int HW, int act, float alpha, float gain,
+                     float clamp, void* stream);
+/* stylegan_utils/fma.py:15 -- y = a*b + c, elementwise on `total` floats. */
+int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long total, void* stream);
+/* stylegan.py:173 -- y[nc,:] = x[nc,:] * s[nc]. */
+int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int HW, void* stream);
+
+/* ---- A9/A8: convolution on the fp32 MFMA units -- replaces F.conv2d / F.conv_transpose2d reached through
+ * conv2d_gradfix.py:35-43,109-116 from conv2d_resample.py:26-51.
+ * Weight preparation: w [O,I,KH,KW] -> wt [I*KH*KW*OP] (GEMM layout, OP = O rounded up to a multiple of 4),
+ *   wscale [O] scratch, wsq [I*OP] (sum over taps of wt^2, for demodulation) or NULL.
+ *   demod=1: w * rsqrt(mean_{I,k,k} w^2) (stylegan.py:146) * gain; demod=0: w * gain (stylegan.py:227).
+ *   layout 0: plain / strided conv (flip=1 gives a true convolution, conv2d_resample.py:32-33);
+ *   layout 1: stride-2 transposed 3x3 conv, four sub-pixel phase blocks. */
+int shg_conv_weight_prep_f32(const float* w, float* wt, float* wscale, float* wsq, int O, int I, int KH, int KW, int OP,
+                             int demod, float gain, int layout, int flip, void* stream);
+/* y = act(out_scale[n,o] * conv(x * in_scale[n,i], wt) + noise*noise_strength + bias[o]) + residual.
+ * mode 0: stride 1, symmetric `pad` -> [NB,O,H+2pad-kh+1,..]; mode 1: stride 2 -> [(H+2pad-kh)/2+1];
+ * mode 2: transposed stride 2, pad 0 -> [2H+1, 2W+1] (conv2d_resample.py:130-137).
+ * Slot b uses the weight set wt + (b % wgroups)*wstride (wgroups > 1 = grouped conv, stylegan.py:187-190).
+ * Any of in_scale [NB,I], out_scale [NB,O], bias [O], noise, residual [NB,O,OH,OW] may be NULL. */
+int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB, int I, int O, int OP, int H, int W, int kh, int kw,
+                   int mode, int pad, int wgroups, long wstride, const float* in_scale, const float* out_scale,
+                   const float* bias, const float* noise, int noise_mode, float noise_strength, int act, float alpha, float gain,
+                   float clamp, const float* residual, void* stream);
+/* 1x1 convolution with I <= 8 input channels (encoder fromrgb, stylegan.py:640-642): y = act(W*wgain @ x + bias). */
+int shg_conv1x1_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int N, int I, int O, int HW, float wgain,
+                            int act, float alpha, float gain, float clamp, void* stream);
+/* torgb (stylegan.py:325-337) fused with the RGB skip up-sampling (comodgan.py:331-338, upfirdn2d.py:305-314):
+ * y[n,o] = sum_i w[o,i]*styles[n,i]*x[n,i] + bias[o] + upsample2d(base_up[n,o], f)   (O <= 4; base_up may be NULL). */
+int shg_torgb_f32(const float* x, const float* w, const float* styles, const float* bias, const float* base_up, const float* f,
+                  float* y, int N, int I, int O, int H, int W, void* stream);
+
+/* ---- A3/A2: dense (stylegan.py:87-98), normalize_2nd_moment (stylegan.py:343-344). */
+int shg_dense_f32(const float* x, const float* w, const float* b, float* y, int N, int K, int O, int ldx, int ldy, float wgain,
+                  float bgain, int act, float alpha, float gain, float clamp, void* stream);
+int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream);
+/* ---- A4: per-forward style side of modulated_conv2d (stylegan.py:147-155):
+ * s_out = styles*pre_gain*rsqrt(mean(.^2)) when demod (else styles*pre_gain); dcoef[n,o] = rsqrt(sum_i s^2*wsq[i,o] + 1e-8). */
+int shg_modconv_style_prep_f32(const float* styles, int ld, const float* wsq, float* s_out, float* dcoef, int N, int I, int O,
+                               int OP, int demod, float pre_gain, void* stream);
+
+/* ---- A16-A19: Spectral Hint Unit (shgan.py:312-336).
+ * rfft2(norm='forward') + row shift of [C] planes of 64x64 per sample (x + n*x_batch_stride) -> T [N,2C,64,33]. */
+int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N, int C, void* stream);
+/* band-weighted sum (bands > 1: Y [N,2C*bands,64,33], cw [bands,64,33]) -> Gaussian split -> unshift -> irfft2 at
+ * r = 4,8,16,32,64: out[l] planes [C][r][r] per sample at out[l] + n*out_batch_stride[l]; accumulate=1 adds in place
+ * (shgan.py:378-382).  gauss[l] = [r, r/2+1] table (shgan.py:281-310). */
+int shg_shu_split_irfft2_f32(const float* Y, const float* cw, const float* const* gauss, float* const* out,
+                             const long* out_batch_stride, int N, int C, int bands, int accumulate, void* stream);
+
+/* ---- A24: eval composite (lib/experiments/shgan_default.py:257-262): x4 [N,4,H,W], img [N,3,H,W] -> u8 [N,3,H,W]. */
+int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""ctypes loader for libshgan_hip.so (the C-ABI of include/shgan_hip.h).
+
+Replaces the reference's JIT plugin loader (lib/model_zoo/stylegan_utils/custom_ops.py:46-124):
+the library is prebuilt in-tree by ``sh-gan_amd/build.py``; there is NO fallback -- a missing or
+stale library raises, it never silently degrades to a PyTorch path (contrast upfirdn2d.py:18-27)."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: the .so binds to torch's already-loaded HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
+ABI_VERSION = 3
+
+c_fp = ctypes.c_void_p      # device pointers travel as void*
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_l = ctypes.c_long
+c_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argtypes (restype is int unless noted); mirrors include/shgan_hip.h one to one
+_SIGS = {
+    'shg_abi_version': [],
+    'shg_device_info': [c_i, ctypes.c_char_p, c_i],
+    'shg_upfirdn2d_out_size': [c_i] * 12 + [ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    'shg_upfirdn2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],
+    'shg_upfirdn2d_epilogue_f32': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_bias_act_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp],
+    'shg_fma_f32': [c_fp, c_fp, c_fp, c_fp, c_l, c_fp],
+    'shg_scale_channels_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_fp],
+    'shg_conv_weight_prep_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_fp],
+    'shg_conv2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_conv1x1_thin_in_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_fp],
+    'shg_torgb_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],
+    'shg_normalize_2nd_moment_f32': [c_fp, c_fp, c_i, c_i, c_f, c_fp],
+    'shg_modconv_style_prep_f32': [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'shg_shu_rfft2_shift_f32': [c_fp, c_l, c_fp, c_i, c_i, c_fp],
+    'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
+    'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+}
+
+_lib = None
+
+
+class ShgError(RuntimeError):
+    """Raised when a C-ABI call returns a negative status (mirrors TORCH_CHECK -> RuntimeError)."""
+
+
+def get_lib():
+    """Load (once) and return the ctypes handle.  Raises if the library is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run `python sh-gan_amd/build.py` '
+            '(or __graft_entry__.build()). There is deliberately no CPU / PyTorch fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
+        fn.argtypes = args
+        fn.restype = c_i
+    lib.shg_last_error.argtypes = []
+    lib.shg_last_error.restype = ctypes.c_char_p
+    ver = lib.shg_abi_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f'libshgan_hip.so ABI {ver} != expected {ABI_VERSION}: rebuild with sh-gan_amd/build.py')
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(list(_SIGS.keys()) + ['shg_last_error'])
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = get_lib().shg_last_error().decode(errors='replace')
+        raise ShgError(f'{what}: {msg} (code {rc})')

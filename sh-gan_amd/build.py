@@ -1,0 +1,77 @@
+"""Build recipe for libshgan_hip.so (gfx950 only, hipcc, in-tree output).
+
+``python sh-gan_amd/build.py`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a GPU.
+The shared object is linked WITHOUT an rpath to /opt/rocm so that, inside a PyTorch-ROCm process,
+it binds to the HIP runtime torch has already loaded (one runtime per process)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIBNAME = 'libshgan_hip.so'
+SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'shu.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, name), 'rb') as fh:
+            h.update(name.encode())
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, '.build_digest')
+    dig = _digest()
+    if not force and os.path.exists(lib_path()) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        if verbose:
+            print(f'[build] {LIBNAME} up to date')
+        return lib_path()
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print('[build]', ' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode(errors='replace'))
+            raise RuntimeError(f'hipcc failed on {src}')
+        if verbose and out.strip():
+            print(out.decode(errors='replace'))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path()] + objs
+    if verbose:
+        print('[build]', ' '.join(cmd))
+    subprocess.check_call(cmd)
+    for obj in objs:
+        os.remove(obj)
+    with open(stamp, 'w') as fh:
+        fh.write(dig)
+    return lib_path()
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,257 @@
+// HBM-bound pointwise / thin-channel kernels of the generator path (gfx950).
+//   * bias_act      : x + bias -> lrelu_agc             (stylegan.py:232-238,298-304; common/utils.py:135-143)
+//   * fromrgb 1x1   : conv 1x1 with tiny I (4) + bias + lrelu_agc   (stylegan.py:226-238 via comodgan.py:45-51)
+//   * torgb         : modulated 1x1 conv to 3 channels, no demod, + bias, fused with the FIR-upsampled
+//                     running RGB image  img = upsample2d(img_prev) + torgb(x)   (stylegan.py:325-337,
+//                     comodgan.py:331-338, upfirdn2d.py:279-314)
+//   * composite_u8  : x[:,1:4]*m + img*(1-m) -> *127.5+127.5 -> clamp -> uint8 (truncation)
+//                     (lib/experiments/shgan_default.py:257-262)
+//   * scale_channels / fma: the non-fused modconv pieces (stylegan.py:173-180, stylegan_utils/fma.py:15)
+#include "shg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// y = act((x [* scale[n,c]]) + noise*strength + bias[c]) [+ residual]   over [N,C,HW]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* x, float* y, const float* scale, const float* bias,
+                                                       const float* noise, int noise_mode, float noise_strength,
+                                                       const float* residual, int C, int HW, long total, int act, float alpha,
+                                                       float gain, float clamp) {
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const long nc = e / HW;
+        const int pix = (int)(e - nc * HW);
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        float v = x[e];
+        if (scale) v *= scale[nc];
+        if (noise_mode == 1) v += noise[pix] * noise_strength;
+        else if (noise_mode == 2) v += noise[n * HW + pix] * noise_strength;
+        if (bias) v += bias[c];
+        v = act ? shg_lrelu_agc(v, alpha, gain, clamp) : v * gain;
+        if (residual) v += residual[e];
+        y[e] = v;
+    }
+}
+
+extern "C" int shg_bias_act_f32(const float* x, float* y, const float* scale, const float* bias, const float* noise,
+                                int noise_mode, float noise_strength, const float* residual, int N, int C, int HW, int act,
+                                float alpha, float gain, float clamp, void* stream) {
+    SHG_CHECK_ARG(x && y, "bias_act: null pointer");
+    SHG_CHECK_ARG(N >= 0 && C >= 1 && HW >= 1, "bias_act: bad shape");
+    const long total = (long)N * C * HW;
+    if (total == 0) return SHG_OK;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, scale, bias, noise,
+                       noise ? noise_mode : 0, noise_strength, residual, C, HW, total, act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// c = a*b + c' with NCHW broadcasting of b:[N,C,1,1] and c':[N,1,H,W] or [H,W]  (stylegan.py:176)
+// handled by bias_act (scale = b, noise = c').  Plain elementwise fma for the generic op:
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fma_kernel(const float* a, const float* b, const float* c, float* y, long total) {
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) y[e] = fmaf(a[e], b[e], c[e]);
+}
+
+extern "C" int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long total, void* stream) {
+    SHG_CHECK_ARG(a && b && c && y, "fma: null pointer");
+    if (total <= 0) return SHG_OK;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, c, y, total);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Thin 1x1 convolution: y[n,o,p] = act(sum_i w[o,i]*wgain * x[n,i,p] * s[n,i] + bias[o]) [+ base]
+// for small I (fromrgb, I = 4) or small O (torgb, O = 3): one lane per 4 pixels, float4 I/O.
+// `base_up` (optional) is the previous-resolution RGB image [N,O,H/2,W/2]; it is FIR-upsampled x2
+// on the fly with the 4x4 filter `f` (pad [2,1,2,1], gain 4: upfirdn2d.py:305-314) and added.
+// ---------------------------------------------------------------------------------------------
+template <int MAXI>
+__global__ __launch_bounds__(256) void conv1x1_small_i_kernel(const float* x, const float* w, const float* bias, float* y, int I,
+                                                              int O, int HW, float wgain, int act, float alpha, float gain,
+                                                              float clamp) {
+    // fromrgb: each thread owns 4 consecutive pixels of one sample, loops over all output channels
+    const int n = blockIdx.y;
+    const long p4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p4 >= HW) return;
+    float4 xv[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        xv[i] = i < I ? *reinterpret_cast<const float4*>(x + ((long)n * I + i) * HW + p4) : make_float4(0, 0, 0, 0);
+    for (int o = 0; o < O; ++o) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            if (i < I) {
+                const float wv = w[o * I + i] * wgain;
+                acc.x += wv * xv[i].x; acc.y += wv * xv[i].y; acc.z += wv * xv[i].z; acc.w += wv * xv[i].w;
+            }
+        }
+        const float b = bias ? bias[o] : 0.f;
+        float r[4] = {acc.x + b, acc.y + b, acc.z + b, acc.w + b};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = act ? shg_lrelu_agc(r[k], alpha, gain, clamp) : r[k] * gain;
+        *reinterpret_cast<float4*>(y + ((long)n * O + o) * HW + p4) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+extern "C" int shg_conv1x1_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int N, int I, int O, int HW,
+                                       float wgain, int act, float alpha, float gain, float clamp, void* stream) {
+    SHG_CHECK_ARG(x && w && y, "conv1x1_thin_in: null pointer");
+    SHG_CHECK_ARG(I >= 1 && I <= 8, "conv1x1_thin_in: I must be in 1..8 (got %d)", I);
+    SHG_CHECK_ARG(HW % 4 == 0, "conv1x1_thin_in: H*W must be a multiple of 4");
+    SHG_CHECK_ARG(N >= 1 && N <= 65535, "conv1x1_thin_in: bad N");
+    dim3 grid(shg_cdiv(HW / 4, 256), N);
+    hipLaunchKernelGGL((conv1x1_small_i_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, I, O, HW, wgain, act,
+                       alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+template <int MAXO>
+__global__ __launch_bounds__(256) void torgb_kernel(const float* x, const float* w, const float* styles, const float* bias,
+                                                    const float* base_up, const float* f, float* y, int I, int O, int H, int W) {
+    // ws[o][i] = w[o,i] * styles[n,i] staged in LDS; one thread = one output pixel x (coalesced rows)
+    extern __shared__ float ws[];   // [MAXO][I]
+    const int n = blockIdx.z;
+    for (int k = threadIdx.x; k < O * I; k += 256) {
+        const int i = k % I;
+        ws[k] = w[k] * (styles ? styles[(long)n * I + i] : 1.f);
+    }
+    __syncthreads();
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.f;
+    const float* xp = x + (long)n * I * HW + pix;
+    int i = 0;
+    for (; i + 4 <= I; i += 4) {
+        const float x0 = xp[(long)i * HW], x1 = xp[(long)(i + 1) * HW], x2 = xp[(long)(i + 2) * HW], x3 = xp[(long)(i + 3) * HW];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o < O) acc[o] += ws[o * I + i] * x0 + ws[o * I + i + 1] * x1 + ws[o * I + i + 2] * x2 + ws[o * I + i + 3] * x3;
+    }
+    for (; i < I; ++i) {
+        const float x0 = xp[(long)i * HW];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o < O) acc[o] += ws[o * I + i] * x0;
+    }
+    const int oy = pix / W, ox = pix - oy * W;
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        if (o >= O) break;
+        float v = acc[o] + (bias ? bias[o] : 0.f);
+        if (base_up) {
+            // upsample2d(up=2, 4x4 filter, pad [2,1,2,1], gain 4): u = oy + ky - 2 must be even, iy = u/2
+            const int h2 = H >> 1, w2 = W >> 1;
+            const float* bp = base_up + ((long)n * O + o) * h2 * w2;
+            float u = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int uy = oy + ky - 2;
+                if (uy < 0 || (uy & 1)) continue;
+                const int iy = uy >> 1;
+                if (iy >= h2) continue;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ux = ox + kx - 2;
+                    if (ux < 0 || (ux & 1)) continue;
+                    const int ix = ux >> 1;
+                    if (ix >= w2) continue;
+                    u += bp[iy * w2 + ix] * (f[(3 - ky) * 4 + (3 - kx)] * 4.f);
+                }
+            }
+            v += u;
+        }
+        y[((long)n * O + o) * HW + pix] = v;
+    }
+}
+
+// y[n,o] = sum_i w[o,i]*styles[n,i]*x[n,i] + bias[o] (+ upsample2d(base_up, f)); O <= 4.
+extern "C" int shg_torgb_f32(const float* x, const float* w, const float* styles, const float* bias, const float* base_up,
+                             const float* f, float* y, int N, int I, int O, int H, int W, void* stream) {
+    SHG_CHECK_ARG(x && w && y, "torgb: null pointer");
+    SHG_CHECK_ARG(O >= 1 && O <= 4, "torgb: O must be in 1..4 (got %d)", O);
+    SHG_CHECK_ARG(!base_up || (f && H % 2 == 0 && W % 2 == 0), "torgb: base_up needs a 4x4 filter and even H, W");
+    SHG_CHECK_ARG(N >= 1 && N <= 65535, "torgb: bad N");
+    SHG_CHECK_ARG((size_t)O * I * 4 <= 64 * 1024, "torgb: I too large");
+    dim3 grid(shg_cdiv(H * W, 256), 1, N);
+    hipLaunchKernelGGL((torgb_kernel<4>), grid, dim3(256), sizeof(float) * O * I, (hipStream_t)stream, x, w, styles, bias, base_up,
+                       f, y, I, O, H, W);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x[n,i,:] *= s[n,i]   (non-fused modulation, stylegan.py:173)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* x, const float* s, float* y, int HW, long total) {
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) y[e] = x[e] * s[e / HW];
+}
+
+extern "C" int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int HW, void* stream) {
+    SHG_CHECK_ARG(x && s && y, "scale_channels: null pointer");
+    const long total = (long)NC * HW;
+    if (total <= 0) return SHG_OK;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, s, y, HW, total);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eval composite -> uint8   (shgan_default.py:257-262); x4 = [N,4,R,R] (ch0 = mask-0.5, ch1..3 = rgb*mask)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_u8_kernel(const float* x4, const float* img, uint8_t* out, int HW, long total4) {
+    // one thread = 4 consecutive pixels of one (n, c) plane
+    const long stride = (long)gridDim.x * 256;
+    const int HW4 = HW >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += stride) {
+        const long nc = e / HW4;
+        const int p4 = (int)(e - nc * HW4) * 4;
+        const long n = nc / 3;
+        const int c = (int)(nc - n * 3);
+        const float4 mk = *reinterpret_cast<const float4*>(x4 + (n * 4) * HW + p4);
+        const float4 kn = *reinterpret_cast<const float4*>(x4 + (n * 4 + 1 + c) * HW + p4);
+        const float4 gi = *reinterpret_cast<const float4*>(img + nc * HW + p4);
+        const float m[4] = {mk.x + 0.5f, mk.y + 0.5f, mk.z + 0.5f, mk.w + 0.5f};
+        const float k[4] = {kn.x, kn.y, kn.z, kn.w};
+        const float g[4] = {gi.x, gi.y, gi.z, gi.w};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // separate roundings, exactly as the PyTorch expression evaluates them
+            const float a = __fmul_rn(k[j], m[j]);
+            const float b = __fmul_rn(g[j], __fsub_rn(1.0f, m[j]));
+            float v = __fadd_rn(a, b);
+            v = __fadd_rn(__fmul_rn(v, 127.5f), 127.5f);
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            packed |= ((uint32_t)(uint8_t)(int)v) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(out + nc * HW + p4) = packed;
+    }
+}
+
+extern "C" int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int H, int W, void* stream) {
+    SHG_CHECK_ARG(x4 && img && out, "composite_u8: null pointer");
+    SHG_CHECK_ARG(N >= 0 && H >= 1 && W >= 1 && (H * W) % 4 == 0, "composite_u8: H*W must be a positive multiple of 4");
+    const long total4 = (long)N * 3 * (H * W / 4);
+    if (total4 == 0) return SHG_OK;
+    int grid = shg_cdiv(total4, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(composite_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x4, img, out, H * W, total4);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

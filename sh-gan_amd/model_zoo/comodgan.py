@@ -1,0 +1,217 @@
+"""Co-modulated GAN generator (encoder + co-modulated synthesis), host side.  Mirrors the registry
+names, constructor arguments, forward signatures and state_dict schema of the reference's
+lib/model_zoo/comodgan.py (``Mapping`` :30, ``encoder_block`` :34, ``encoder_epilogue`` :66,
+``Encoder`` :115, ``synthesis_block_first`` :207, ``synthesis_block`` :264, ``Synthesis`` :342,
+``Generator`` :435); every tensor op runs on libshgan_hip kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import kernels
+from .common.get_model import get_model, register
+from .stylegan import Generator as Generator_StyleGan
+from .stylegan import Mapping as Mapping_StyleGan
+from .stylegan import dense, discrim_block, discrim_epilogue, synthesis_layer, torgb_layer
+from .stylegan import synthesis_block as stylegan_synthesis_block
+from .stylegan_utils import upfirdn2d
+
+version = '0'
+symbol = 'comodgan'
+
+_ACT = 'lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)'
+
+
+@register('comodgan_mapping')
+class Mapping(Mapping_StyleGan):
+    pass
+
+
+class encoder_block(discrim_block):
+    """Down block that also returns its pre-downsample feature map (comodgan.py:38-64)."""
+
+    def forward(self, x, img):
+        if self.fromrgb is not None:
+            y = self.fromrgb(img.to(torch.float32))
+            x = kernels.bias_act(x, residual=y, act=False) if x is not None else y
+        if self.reslink:
+            y = self.skip(x, gain=np.sqrt(0.5))
+            feat = self.conv0(x)
+            x = kernels.bias_act(self.conv1(feat, gain=np.sqrt(0.5)), residual=y, act=False)
+        else:
+            feat = self.conv0(x)
+            x = self.conv1(feat)
+        return x, None, feat
+
+
+class encoder_epilogue(discrim_epilogue):
+    """4x4 tail of the encoder: conv -> flatten -> fc -> [out] -> dropout (comodgan.py:66-113)."""
+
+    def __init__(self, ic_n, oc_n, resolution, cmap_dim, rgb_n=None, mbstd_group_size=4, mbstd_c_n=1, activation=_ACT,
+                 reslink=True, use_dropout=True, has_extra_final_layer=True):
+        super().__init__(ic_n=ic_n, resolution=resolution, cmap_dim=cmap_dim, rgb_n=rgb_n, mbstd_group_size=mbstd_group_size,
+                         mbstd_c_n=mbstd_c_n, activation=activation, reslink=reslink)
+        self.fc = dense(ic_n * (resolution ** 2), oc_n, activation=activation)
+        self.out = dense(oc_n, oc_n, activation=None) if has_extra_final_layer else None
+        self.dropout = nn.Dropout(p=0.5) if use_dropout else None
+
+    def forward(self, x, img=None, cmap=None):
+        if self.fromrgb is not None:
+            x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+        feat = self.conv(x)
+        x = self.fc(feat.flatten(1))
+        if self.out is not None:
+            x = self.out(x)
+        if self.dropout is not None and self.training:
+            raise NotImplementedError('the HIP path is inference-only: call .eval() (dropout is identity in eval)')
+        if self.cmap_dim is not None:
+            raise NotImplementedError('conditional projection is not on the generator path')
+        return x, feat
+
+
+@register('comodgan_encoder', version)
+class Encoder(nn.Module):
+    def __init__(self, resolution=256, ic_n=3, oc_n=1024, ch_base=16384, ch_max=512, use_fp16_before_res=16,
+                 resample_filter=[1, 3, 3, 1], activation=_ACT, mbstd_group_size=4, mbstd_c_n=1, c_dim=None, cmap_dim=None,
+                 use_dropout=True, has_extra_final_layer=True):
+        super().__init__()
+        log2res = int(np.log2(resolution))
+        if 2 ** log2res != resolution:
+            raise ValueError
+        if use_fp16_before_res is not None and resolution > use_fp16_before_res:
+            raise NotImplementedError('the HIP path is fp32: pass use_fp16_before_res=None (as all shipped configs do)')
+        if c_dim is not None and c_dim > 0:
+            raise NotImplementedError('label-conditioned encoders are not on the SH-GAN path')
+        self.encode_res = [2 ** i for i in range(log2res, 1, -1)]
+        self.ic_n, self.ch_base, self.ch_max = ic_n, ch_base, ch_max
+        self.resample_filter, self.activation = resample_filter, activation
+        for idx, (ri, rj) in enumerate(zip(self.encode_res[:-1], self.encode_res[1:])):
+            ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
+            setattr(self, 'b{}'.format(ri), encoder_block(ci, ci, cj, rgb_n=(ic_n if idx == 0 else None),
+                                                        resample_filter=resample_filter, activation=activation,
+                                                        reslink=False, use_fp16=False))
+        self.mapping = None
+        c4 = min(ch_base // self.encode_res[-1], ch_max)
+        self.b4 = encoder_epilogue(c4, oc_n, resolution=4, cmap_dim=None, activation=activation,
+                                   mbstd_group_size=mbstd_group_size, mbstd_c_n=mbstd_c_n, reslink=False,
+                                   use_dropout=use_dropout, has_extra_final_layer=has_extra_final_layer)
+
+    def forward(self, img, c=None):
+        x = None
+        feats = {}
+        for res in self.encode_res[0:-1]:
+            x, img, feat = getattr(self, 'b{}'.format(res))(x, img)
+            feats[res] = feat
+        x, feat = self.b4(x, img, None)
+        feats[4] = feat
+        return x, feats
+
+
+class synthesis_block_first(nn.Module):
+    """4x4 block: fc(x_global) reshaped + encoder feature, one modulated conv, torgb (comodgan.py:207-262)."""
+
+    def __init__(self, w0_dim, oc_n, w_dim, resolution, rgb_n=None, activation=_ACT):
+        super().__init__()
+        self.resolution = resolution
+        self.fc = dense(w0_dim, oc_n * (resolution ** 2), activation=activation)
+        self.num_conv = 0
+        self.num_torgb = 0
+        self.conv = synthesis_layer(oc_n, oc_n, 3, w0_dim + w_dim, resolution=4, bias=True, activation=activation)
+        self.num_conv += 1
+        self.torgb = None
+        if rgb_n is not None:
+            self.torgb = torgb_layer(oc_n, rgb_n, 1, w0_dim + w_dim, activation=None)
+            self.num_torgb += 1
+
+    def forward(self, x, x0, ws, fused_modconv=None, noise_mode='random'):
+        w0 = x.to(torch.float32)
+        x = self.fc(w0).view(w0.size(0), -1, self.resolution, self.resolution)
+        x = kernels.bias_act(x, residual=x0, act=False)
+        w_iter = iter(ws.unbind(dim=1))
+        x = self.conv(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode)
+        img = None
+        if self.torgb is not None:
+            img = self.torgb(x, torch.cat([next(w_iter), w0], dim=1))
+        return x, img
+
+
+class synthesis_block(stylegan_synthesis_block):
+    """up-conv (+ encoder skip) -> conv -> RGB skip, every style = affine(cat[w, x_global]) (comodgan.py:264-340)."""
+
+    def __init__(self, ic_n, oc_n, w_dim, w0_dim, resolution, rgb_n, resample_filter=[1, 3, 3, 1], activation=_ACT,
+                 res_link=False, use_fp16=False):
+        if ic_n == 0:
+            raise ValueError
+        super().__init__(ic_n, oc_n, w_dim, resolution, rgb_n, resample_filter, activation, res_link, use_fp16)
+        self.conv0 = synthesis_layer(ic_n, oc_n, 3, w_dim=w_dim + w0_dim, resolution=resolution, up=2, activation=activation,
+                                     resample_filter=resample_filter, use_noise=True)
+        self.conv1 = synthesis_layer(oc_n, oc_n, 3, w_dim=w_dim + w0_dim, resolution=resolution, up=1, activation=activation,
+                                     resample_filter=None, use_noise=True)
+        if self.torgb is not None:
+            self.torgb = torgb_layer(oc_n, rgb_n, 1, w_dim=w_dim + w0_dim, activation=None)
+
+    def forward(self, x, x0, img, ws, w0, fused_modconv=None, noise_mode='random'):
+        w_iter = iter(ws.unbind(dim=1))
+        if self.res_link:
+            y = self.skip(x, gain=np.sqrt(0.5))
+        x = self.conv0(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode, residual=x0)
+        if self.res_link:
+            x = self.conv1(x, torch.cat([next(w_iter), w0], dim=1), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y)
+        else:
+            x = self.conv1(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode)
+        if self.torgb is not None:
+            img = self.torgb(x, torch.cat([next(w_iter), w0], dim=1), base_img=img, base_filter=self.resample_filter)
+        elif img is not None:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        return x, img
+
+
+@register('comodgan_synthesis', version)
+class Synthesis(nn.Module):
+    def __init__(self, w_dim=512, w0_dim=1024, resolution=256, rgb_n=3, ch_base=16384, ch_max=512, use_fp16_after_res=16,
+                 resample_filter=[1, 3, 3, 1], activation=_ACT):
+        super().__init__()
+        log2res = int(np.log2(resolution))
+        if 2 ** log2res != resolution:
+            raise ValueError
+        if use_fp16_after_res is not None and resolution > use_fp16_after_res:
+            raise NotImplementedError('the HIP path is fp32: pass use_fp16_after_res=None (as all shipped configs do)')
+        self.block_res = [2 ** i for i in range(2, log2res + 1)]
+        self.w_dim, self.resolution, self.rgb_n = w_dim, resolution, rgb_n
+        if resolution in (256, 512, 1024):        # comodgan.py:367-372
+            self.num_ws = {256: 14, 512: 16, 1024: 18}[resolution]
+        c4 = min(ch_base // self.block_res[0], ch_max)
+        self.b4 = synthesis_block_first(w0_dim, c4, w_dim, resolution=4, rgb_n=rgb_n, activation=activation)
+        for ri, rj in zip(self.block_res[:-1], self.block_res[1:]):
+            ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
+            setattr(self, 'b{}'.format(rj), synthesis_block(ci, cj, w_dim=w_dim, w0_dim=w0_dim, resolution=rj, rgb_n=rgb_n,
+                                                          resample_filter=resample_filter, activation=activation,
+                                                          res_link=False, use_fp16=False))
+
+    def forward(self, x, feats, ws, noise_mode='random'):
+        ws = ws.to(torch.float32)
+        block_ws = []
+        w_idx = 0
+        for res in self.block_res:   # a block's torgb shares the next block's first w (comodgan.py:399-403)
+            block = getattr(self, f'b{res}')
+            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+            w_idx += block.num_conv
+        w0 = x
+        x, img = self.b4(x, feats[4], block_ws[0], noise_mode=noise_mode)
+        for res, cur_ws in zip(self.block_res[1:], block_ws[1:]):
+            x, img = getattr(self, f'b{res}')(x, feats[res], img, cur_ws, w0, noise_mode=noise_mode)
+        return img
+
+
+@register('comodgan_generator', version)
+class Generator(Generator_StyleGan):
+    """x [N,4,R,R] (mask-0.5, rgb*mask), z [N,512], c [N,0] -> img [N,3,R,R] (comodgan.py:435-481)."""
+
+    def __init__(self, mapping, encoder, synthesis):
+        super().__init__(mapping, synthesis)
+        self.encoder = encoder if isinstance(encoder, nn.Module) else get_model()(encoder)
+        self.ic_n = self.encoder.ic_n
+
+    def forward(self, x, z, c, truncation_psi=1, truncation_cutoff=None, noise_mode='random'):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        x, feats = self.encoder(x)
+        return self.synthesis(x, feats, ws, noise_mode=noise_mode)

@@ -1,0 +1,535 @@
+"""StyleGAN2 building blocks of the SH-GAN generator, host side (PyTorch-ROCm nn.Modules whose
+forward enqueues libshgan_hip kernels).  Mirrors the module/operator surface and the state_dict
+schema of the reference's lib/model_zoo/stylegan.py (``conv2d`` :28, ``dense`` :66,
+``modulated_conv2d`` :103, ``conv2d_layer`` :195, ``synthesis_layer`` :243, ``torgb_layer`` :306,
+``Mapping`` :347, ``synthesis_block`` :436, ``Synthesis`` :523, ``Generator`` :581,
+``discrim_block`` :624, ``discrim_epilogue`` :707) so released checkpoints load with strict=True.
+
+MI355X-first differences:
+  * modulation is executed in the "scale activations" algebra (stylegan.py:172-181) for every value
+    of ``fused_modconv``: one batch-shared GEMM weight + per-sample in/out scales, instead of the
+    groups=batch grouped convolution with N materialised weight copies;
+  * weight layout transforms / demodulation tables are cached per layer and refreshed when the
+    parameter changes (version counter), so an eval forward does no per-call weight work;
+  * bias, noise, activation, skip-add, FIR and RGB-upsample are epilogues of the producing kernels.
+Inference only: there is no autograd support in the HIP path."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import kernels
+from .common import utils
+from .common.get_model import get_model, register
+from .stylegan_utils import conv2d_resample, fma, misc, upfirdn2d  # noqa: F401
+
+version = '0'
+symbol = 'stylegan'
+
+
+# ------------------------------------------------------------------------------------------------
+# small helpers
+# ------------------------------------------------------------------------------------------------
+
+def _make_act(activation):
+    return None if activation is None else utils.get_unit()(activation)()
+
+
+def _act_kwargs(act_obj, gain=1.0):
+    """kwargs for the fused epilogues from an activation object (only lrelu_agc can be fused)."""
+    if act_obj is None:
+        return dict(act=False, gain=gain)
+    if isinstance(act_obj, utils.lrelu_agc):
+        return dict(act=True, gain=gain, alpha=act_obj.alpha, act_gain=act_obj.gain, clamp=act_obj.clamp)
+    return None
+
+
+class _ParamCache:
+    """Derived device tensors (GEMM-layout weights, host copies of scalars) keyed by the identity and
+    version counter of the parameters they were computed from."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, tag, params, builder):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        hit = self.store.get(tag)
+        if hit is None or hit[0] != key:
+            hit = (key, builder())
+            self.store[tag] = hit
+        return hit[1]
+
+    def __deepcopy__(self, memo):
+        return _ParamCache()
+
+
+def _cache_of(module):
+    c = module.__dict__.get('_shg_cache')
+    if c is None:
+        c = _ParamCache()
+        module.__dict__['_shg_cache'] = c
+    return c
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+
+class conv2d(nn.Conv2d):
+    """nn.Conv2d with He-normal init and an optional runtime weight scale (stylegan.py:28-64);
+    used by the SHU for its 1x1 spectral convolution.  Forward = MFMA conv kernel."""
+
+    def __init__(self, *args, **kwargs):
+        use_wscale = kwargs.pop('use_wscale', False)
+        super().__init__(*args, **kwargs)
+        in_channels = args[0] if len(args) > 0 else kwargs['in_channels']
+        kernel_size = args[2] if len(args) > 2 else kwargs['kernel_size']
+        he_std = 1.0 / np.sqrt(in_channels * kernel_size * kernel_size)
+        self.weight_gain = he_std if use_wscale else 1
+        self.bias_gain = 1
+        nn.init.normal_(self.weight, mean=0.0, std=1.0 if use_wscale else he_std)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+
+    def prepped(self):
+        return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
+            self.weight.detach(), gain=self.weight_gain))
+
+    def forward(self, x, relu=False):
+        if self.padding_mode != 'zeros' or self.groups != 1 or tuple(self.dilation) != (1, 1):
+            raise NotImplementedError('conv2d: only zero padding, groups=1, dilation=1 run on the HIP path')
+        stride, pad = self.stride[0], self.padding[0]
+        mode = kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2
+        b = self.bias.detach() if self.bias is not None else None
+        return kernels.conv2d(x, self.prepped(), mode=mode, pad=pad, bias=b, act=relu, alpha=0.0, act_gain=1.0, clamp=None)
+
+
+class dense(nn.Module):
+    """y = act(x @ (W * lr/sqrt(in))^T + b*lr)   (stylegan.py:66-101)."""
+
+    def __init__(self, in_features, out_features, bias=True, bias_init=0, activation=None, lr_multi=1):
+        super().__init__()
+        self.activation = _make_act(activation)
+        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multi)
+        self.bias = nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multi / np.sqrt(in_features)
+        self.bias_gain = lr_multi
+        self.repr = 'dense({}, {}, bias={}, act={}, lr_multi={})'.format(in_features, out_features, bias, activation, lr_multi)
+
+    def forward(self, x, out=None):
+        ak = _act_kwargs(self.activation)
+        b = self.bias.detach() if self.bias is not None else None
+        if ak is None:   # non-fusable activation object
+            return self.activation(kernels.dense(x, self.weight.detach(), b, wgain=self.weight_gain, bgain=self.bias_gain))
+        return kernels.dense(x, self.weight.detach(), b, wgain=self.weight_gain, bgain=self.bias_gain, act=ak['act'], out=out)
+
+    def __repr__(self):
+        return self.repr
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True, _prepped=None, _epilogue=None):
+    """Modulated (and demodulated) convolution, signature of stylegan.py:103-113.
+
+    x [N,I,H,W], weight [O,I,k,k], styles [N,I], noise broadcastable to the output ([H',W'] or
+    [N,1,H',W']).  Both values of ``fused_modconv`` run the same kernels: the activations are scaled by
+    the normalised styles while the input tile is staged, the shared weight is pre-normalised
+    (stylegan.py:146), and the demodulation coefficient (stylegan.py:155) is applied in the epilogue.
+    ``_prepped`` / ``_epilogue`` are used by the layer classes to pass cached weights and to fuse
+    bias / activation / residual."""
+    batch_size = x.shape[0]
+    out_channels, in_channels, kh, kw = weight.shape
+    misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
+    misc.assert_shape(x, [batch_size, in_channels, None, None])
+    misc.assert_shape(styles, [batch_size, in_channels])
+    ep = dict(_epilogue or {})
+    if noise is not None and noise.ndim == 4 and noise.shape[0] == 1:
+        noise = noise[0, 0]
+
+    fast_plain = up == 1 and down == 1 and kh == kw and kh in (1, 3) and padding == kh // 2
+    fast_up = (up == 2 and down == 1 and kh == kw == 3 and padding == 1 and resample_filter is not None
+               and resample_filter.ndim == 2 and tuple(resample_filter.shape) == (4, 4))
+    if fast_plain or fast_up:
+        pw = _prepped
+        if pw is None:
+            # plain path: F.conv2d correlation unless flip_weight is False (conv2d_resample.py:32-33);
+            # up path: conv2d_resample hands (not flip_weight) to the transposed wrapper (:137)
+            pw = kernels.conv_weight_prep(weight, demod=demodulate, transposed=fast_up,
+                                          flip=(flip_weight if fast_up else not flip_weight))
+        s, d = kernels.modconv_style_prep(styles, pw, demod=demodulate)
+        if fast_plain:
+            return kernels.conv2d(x, pw, mode=kernels.MODE_SAME, pad=padding, in_scale=s, out_scale=d, noise=noise,
+                                  bias=ep.get('bias'), residual=ep.get('residual'),
+                                  **{k: v for k, v in ep.items() if k in ('act', 'gain', 'alpha', 'act_gain', 'clamp')})
+        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s)
+        fe = dict(scale=d.reshape(-1) if d is not None else None, noise=noise, bias=ep.get('bias'),
+                  residual=ep.get('residual'),
+                  **{k: v for k, v in ep.items() if k in ('act', 'gain', 'alpha', 'act_gain', 'clamp')})
+        return kernels.upfirdn2d(mid, resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0, epilogue=fe)
+
+    # generic geometry: explicit scale -> conv2d_resample -> demod/noise epilogue (stylegan.py:172-181)
+    pw_tmp = kernels.conv_weight_prep(weight, demod=demodulate)   # only for wsq / the normalised weight scale
+    s, d = kernels.modconv_style_prep(styles, pw_tmp, demod=demodulate)
+    wn = weight
+    if demodulate:
+        wn = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()
+    y = conv2d_resample.conv2d_resample(x=kernels.scale_channels(x, s.reshape(-1)), w=wn, f=resample_filter, up=up, down=down,
+                                        padding=padding, flip_weight=flip_weight)
+    return kernels.bias_act(y, scale=d.reshape(-1) if d is not None else None, noise=noise, bias=ep.get('bias'),
+                            residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
+
+
+class conv2d_layer(nn.Module):
+    """conv (+FIR up/down) -> +bias -> activation*gain   (stylegan.py:195-241)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation=None, up=1, down=1,
+                 resample_filter=[1, 3, 3, 1]):
+        super().__init__()
+        self.up = up
+        self.down = down
+        if resample_filter is not None:
+            self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        else:
+            self.resample_filter = None
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.activation = _make_act(activation)
+        self.weight = nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        self.bias = nn.Parameter(torch.zeros([out_channels])) if bias else None
+        self.repr = 'conv2d_layer({}, {}, kernal_size={}, bias={}, up={}, down={}, act={})'.format(
+            in_channels, out_channels, kernel_size, bias, up, down, activation)
+
+    def prepped(self):
+        # flip_weight = (up == 1): plain/strided convs are correlations, weights used as stored
+        return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
+            self.weight.detach(), gain=self.weight_gain))
+
+    def forward(self, x, gain=1):
+        ak = _act_kwargs(self.activation, gain)
+        b = self.bias.detach() if self.bias is not None else None
+        k = self.weight.shape[2]
+        fusable = ak is not None and self.up == 1 and self.down in (1, 2) and k in (1, 3)
+        if fusable and self.down == 2 and not (k == 3 and self.resample_filter is not None and self.resample_filter.ndim == 2):
+            fusable = False
+        if fusable:
+            if self.down == 1:
+                if k == 1 and self.weight.shape[1] <= 8 and (x.shape[2] * x.shape[3]) % 4 == 0:
+                    return kernels.conv1x1_thin_in(x, self.weight.detach().reshape(self.weight.shape[0], -1), b,
+                                                   wgain=self.weight_gain, act=ak['act'], gain=gain)
+                return kernels.conv2d(x, self.prepped(), mode=kernels.MODE_SAME, pad=self.padding, bias=b, **ak)
+            # low-pass with the resample filter, then the stride-2 convolution (conv2d_resample.py:116-120)
+            f = self.resample_filter
+            fw, fh = f.shape[1], f.shape[0]
+            p = self.padding
+            pads = [p + (fw - 1) // 2, p + (fw - 2) // 2, p + (fh - 1) // 2, p + (fh - 2) // 2]
+            y = kernels.upfirdn2d(x, f, padx0=pads[0], padx1=pads[1], pady0=pads[2], pady1=pads[3])
+            return kernels.conv2d(y, self.prepped(), mode=kernels.MODE_DOWN2, pad=0, bias=b, **ak)
+        # generic composition
+        w = self.weight.detach() * self.weight_gain
+        y = conv2d_resample.conv2d_resample(x=x, w=w, f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        if ak is None:
+            if b is not None:
+                y = kernels.bias_act(y, bias=b, act=False)
+            return self.activation(y, gain=gain)
+        return kernels.bias_act(y, bias=b, **ak)
+
+    def __repr__(self):
+        return self.repr
+
+
+class synthesis_layer(conv2d_layer):
+    """affine(w) -> modulated conv (x2 upsampling when up == 2) -> +noise -> +bias -> activation
+    (stylegan.py:243-304).  ``residual`` (extension) is added after the activation so the skip
+    connection of comodgan.py:320-327 costs no extra pass."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, w_dim, resolution, bias=True,
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2)', up=1, resample_filter=[1, 3, 3, 1], use_noise=True):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, activation=activation, up=up, down=1,
+                         resample_filter=resample_filter)
+        self.affine = dense(w_dim, in_channels, bias=True, bias_init=1, activation=None)
+        self.resolution = resolution
+        self.use_noise = use_noise
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros([out_channels]))
+        self.repr = 'synthesis_layer({}, {}, kernal_size={}, bias={}, up={}, act={}, noise={})'.format(
+            in_channels, out_channels, kernel_size, bias, up, activation, use_noise)
+
+    def prepped(self):
+        # demodulated layers ignore weight_gain (it cancels, stylegan.py:289-294); the up path is a
+        # transposed conv called with flip_weight=False -> no explicit flip (conv2d_resample.py:137)
+        return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
+            self.weight.detach(), demod=True, transposed=(self.up == 2)))
+
+    def _noise_strength_host(self):
+        return _cache_of(self).get('ns', [self.noise_strength], lambda: float(self.noise_strength.detach().cpu()))
+
+    def forward(self, x, w, fused_modconv=True, gain=1, noise_mode='random', residual=None):
+        if noise_mode not in ('random', 'const', 'none'):
+            raise AssertionError(f'bad noise_mode {noise_mode!r}')
+        styles = self.affine(w)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+        elif self.use_noise and noise_mode == 'const':
+            noise = self.noise_const
+        ak = _act_kwargs(self.activation, gain)
+        if ak is None or self.up not in (1, 2) or self.weight.shape[2] != 3:
+            raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
+        ns = self._noise_strength_host() if noise is not None else 0.0
+        pw = self.prepped()
+        s, d = kernels.modconv_style_prep(styles, pw, demod=True)
+        b = self.bias.detach()
+        if self.up == 1:
+            return kernels.conv2d(x, pw, mode=kernels.MODE_SAME, pad=self.padding, in_scale=s, out_scale=d, noise=noise,
+                                  noise_strength=ns, bias=b, residual=residual, **ak)
+        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s)
+        fe = dict(scale=d.reshape(-1), noise=noise, noise_strength=ns, bias=b, residual=residual, **ak)
+        return kernels.upfirdn2d(mid, self.resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0, epilogue=fe)
+
+
+class torgb_layer(conv2d_layer):
+    """Modulated 1x1 conv to RGB without demodulation (stylegan.py:306-337).  ``base_img`` /
+    ``base_filter`` (extension) fuse ``upsample2d(img) + torgb(x)`` of the skip architecture."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, w_dim, activation=None):
+        super().__init__(in_channels, out_channels, kernel_size, bias=True, activation=activation, up=1, down=1,
+                         resample_filter=None)
+        self.affine = dense(w_dim, in_channels, bias=True, bias_init=1, activation=None)
+
+    def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None):
+        styles = self.affine(w)
+        if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
+            raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
+        s, _ = kernels.modconv_style_prep(styles, None, demod=False, pre_gain=self.weight_gain)
+        wmat = self.weight.detach().reshape(self.weight.shape[0], -1)
+        return kernels.torgb(x, wmat, s, self.bias.detach(), base_up=base_img, f=base_filter)
+
+
+# ------------------------------------------------------------------------------------------------
+# mapping network
+# ------------------------------------------------------------------------------------------------
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    if dim != 1 or x.ndim != 2:
+        raise NotImplementedError('normalize_2nd_moment: HIP path handles [N,K] along dim 1')
+    return kernels.normalize_2nd_moment(x, eps)
+
+
+@register('stylegan2_mapping', version)
+class Mapping(nn.Module):
+    """z (and optional label c) -> w, broadcast to num_ws rows, optional truncation (stylegan.py:347-430)."""
+
+    def __init__(self, z_dim=512, c_dim=0, w_dim=512, num_ws=14, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', lr_multiplier=0.01, w_avg_beta=0.995):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = z_dim, c_dim, w_dim, num_ws
+        self.num_layers, self.w_avg_beta = num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        widths = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = dense(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', dense(widths[idx], widths[idx + 1], activation=activation, lr_multi=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        x = None
+        if self.z_dim > 0:
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            if self.w_avg_beta is None:
+                raise AssertionError('truncation needs w_avg')
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+# plain StyleGAN2 synthesis (kept for API completeness; the SH-GAN path uses comodgan.Synthesis)
+# ------------------------------------------------------------------------------------------------
+
+class synthesis_block(nn.Module):
+    def __init__(self, ic_n, oc_n, w_dim, resolution, rgb_n=None, resample_filter=[1, 3, 3, 1],
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', res_link=False, use_fp16=False):
+        super().__init__()
+        if use_fp16:
+            raise NotImplementedError('the HIP path is fp32 (all shipped SH-GAN configs run fp32)')
+        self.w_dim, self.resolution, self.use_fp16, self.res_link = w_dim, resolution, use_fp16, res_link
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = 0
+        self.num_torgb = 0
+        self.const = None
+        self.conv0 = None
+        if ic_n == 0:
+            self.const = nn.Parameter(torch.randn([oc_n, resolution, resolution]))
+        else:
+            self.conv0 = synthesis_layer(ic_n, oc_n, 3, w_dim=w_dim, resolution=resolution, up=2, activation=activation,
+                                         resample_filter=resample_filter, use_noise=True)
+            self.num_conv += 1
+        self.conv1 = synthesis_layer(oc_n, oc_n, 3, w_dim=w_dim, resolution=resolution, up=1, activation=activation,
+                                     resample_filter=None, use_noise=True)
+        self.num_conv += 1
+        self.torgb = None
+        if rgb_n is not None:
+            self.torgb = torgb_layer(oc_n, rgb_n, 1, w_dim=w_dim, activation=None)
+            self.num_torgb += 1
+        if ic_n != 0 and res_link:
+            self.skip = conv2d_layer(ic_n, oc_n, kernel_size=1, bias=False, up=2, down=1, resample_filter=resample_filter)
+
+    def forward(self, x, img, ws, fused_modconv=None, noise_mode='random'):
+        if self.const is not None:
+            x = self.const.detach().unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        if self.res_link:
+            y = self.skip(x, gain=np.sqrt(0.5))
+        w_iter = iter(ws.unbind(dim=1))
+        if self.conv0 is not None:
+            x = self.conv0(x, next(w_iter).contiguous(), noise_mode=noise_mode)
+        if self.res_link:
+            x = self.conv1(x, next(w_iter).contiguous(), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y)
+        else:
+            x = self.conv1(x, next(w_iter).contiguous(), noise_mode=noise_mode)
+        if self.torgb is not None:
+            img = self.torgb(x, next(w_iter).contiguous(), base_img=img, base_filter=self.resample_filter)
+        elif img is not None:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        return x, img
+
+
+@register('stylegan2_synthesis', version)
+class Synthesis(nn.Module):
+    def __init__(self, w_dim=512, resolution=256, rgb_n=3, ch_base=16384, ch_max=512, use_fp16_after_res=16,
+                 resample_filter=[1, 3, 3, 1], activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)'):
+        super().__init__()
+        log2res = int(np.log2(resolution))
+        if 2 ** log2res != resolution:
+            raise ValueError
+        self.w_dim, self.resolution, self.rgb_n = w_dim, resolution, rgb_n
+        self.block_res = [2 ** i for i in range(2, log2res + 1)]
+        self.num_ws = 0
+        for resi, resj in zip([None] + self.block_res[:-1], self.block_res):
+            ci = min(ch_base // resi, ch_max) if resi is not None else 0
+            cj = min(ch_base // resj, ch_max)
+            block = synthesis_block(ci, cj, w_dim=w_dim, resolution=resj, rgb_n=rgb_n, resample_filter=resample_filter,
+                                    activation=activation, res_link=False, use_fp16=False)
+            self.num_ws += block.num_conv
+            if resj == self.block_res[-1]:
+                self.num_ws += block.num_torgb
+            setattr(self, 'b{}'.format(resj), block)
+
+    def forward(self, ws, noise_mode='random'):
+        ws = ws.to(torch.float32)
+        x = img = None
+        w_idx = 0
+        for res in self.block_res:
+            block = getattr(self, f'b{res}')
+            x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), noise_mode=noise_mode)
+            w_idx += block.num_conv
+        return img
+
+
+@register('stylegan2_generator', version)
+class Generator(nn.Module):
+    """mapping + synthesis; sub-networks are modules or registry configs (stylegan.py:581-606)."""
+
+    def __init__(self, mapping, synthesis):
+        super().__init__()
+        self.mapping = mapping if isinstance(mapping, nn.Module) else get_model()(mapping)
+        self.synthesis = synthesis if isinstance(synthesis, nn.Module) else get_model()(synthesis)
+        if self.synthesis.num_ws != self.mapping.num_ws:
+            raise ValueError
+        self.num_ws = self.mapping.num_ws
+        self.z_dim, self.c_dim, self.w_dim = self.mapping.z_dim, self.mapping.c_dim, self.mapping.w_dim
+        self.img_resolution = self.synthesis.resolution
+        self.img_channels = self.synthesis.rgb_n
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, **synthesis_kwargs)
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator-style down blocks (the co-modulation encoder is built from these)
+# ------------------------------------------------------------------------------------------------
+
+class discrim_block(nn.Module):
+    """[fromrgb] -> conv0 3x3 -> conv1 3x3 stride-2 with FIR pre-filter (stylegan.py:624-684)."""
+
+    def __init__(self, ic_n, mc_n, oc_n, rgb_n=None, resample_filter=[1, 3, 3, 1],
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', reslink=False, use_fp16=False):
+        super().__init__()
+        if use_fp16:
+            raise NotImplementedError('the HIP path is fp32 (all shipped SH-GAN configs run fp32)')
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.fromrgb = None
+        if rgb_n is not None:
+            self.fromrgb = conv2d_layer(rgb_n, mc_n, 1, bias=True, activation=activation, up=1, down=1, resample_filter=None)
+        self.conv0 = conv2d_layer(ic_n, mc_n, 3, bias=True, activation=activation, up=1, down=1, resample_filter=None)
+        self.conv1 = conv2d_layer(mc_n, oc_n, 3, bias=True, activation=activation, up=1, down=2,
+                                  resample_filter=resample_filter)
+        self.reslink = reslink
+        if reslink:
+            self.skip = conv2d_layer(mc_n, oc_n, 1, bias=False, activation=None, up=1, down=2, resample_filter=resample_filter)
+        self.use_fp16 = use_fp16
+
+    def forward(self, x, img):
+        if self.fromrgb is not None:
+            y = self.fromrgb(img.to(torch.float32))
+            x = kernels.bias_act(x, residual=y, act=False) if x is not None else y
+        img = None
+        if self.reslink:
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv1(self.conv0(x), gain=np.sqrt(0.5))
+            x = kernels.bias_act(x, residual=y, act=False)
+        else:
+            x = self.conv1(self.conv0(x))
+        return x, img
+
+
+class discrim_epilogue(nn.Module):
+    """4x4 tail: conv 3x3 -> fc -> out (stylegan.py:707-755); minibatch-std is not on the generator
+    path (mbstd_c_n = 0 for the encoder) and is rejected here."""
+
+    def __init__(self, ic_n, resolution, cmap_dim, rgb_n=None, mbstd_group_size=4, mbstd_c_n=1,
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', reslink=True):
+        super().__init__()
+        if mbstd_c_n > 0:
+            raise NotImplementedError('minibatch_std_layer is discriminator-only and out of the generator hot path')
+        self.ic_n, self.cmap_dim, self.resolution, self.rgb_n, self.reslink = ic_n, cmap_dim, resolution, rgb_n, reslink
+        self.fromrgb = None
+        if rgb_n is not None:
+            self.fromrgb = conv2d_layer(rgb_n, ic_n, 1, bias=True, activation=activation, up=1, down=1, resample_filter=None)
+        self.mbstd = None
+        self.conv = conv2d_layer(ic_n + mbstd_c_n, ic_n, 3, bias=True, activation=activation, up=1, down=1,
+                                 resample_filter=None)
+        self.fc = dense(ic_n * (resolution ** 2), ic_n, activation=activation)
+        self.out = dense(ic_n, 1 if cmap_dim is None else cmap_dim, activation=None)
+
+    def forward(self, x, img=None, cmap=None):
+        if self.fromrgb is not None:
+            x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+        x = self.conv(x)
+        x = self.out(self.fc(x.flatten(1)))
+        if self.cmap_dim is not None:
+            raise NotImplementedError('conditional projection is not on the generator path')
+        return x

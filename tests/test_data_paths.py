@@ -1,0 +1,76 @@
+"""CPU: the product's integer paths (masks, sampler, re-interleave) are bit-exact with the reference's
+golden outputs; world_size-2 gloo run of the sharded index logic."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import shgan_amd  # noqa: F401
+from conftest import ROOT, load_golden
+from shgan_amd import data
+
+
+def test_random_mask_bit_exact():
+    g = load_golden('integer_paths')
+    for s in (64, 256, 512):
+        np.random.seed(0)
+        for i in range(4):
+            m = data.RandomMask(s, [0, 1])
+            assert m.shape == (1, s, s) and m.dtype == np.float32 and set(np.unique(m)) <= {0.0, 1.0}
+            bits = np.packbits(m.astype(np.uint8))
+            assert np.array_equal(bits, g[f'mask{s}_bits'][i]), (s, i)
+            assert hashlib.sha256(bits.tobytes()).hexdigest()[:16] == str(g[f'mask{s}_sha'][i])
+
+
+def test_sampler_and_zipzap_bit_exact():
+    g = load_golden('integer_paths')
+    for row in g['sampler_rows']:
+        n_items, world, rank = [int(v) for v in row[:3]]
+        smp = data.DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)
+        assert list(iter(smp)) == [int(v) for v in row[3:]]    # incl. the short-pad quirk when n_items < world/2
+    assert data.zipzap_arrange([[0, 2, 4, 6], [1, 3, 5, 7]]) == list(g['zipzap_out'])
+    assert data.zipzap_arrange([[0, 3, 6], [1, 4, 7], [2, 5]]) == list(g['zipzap_out_ragged'])
+    a = data.zipzap_arrange([np.arange(0, 8, 2).reshape(4, 1), np.arange(1, 6, 2).reshape(3, 1)])
+    assert a[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6]
+    # empty / ragged edge cases
+    assert list(iter(data.DistributedSampler([], num_replicas=2, rank=1, shuffle=False, extend=True))) == []
+    # reference quirk kept on purpose: the pad re-uses at most len(dataset) leading ids, so with 1 item and
+    # 4 ranks only ranks 0 and 1 receive a sample (ds_sampler.py:60-62)
+    got = [list(iter(data.DistributedSampler([0], num_replicas=4, rank=r, shuffle=False, extend=True))) for r in range(4)]
+    assert got == [[0], [0], [], []]
+
+
+def test_gloo_world2_sharding_covers_dataset_once():
+    """N > 1 path on CPU: two gloo ranks shard 11 items, all-gather their ids, re-interleave."""
+    script = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd import data
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+ids = list(iter(data.DistributedSampler(list(range(11)), shuffle=False, extend=True)))
+t = torch.tensor(ids)
+out = [torch.zeros_like(t) for _ in range(2)]
+dist.all_gather(out, t)
+order = data.zipzap_arrange([o.tolist() for o in out])
+assert order[:11] == list(range(11)), order
+smp = data.DistributedSampler(list(range(11)), shuffle=True, extend=True)
+a = torch.tensor(list(iter(smp)))
+g = [torch.zeros_like(a) for _ in range(2)]
+dist.all_gather(g, a)
+assert sorted(data.zipzap_arrange([x.tolist() for x in g])[:11]) == list(range(11))
+dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
