@@ -33,7 +33,9 @@ def cpu_baseline(resolution, n_images, seed):
     """Time the CPU oracle (torch fp32 CPU ops, all host threads) on a bounded sample."""
     import torch
     from oracle import shgan_oracle as orc
-    threads = os.cpu_count() or 1
+    # more threads than ~32 make torch's CPU grouped convolutions *slower* on a 256-core host
+    # (measured: 16 thr 0.94, 32 thr 0.97, 64 thr 0.59, 256 thr 0.04 img/s at 512x512), so cap at 32
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     sd = orc.init_state_dict(resolution, seed=seed)
     x, z, _, _ = orc.synthetic_batch(n_images, resolution, 512, seed=seed + 1)

@@ -232,11 +232,15 @@ __global__ __launch_bounds__(256) void composite_u8_kernel(const float* x4, cons
         uint32_t packed = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // separate roundings, exactly as the PyTorch expression evaluates them
-            const float a = __fmul_rn(k[j], m[j]);
-            const float b = __fmul_rn(g[j], __fsub_rn(1.0f, m[j]));
-            float v = __fadd_rn(a, b);
-            v = __fadd_rn(__fmul_rn(v, 127.5f), 127.5f);
+            // every product and sum is rounded separately, exactly as the PyTorch expression evaluates
+            // them op by op: fused multiply-adds would move values across the truncation boundary
+            // (HIP's __fmul_rn/__fadd_rn are plain operators, so contraction is switched off here).
+#pragma clang fp contract(off)
+            const float a = k[j] * m[j];
+            const float b = g[j] * (1.0f - m[j]);
+            float v = a + b;
+            v = v * 127.5f;
+            v = v + 127.5f;
             v = fminf(fmaxf(v, 0.f), 255.f);
             packed |= ((uint32_t)(uint8_t)(int)v) << (8 * j);
         }
