@@ -14,6 +14,7 @@
  */
 #ifndef SHGAN_HIP_H
 #define SHGAN_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -58,19 +59,27 @@ int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int
  * Weight preparation: w [O,I,KH,KW] -> wt [I*KH*KW*OP] (GEMM layout, OP = O rounded up to a multiple of 4),
  *   wscale [O] scratch, wsq [I*OP] (sum over taps of wt^2, for demodulation) or NULL.
  *   demod=1: w * rsqrt(mean_{I,k,k} w^2) (stylegan.py:146) * gain; demod=0: w * gain (stylegan.py:227).
- *   layout 0: plain / strided conv (flip=1 gives a true convolution, conv2d_resample.py:32-33);
- *   layout 1: stride-2 transposed 3x3 conv, four sub-pixel phase blocks. */
+ *   flip=1 gives a true convolution (w.flip([2,3]), conv2d_resample.py:32-33); one layout serves all modes. */
 int shg_conv_weight_prep_f32(const float* w, float* wt, float* wscale, float* wsq, int O, int I, int KH, int KW, int OP,
-                             int demod, float gain, int layout, int flip, void* stream);
+                             int demod, float gain, int flip, void* stream);
 /* y = act(out_scale[n,o] * conv(x * in_scale[n,i], wt) + noise*noise_strength + bias[o]) + residual.
  * mode 0: stride 1, symmetric `pad` -> [NB,O,H+2pad-kh+1,..]; mode 1: stride 2 -> [(H+2pad-kh)/2+1];
- * mode 2: transposed stride 2, pad 0 -> [2H+1, 2W+1] (conv2d_resample.py:130-137).
+ * mode 2: transposed stride 2, pad 0 -> [2H+1, 2W+1] (conv2d_resample.py:130-137); all four sub-pixel phases in one pass.
  * Slot b uses the weight set wt + (b % wgroups)*wstride (wgroups > 1 = grouped conv, stylegan.py:187-190).
  * Any of in_scale [NB,I], out_scale [NB,O], bias [O], noise, residual [NB,O,OH,OW] may be NULL. */
 int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB, int I, int O, int OP, int H, int W, int kh, int kw,
                    int mode, int pad, int wgroups, long wstride, const float* in_scale, const float* out_scale,
                    const float* bias, const float* noise, int noise_mode, float noise_strength, int act, float alpha, float gain,
-                   float clamp, const float* residual, void* stream);
+                   float clamp, const float* residual, int out_mode, void* workspace, size_t ws_bytes, void* stream);
+/* Split-K workspace (bytes) shg_conv2d_f32 can use for this problem; 0 = no split.  Small grids (4x4..16x16 layers)
+ * are split along the input channels so that they still fill 256 CUs. */
+size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W, int kh, int kw, int mode, int pad, int wgroups);
+/* mode 2 with out_mode 1 writes the four sub-pixel phases as planes [4][NB,O,H+1,W+1] (coalesced); this kernel applies the
+ * 4x4 FIR of conv2d_resample.py:138 (pad 1) straight from the planes and fuses the synthesis-layer tail:
+ * y [N,C,2H,2W] = lrelu_agc(FIR(mid)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.  H, W = low-res extents. */
+int shg_upfir_planar_f32(const float* mid, const float* f, float* y, int N, int C, int H, int W, int flip, float gain,
+                         const float* scale, const float* bias, const float* noise, int noise_mode, float noise_strength,
+                         int act, float alpha, float act_gain, float clamp, const float* residual, void* stream);
 /* 1x1 convolution with I <= 8 input channels (encoder fromrgb, stylegan.py:640-642): y = act(W*wgain @ x + bias). */
 int shg_conv1x1_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int N, int I, int O, int HW, float wgain,
                             int act, float alpha, float gain, float clamp, void* stream);

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -28,8 +28,11 @@ _SIGS = {
     'shg_bias_act_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp],
     'shg_fma_f32': [c_fp, c_fp, c_fp, c_fp, c_l, c_fp],
     'shg_scale_channels_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_fp],
-    'shg_conv_weight_prep_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_fp],
-    'shg_conv2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_conv_weight_prep_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_fp],
+    'shg_conv2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_i,
+                       c_fp, ctypes.c_size_t, c_fp],
+    'shg_conv2d_workspace_bytes': [c_i] * 10,
+    'shg_upfir_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_conv1x1_thin_in_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_torgb_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],
@@ -63,6 +66,7 @@ def get_lib():
         fn.restype = c_i
     lib.shg_last_error.argtypes = []
     lib.shg_last_error.restype = ctypes.c_char_p
+    lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
     ver = lib.shg_abi_version()
     if ver != ABI_VERSION:
         raise RuntimeError(f'libshgan_hip.so ABI {ver} != expected {ABI_VERSION}: rebuild with sh-gan_amd/build.py')

@@ -123,6 +123,64 @@ __global__ __launch_bounds__(256) void upfirdn_generic_kernel(const UfdParams p)
     }
 }
 
+// FIR after the all-phase transposed convolution (conv_mfma.hip, out_mode 1): the (2H+1)x(2W+1)
+// intermediate lives as four phase planes mid[(a*2+b)][nc][u][v] = full[2u+a][2v+b], each (H+1)x(W+1).
+// y[Y,X] = sum_{ky,kx<4} fk[ky][kx] * full[Y+ky-1][X+kx-1]   (pad [1,1,1,1], conv2d_resample.py:138).
+// One lane owns the 2x2 output block of low-res pixel (u,v): 25 coalesced plane loads -> 4 outputs.
+__global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
+    __shared__ float sf[16];
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        const int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
+        sf[threadIdx.x] = p.f[sy * 4 + sx] * p.gain;
+    }
+    __syncthreads();
+    float fr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fr[k] = sf[k];
+    const int v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int u = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= p.H || v >= p.W) return;
+    const int PW = p.W + 1;
+    const long P = (long)(p.H + 1) * PW;
+    int roff[5], coff[5];          // element offsets inside a plane; plane index contribution separately
+    int rpl[5], cpl[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int Y = 2 * u - 1 + r, X = 2 * v - 1 + r;
+        rpl[r] = (Y >= 0 && Y <= 2 * p.H) ? (Y & 1) : -1;
+        cpl[r] = (X >= 0 && X <= 2 * p.W) ? (X & 1) : -1;
+        roff[r] = (Y >> 1) * PW;
+        coff[r] = X >> 1;
+    }
+    for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
+        float m[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                float val = 0.f;
+                if (rpl[r] >= 0 && cpl[c] >= 0)
+                    val = p.x[((long)(rpl[r] * 2 + cpl[c]) * p.NC + nc) * P + roff[r] + coff[c]];
+                m[r][c] = val;
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float o2[2];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
+                o2[dx] = ufd_epilogue(p, acc, nc, 2 * u + dy, 2 * v + dx);
+            }
+            *reinterpret_cast<float2*>(p.y + ((long)nc * p.OH + 2 * u + dy) * p.OW + 2 * v) = make_float2(o2[0], o2[1]);
+        }
+    }
+}
+
 static int ufd_launch(UfdParams& p, hipStream_t s) {
     const int gz = p.NC < 32768 ? p.NC : 32768;
     if (p.upx == 1 && p.upy == 1 && p.dnx == 1 && p.dny == 1 && p.fh == 4 && p.fw == 4) {
@@ -190,4 +248,27 @@ extern "C" int shg_upfirdn2d_epilogue_f32(const float* x, const float* f, float*
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
     return ufd_launch(p, (hipStream_t)stream);
+}
+
+// Second half of the up-sampling synthesis layer: 4x4 FIR (pad 1, `gain`) over the four phase planes written by
+// shg_conv2d_f32(mode 2, out_mode 1) -> y [N,C,2H,2W], fused with scale/noise/bias/lrelu_agc/residual
+// (stylegan.py:295-304, comodgan.py:326-327).  H, W are the LOW-resolution extents.
+extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, int N, int C, int H, int W, int flip, float gain,
+                                    const float* scale, const float* bias, const float* noise, int noise_mode,
+                                    float noise_strength, int act, float alpha, float act_gain, float clamp,
+                                    const float* residual, void* stream) {
+    SHG_CHECK_ARG(mid && f && y, "upfir_planar: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1 && H >= 1 && W >= 1, "upfir_planar: bad shape");
+    SHG_CHECK_ARG(4L * N * C * (H + 1) * (W + 1) <= 2147483647L && 4L * N * C * H * W <= 2147483647L, "upfir_planar: tensor too large");
+    SHG_CHECK_ARG(noise_mode >= 0 && noise_mode <= 2, "upfir_planar: bad noise_mode");
+    UfdParams p{};
+    p.x = mid; p.f = f; p.y = y; p.NC = N * C; p.C = C; p.H = H; p.W = W; p.OH = 2 * H; p.OW = 2 * W;
+    p.fh = 4; p.fw = 4; p.upx = p.upy = p.dnx = p.dny = 1; p.px0 = p.py0 = 1; p.flip = flip ? 1 : 0; p.gain = gain;
+    p.scale = scale; p.bias = bias; p.noise = noise; p.residual = residual;
+    p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
+    p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
+    const int gz = p.NC < 32768 ? p.NC : 32768;
+    hipLaunchKernelGGL(fir_up_planar_kernel, dim3(shg_cdiv(W, 64), shg_cdiv(H, 4), gz), dim3(256), 0, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
 }

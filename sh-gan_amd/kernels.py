@@ -151,15 +151,14 @@ def composite_u8(x4, img):
 
 class PreppedWeight:
     """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq)."""
-    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'layout', 'groups')
+    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups')
 
-    def __init__(self, wt, wsq, o, i, op, kh, kw, layout, groups=1):
-        self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.layout, self.groups = \
-            wt, wsq, o, i, op, kh, kw, layout, groups
+    def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1):
+        self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.groups = wt, wsq, o, i, op, kh, kw, groups
 
 
-def conv_weight_prep(w, demod=False, gain=1.0, transposed=False, flip=False, groups=1):
-    """w [O,I,kh,kw] (or [G*Og, I, kh, kw] with ``groups``) -> PreppedWeight."""
+def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
+    """w [O,I,kh,kw] (or [G*Og, I, kh, kw] with ``groups``) -> PreppedWeight (one layout for all conv modes)."""
     w = _req(w, 'w')
     o_all, i, kh, kw = w.shape
     o = o_all // groups
@@ -172,9 +171,8 @@ def conv_weight_prep(w, demod=False, gain=1.0, transposed=False, flip=False, gro
     for g in range(groups):
         wg = w[g * o:(g + 1) * o]
         check(lib.shg_conv_weight_prep_f32(_ptr(wg), _ptr(wt[g]), _ptr(wscale), _ptr(wsq[g]) if demod else None, o, i, kh, kw,
-                                           op, int(bool(demod)), float(gain), 1 if transposed else 0, int(bool(flip)),
-                                           _stream()), 'conv_weight_prep')
-    return PreppedWeight(wt, wsq, o, i, op, kh, kw, 1 if transposed else 0, groups)
+                                           op, int(bool(demod)), float(gain), int(bool(flip)), _stream()), 'conv_weight_prep')
+    return PreppedWeight(wt, wsq, o, i, op, kh, kw, groups)
 
 
 MODE_SAME, MODE_DOWN2, MODE_UP2T = 0, 1, 2
@@ -214,36 +212,65 @@ def set_timer(t):
 
 
 def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=None, noise=None, noise_strength=1.0,
-           act=False, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0, residual=None):
-    """x [NB, I, H, W] (for grouped weights NB = N*groups slots) -> y [NB, O, OH, OW]."""
+           act=False, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0, residual=None, planar=False):
+    """x [NB, I, H, W] (for grouped weights NB = N*groups slots) -> y [NB, O, OH, OW].
+    MODE_UP2T with ``planar`` returns the four sub-pixel phase planes [4, NB, O, H+1, W+1] for ``upfir_planar``."""
     x = _req(x, 'x')
     nb, i, h, w = x.shape
     if i != pw.i:
         raise _lib.ShgError(f'conv2d: x has {i} channels, weights expect {pw.i}')
-    if (mode == MODE_UP2T) != (pw.layout == 1):
-        raise _lib.ShgError('conv2d: weight layout does not match the convolution mode')
     if mode == MODE_SAME:
         oh, ow = h + 2 * pad - pw.kh + 1, w + 2 * pad - pw.kw + 1
     elif mode == MODE_DOWN2:
         oh, ow = (h + 2 * pad - pw.kh) // 2 + 1, (w + 2 * pad - pw.kw) // 2 + 1
     else:
         oh, ow = 2 * h + 1, 2 * w + 1
-    y = torch.empty((nb, pw.o, oh, ow), device=x.device, dtype=torch.float32)
+    lib = _lib.get_lib()
+    if mode == MODE_UP2T and planar:
+        y = torch.empty((4, nb, pw.o, h + 1, w + 1), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((nb, pw.o, oh, ow), device=x.device, dtype=torch.float32)
     noise, nmode = _noise_args(noise, nb)
     a, al, g, cl = _act_args(act, gain, alpha, act_gain, clamp)
     residual = _req(residual, 'residual')
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.ShgError('conv2d: residual shape mismatch')
+    ws, ws_bytes = None, 0
+    if mode != MODE_UP2T:
+        ws_bytes = int(lib.shg_conv2d_workspace_bytes(nb, i, pw.o, h, w, pw.kh, pw.kw, mode, pad, pw.groups))
+        if ws_bytes:
+            ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
     t0 = _timer.begin() if _timer is not None else None
-    check(_lib.get_lib().shg_conv2d_f32(
+    check(lib.shg_conv2d_f32(
         _ptr(x), _ptr(pw.wt), _ptr(y), nb, i, pw.o, pw.op, h, w, pw.kh, pw.kw, mode, pad, pw.groups, pw.wt.shape[1],
         _ptr(_req(in_scale, 'in_scale')), _ptr(_req(out_scale, 'out_scale')), _ptr(_req(bias, 'bias')), _ptr(noise), nmode,
-        float(noise_strength), a, al, g, cl, _ptr(residual), _stream()), 'conv2d')
+        float(noise_strength), a, al, g, cl, _ptr(residual), 1 if planar else 0, _ptr(ws), ws_bytes, _stream()), 'conv2d')
     if t0 is not None:
         # algorithmic MACs: every (input pixel, tap) pair of the reference convolution, x2 flops
         taps = pw.kh * pw.kw
         pix = (h * w) if mode == MODE_UP2T else (oh * ow)
         _timer.end('conv_mfma', t0, 2.0 * nb * pw.o * i * taps * pix)
+    return y
+
+
+def upfir_planar(mid, f, scale=None, bias=None, noise=None, noise_strength=1.0, residual=None, act=False, gain=1.0,
+                 alpha=0.2, act_gain=SQRT2, clamp=256.0, fir_gain=4.0, flip=False):
+    """mid [4,N,C,H+1,W+1] (phase planes of the transposed conv) -> y [N,C,2H,2W]: 4x4 FIR (pad 1) + fused layer tail."""
+    mid = _req(mid, 'mid')
+    f = _req(f, 'f')
+    if mid.ndim != 5 or mid.shape[0] != 4 or tuple(f.shape) != (4, 4):
+        raise _lib.ShgError('upfir_planar: mid must be [4,N,C,H+1,W+1] and f 4x4')
+    _, n, c, hp, wp = mid.shape
+    h, w = hp - 1, wp - 1
+    y = torch.empty((n, c, 2 * h, 2 * w), device=mid.device, dtype=torch.float32)
+    noise, nmode = _noise_args(noise, n)
+    a, al, g, cl = _act_args(act, gain, alpha, act_gain, clamp)
+    residual = _req(residual, 'residual')
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise _lib.ShgError('upfir_planar: residual shape mismatch')
+    check(_lib.get_lib().shg_upfir_planar_f32(_ptr(mid), _ptr(f), _ptr(y), n, c, h, w, int(bool(flip)), float(fir_gain),
+                                              _ptr(_req(scale, 'scale')), _ptr(_req(bias, 'bias')), _ptr(noise), nmode,
+                                              float(noise_strength), a, al, g, cl, _ptr(residual), _stream()), 'upfir_planar')
     return y
 
 

@@ -94,7 +94,7 @@ class heterogeneous_filter(nn.Module):
         def build():
             i, ob = self.weight.shape
             w = self.weight.detach().contiguous()
-            return kernels.PreppedWeight(w.reshape(1, -1), None, ob, i, ob, 1, 1, 0, 1)
+            return kernels.PreppedWeight(w.reshape(1, -1), None, ob, i, ob, 1, 1, 1)
         return _cache_of(self).get('w', [self.weight], build)
 
     def band_conv(self, x):

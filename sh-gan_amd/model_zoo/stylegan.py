@@ -155,18 +155,16 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         if pw is None:
             # plain path: F.conv2d correlation unless flip_weight is False (conv2d_resample.py:32-33);
             # up path: conv2d_resample hands (not flip_weight) to the transposed wrapper (:137)
-            pw = kernels.conv_weight_prep(weight, demod=demodulate, transposed=fast_up,
-                                          flip=(flip_weight if fast_up else not flip_weight))
+            pw = kernels.conv_weight_prep(weight, demod=demodulate, flip=(flip_weight if fast_up else not flip_weight))
         s, d = kernels.modconv_style_prep(styles, pw, demod=demodulate)
         if fast_plain:
             return kernels.conv2d(x, pw, mode=kernels.MODE_SAME, pad=padding, in_scale=s, out_scale=d, noise=noise,
                                   bias=ep.get('bias'), residual=ep.get('residual'),
                                   **{k: v for k, v in ep.items() if k in ('act', 'gain', 'alpha', 'act_gain', 'clamp')})
-        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s)
-        fe = dict(scale=d.reshape(-1) if d is not None else None, noise=noise, bias=ep.get('bias'),
-                  residual=ep.get('residual'),
-                  **{k: v for k, v in ep.items() if k in ('act', 'gain', 'alpha', 'act_gain', 'clamp')})
-        return kernels.upfirdn2d(mid, resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0, epilogue=fe)
+        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s, planar=True)
+        return kernels.upfir_planar(mid, resample_filter, scale=d.reshape(-1) if d is not None else None, noise=noise,
+                                    bias=ep.get('bias'), residual=ep.get('residual'),
+                                    **{k: v for k, v in ep.items() if k in ('act', 'gain', 'alpha', 'act_gain', 'clamp')})
 
     # generic geometry: explicit scale -> conv2d_resample -> demod/noise epilogue (stylegan.py:172-181)
     pw_tmp = kernels.conv_weight_prep(weight, demod=demodulate)   # only for wsq / the normalised weight scale
@@ -261,8 +259,7 @@ class synthesis_layer(conv2d_layer):
     def prepped(self):
         # demodulated layers ignore weight_gain (it cancels, stylegan.py:289-294); the up path is a
         # transposed conv called with flip_weight=False -> no explicit flip (conv2d_resample.py:137)
-        return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
-            self.weight.detach(), demod=True, transposed=(self.up == 2)))
+        return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(self.weight.detach(), demod=True))
 
     def _noise_strength_host(self):
         return _cache_of(self).get('ns', [self.noise_strength], lambda: float(self.noise_strength.detach().cpu()))
@@ -286,9 +283,9 @@ class synthesis_layer(conv2d_layer):
         if self.up == 1:
             return kernels.conv2d(x, pw, mode=kernels.MODE_SAME, pad=self.padding, in_scale=s, out_scale=d, noise=noise,
                                   noise_strength=ns, bias=b, residual=residual, **ak)
-        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s)
-        fe = dict(scale=d.reshape(-1), noise=noise, noise_strength=ns, bias=b, residual=residual, **ak)
-        return kernels.upfirdn2d(mid, self.resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0, epilogue=fe)
+        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, in_scale=s, planar=True)      # four phase planes
+        return kernels.upfir_planar(mid, self.resample_filter, scale=d.reshape(-1), noise=noise, noise_strength=ns, bias=b,
+                                    residual=residual, **ak)
 
 
 class torgb_layer(conv2d_layer):

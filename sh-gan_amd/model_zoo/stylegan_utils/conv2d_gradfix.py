@@ -42,7 +42,7 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     ci_g, co_g = weight.shape[0] // groups, weight.shape[1]
     # torch layout [Cin, Cout/g, kh, kw] -> per group [Cout/g, Cin/g, kh, kw]
     wg = weight.reshape(groups, ci_g, co_g, 3, 3).transpose(1, 2).reshape(groups * co_g, ci_g, 3, 3).contiguous()
-    pw = kernels.conv_weight_prep(wg, transposed=True, groups=groups)
+    pw = kernels.conv_weight_prep(wg, groups=groups)
     y = kernels.conv2d(input.reshape(n * groups, ci_g, h, w), pw, mode=kernels.MODE_UP2T, bias=(bias if groups == 1 else None))
     y = y.reshape(n, -1, *y.shape[2:])
     if padding:

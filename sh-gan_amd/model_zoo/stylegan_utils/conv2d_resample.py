@@ -25,7 +25,7 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     if transpose:
         if stride != 2:
             raise NotImplementedError('transposed convolution is implemented for stride 2')
-        pw = kernels.conv_weight_prep(w, transposed=True, flip=not flip_weight, groups=groups)
+        pw = kernels.conv_weight_prep(w, flip=not flip_weight, groups=groups)
         y = kernels.conv2d(xs, pw, mode=kernels.MODE_UP2T)
         if padding:
             y = y[:, :, padding:y.shape[2] - padding, padding:y.shape[3] - padding].contiguous()

@@ -117,6 +117,10 @@ CONV_CASES = [
     (5, 16, 16, 4, 4, 3, 0, 1), (2, 33, 65, 17, 17, 3, 1, 0), (2, 16, 24, 33, 33, 3, 1, 0), (2, 12, 20, 8, 8, 3, 2, 0),
     (1, 64, 128, 16, 16, 3, 2, 0), (3, 9, 7, 5, 7, 3, 2, 0), (2, 64, 384, 66, 32, 1, 0, 0), (2, 10, 3, 9, 9, 1, 0, 0),
     (1, 128, 64, 64, 64, 3, 0, 1),
+    # small spatial grids with deep K -> split-K path (partials + fused reduce/epilogue)
+    (16, 256, 256, 4, 4, 3, 0, 1), (16, 512, 512, 8, 8, 3, 0, 1), (4, 192, 130, 16, 16, 3, 0, 1), (8, 128, 128, 17, 17, 3, 1, 0),
+    # all-phase transposed conv at sizes that cross tile borders
+    (2, 40, 70, 33, 35, 3, 2, 0), (16, 64, 64, 4, 4, 3, 2, 0),
 ]
 
 
@@ -134,7 +138,7 @@ def test_mfma_conv_vs_torch_cpu(mods, n, ci, co, h, w, k, mode, pad):
         ref = F.conv2d(x, wt, stride=2, padding=pad)
     else:
         ref = F.conv_transpose2d(x, wt.transpose(0, 1), stride=2)
-    pw = kk.conv_weight_prep(wt.to(DEV), transposed=(mode == 2))
+    pw = kk.conv_weight_prep(wt.to(DEV))
     y = kk.conv2d(x.to(DEV), pw, mode=mode, pad=pad)
     assert tuple(y.shape) == tuple(ref.shape)
     assert rel_err(c(y), ref.numpy()) < 2e-5
@@ -158,6 +162,29 @@ def test_mfma_conv_fused_epilogue(mods):
     y = kk.conv2d(x.to(DEV), pw, mode=0, pad=1, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV),
                   noise=noise.to(DEV), noise_strength=0.25, act=True, gain=0.5, residual=res.to(DEV))
     assert rel_err(c(y), ref.numpy()) < 2e-5
+
+
+def test_up_layer_planar_path_vs_oracle(mods):
+    """convT (all phases, planar) -> FIR-from-planes with the fused tail == oracle convT -> FIR -> noise/bias/act/skip."""
+    kk, orc = mods['kernels'], mods['orc']
+    rs = np.random.RandomState(21)
+    for n, ci, co, r in [(2, 12, 20, 8), (3, 70, 66, 16), (1, 32, 64, 33)]:
+        x = torch.from_numpy(rs.standard_normal((n, ci, r, r + 1)).astype(np.float32))
+        w = torch.from_numpy(rs.standard_normal((co, ci, 3, 3)).astype(np.float32))
+        f = torch.from_numpy(rs.rand(4, 4).astype(np.float32))                      # asymmetric filter
+        s_in = torch.from_numpy(rs.rand(n, ci).astype(np.float32) + 0.5)
+        s_out = torch.from_numpy(rs.rand(n, co).astype(np.float32) + 0.5)
+        bias = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+        noise = torch.from_numpy(rs.standard_normal((n, 1, 2 * r, 2 * r + 2)).astype(np.float32))
+        res = torch.from_numpy(rs.standard_normal((n, co, 2 * r, 2 * r + 2)).astype(np.float32))
+        ref = orc.conv2d_resample(x * s_in[:, :, None, None], w, f=f, up=2, padding=1, flip_weight=False)
+        ref = orc.lrelu_agc(ref * s_out[:, :, None, None] + noise * 0.4 + bias.view(1, -1, 1, 1), gain=0.8) + res
+        pw = kk.conv_weight_prep(w.to(DEV))
+        mid = kk.conv2d(x.to(DEV), pw, mode=kk.MODE_UP2T, in_scale=s_in.to(DEV), planar=True)
+        y = kk.upfir_planar(mid, f.to(DEV), scale=s_out.reshape(-1).to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
+                            noise_strength=0.4, residual=res.to(DEV), act=True, gain=0.8)
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert rel_err(c(y), ref.numpy()) < 2e-5, (n, ci, co, r)
 
 
 def test_modulated_conv2d_golden(mods):
