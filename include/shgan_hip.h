@@ -56,7 +56,8 @@ int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int
 
 /* ---- A9/A8: convolution on the fp32 MFMA units -- replaces F.conv2d / F.conv_transpose2d reached through
  * conv2d_gradfix.py:35-43,109-116 from conv2d_resample.py:26-51.
- * Weight preparation: w [O,I,KH,KW] -> wt [I*KH*KW*OP] (GEMM layout, OP = O rounded up to a multiple of 4),
+ * Weight preparation: w [O,I,KH,KW] -> wt [OP/64][IP*KH*KW][64] (GEMM layout in 64-column blocks; OP = O rounded up to a
+ *   multiple of 64, IP = I rounded up to a multiple of 32, padding zero filled),
  *   wscale [O] scratch, wsq [I*OP] (sum over taps of wt^2, for demodulation) or NULL.
  *   demod=1: w * rsqrt(mean_{I,k,k} w^2) (stylegan.py:146) * gain; demod=0: w * gain (stylegan.py:227).
  *   flip=1 gives a true convolution (w.flip([2,3]), conv2d_resample.py:32-33); one layout serves all modes. */

@@ -27,12 +27,14 @@
 // barrier gaps.  Small grids are split along K (partial sums to a workspace + a fused reduce/epilogue
 // kernel) so that 4x4..16x16 layers still fill 256 CUs.
 #include "shg_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copies may not)
 
 struct ConvParams {
     const float* x;          // [NB, I, H, W]
-    const float* wt;         // prepped weights [wgroups][I][NTAPS][OP]
+    const float* wt;         // prepped weights [wgroups][OP/64][IP*NTAPS][64]  (column-blocked: a tile's chunk is contiguous)
     float* y;                // output (see out_mode)
     float* part;             // split-K partial sums [ksplit][...same indexing as y...] or null
     const float* in_scale;   // [NB, I] or null
@@ -40,7 +42,8 @@ struct ConvParams {
     const float* bias;       // [O] or null
     const float* noise;      // see noise_mode
     const float* residual;   // like y, added after the activation
-    int NB, I, O, OP;
+    int NB, I, O, OP;        // OP = O rounded up to 64
+    int IPK;                 // IP*NTAPS rows per 64-column weight block (IP = I rounded up to 32)
     int H, W;
     int OHp, OWp;            // output grid computed by this launch
     int OHt, OWt;            // full output tensor extent
@@ -59,6 +62,8 @@ struct ConvParams {
     int act;
     float alpha, gain, clamp;
     int tap_off[9];          // LDS patch offset (in patch elements) of tap t
+    int dbg;                 // ablation bits for kernel timing studies (SHG_CONV_DBG, default 0): 1 skip W loads, 2 skip X loads,
+                             // 4 skip LDS stores, 8 skip barriers, 16 skip epilogue
 };
 
 // Bijective XCD-aware remap (blocks b, b+8, ... share an XCD and its L2): every XCD walks a
@@ -79,8 +84,12 @@ __device__ __forceinline__ float conv_epilogue(const ConvParams& p, float v, int
     return v;
 }
 
-template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP>
-__global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvParams p) {
+// DB = double-buffered LDS (one barrier per chunk, staging hand-over in the middle of the MFMA block; meant for
+// 8-wave workgroups, 1 per CU, whose two wave groups hand over at different times).  !DB = single LDS buffer,
+// two barriers per chunk, small footprint: 3 workgroups per CU cover each other's barrier / staging gaps.
+// OCC = waves per SIMD the register allocator must leave room for.
+template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP, bool DB, int OCC>
+__global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BO = MO * 32 * WO;
     constexpr int NT = WO * WP * 64;
     constexpr int ROWS = KC * NTAPS;
@@ -89,8 +98,15 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvPa
     constexpr int V4 = ROWS * BO / 4;
     constexpr int PER = (V4 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                // [ROWS][BO]
-    float* Xl = smem + ROWS * BO;    // [PATCH][XP]
+    // LDS: two weight buffers [ROWS][BO], the tile's input scales [TN][i_per_slice] (modulated layers only),
+    // two patch buffers [PATCH][XP].  Chunk c lives in buffer c&1: while chunk c is multiplied, chunk c+1 is
+    // written to the other buffer in the middle of the MFMA block -> one barrier per chunk, no exposed store.
+    constexpr int WSZ = ROWS * BO;
+    constexpr int NBUF = DB ? 2 : 1;
+    float* Wl = smem;
+    float* Sl = smem + NBUF * WSZ;
+    float* Xl = Sl + (p.in_scale ? (1 << p.tn_log2) * p.i_per_slice : 0);
+    const int XSZ = XP * p.PATCH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -113,6 +129,16 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvPa
     const int i_begin = kslice * p.i_per_slice;
     const int i_end = min(p.I, i_begin + p.i_per_slice);
 
+    // ---- input scales (styles) of the tile's images -> LDS, applied when the patch is written to LDS
+    if (p.in_scale) {
+        const int span = i_end - i_begin;
+        for (int e = tid; e < TN * span; e += NT) {
+            const int tn = e / span, ii = e - tn * span;
+            const int n = n0 + tn;
+            Sl[tn * p.i_per_slice + ii] = n < p.NB ? p.in_scale[(long)n * p.I + i_begin + ii] : 0.f;
+        }
+    }
+
     // ---- per-lane staging assignment: patch elements q = tid + k*NT -> global offset (or -1 = padding)
     int xoff[XQ], xsn[XQ];
 #pragma unroll
@@ -125,7 +151,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvPa
         const int iy = oy0 * p.S + p.dy0 + py, ix = ox0 * p.S + p.dx0 + px;
         const bool ok = (q < p.PATCH) && (n < p.NB) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
         xoff[k] = ok ? (n * p.I * HW + iy * p.W + ix) : -1;
-        xsn[k] = n * p.I;
+        xsn[k] = tn * p.i_per_slice;      // row of this element's image in the LDS scale table
     }
 
     // ---- per-lane B-fragment base inside the patch (pixel j of the tile -> patch element)
@@ -153,110 +179,177 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvPa
 
     const float* wbase = p.wt + (long)(p.wgroups > 1 ? (n0 % p.wgroups) : 0) * p.wstride;
 
-    float4 wv[PER];
+    // ---- staging registers and their per-lane constant offsets.  Staging is cut into small "pieces"
+    // (one weight float4, or four channels of one patch element) that are slotted between the MFMA
+    // groups of the running chunk: the MFMA pipe never waits for a monolithic copy phase.
+    // Loads are unconditional (addresses clamped into valid memory; the weight buffer is zero padded to a
+    // multiple of 32 input channels by shg_conv_weight_prep_f32) and nothing is computed on loaded values
+    // until they are written to LDS, so they stay in flight for a whole chunk.
+    f32x4 wv[PER];
     float xv[XQ][KC];
-    auto load_chunk = [&](int i0) {
+    unsigned wl[PER], xo[XQ];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = tid + k * NT;
-            const int row = e / (BO / 4), c4 = e - row * (BO / 4);
-            const int o = o0 + c4 * 4;
-            const long grow = (long)i0 * NTAPS + row;
-            wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < V4 && grow < (long)i_end * NTAPS && o < p.OP)
-                wv[k] = *reinterpret_cast<const float4*>(wbase + grow * p.OP + o);
-        }
+    for (int k = 0; k < PER; ++k) {
+        const int e = min(tid + k * NT, V4 - 1);
+        const int row = e / (BO / 4), c4 = e - row * (BO / 4);
+        const int o = min(o0 + c4 * 4, p.OP - 4);
+        wl[k] = (unsigned)(((o >> 6) * p.IPK + row) * 64 + (o & 63));
+    }
 #pragma unroll
-        for (int k = 0; k < XQ; ++k) {
+    for (int k = 0; k < XQ; ++k) xo[k] = xoff[k] >= 0 ? (unsigned)xoff[k] : 0u;
+    constexpr int XG = KC / 4;                       // 4-channel groups per patch element
+    constexpr int NPIECE = PER + XQ * XG;
+
+    auto piece_load = [&](int j, int i0) __attribute__((always_inline)) {
+        if (j < PER) {
+            if (!(p.dbg & 1)) wv[j] = *reinterpret_cast<const f32x4*>(wbase + (size_t)i0 * NTAPS * 64 + wl[j]);
+        } else {
+            const int k = (j - PER) / XG, g = (j - PER) % XG;
+            if (!(p.dbg & 2)) {
 #pragma unroll
-            for (int ic = 0; ic < KC; ++ic) {
-                const int i = i0 + ic;
-                float v = 0.f;
-                if (xoff[k] >= 0 && i < i_end) {
-                    v = p.x[xoff[k] + i * HW];
-                    if (p.in_scale) v *= p.in_scale[xsn[k] + i];
+                for (int c = 0; c < 4; ++c) {
+                    const int ic = g * 4 + c;
+                    xv[k][ic] = p.x[xo[k] + (unsigned)(min(i0 + ic, p.I - 1) * HW)];
                 }
-                xv[k][ic] = v;
             }
         }
     };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = tid + k * NT;
-            if (e < V4) *reinterpret_cast<float4*>(Wl + e * 4) = wv[k];
-        }
-#pragma unroll
-        for (int k = 0; k < XQ; ++k) {
+    auto piece_store = [&](int j, int i0, int buf) __attribute__((always_inline)) {
+        if (p.dbg & 4) return;
+        if (j < PER) {
+            const int e = tid + j * NT;
+            if (e < V4) *reinterpret_cast<f32x4*>(Wl + buf * WSZ + e * 4) = wv[j];
+        } else {
+            const int k = (j - PER) / XG, g = (j - PER) % XG;
             const int q = tid + k * NT;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+            if (p.in_scale) sc = *reinterpret_cast<const f32x4*>(Sl + xsn[k] + (i0 - i_begin) + g * 4);
             if (q < p.PATCH) {
+                float* dst = Xl + buf * XSZ + q * XP + g * 4;
 #pragma unroll
-                for (int ic = 0; ic < KC; ++ic) Xl[q * XP + ic] = xv[k][ic];
+                for (int c = 0; c < 4; ++c)
+                    dst[c] = (xoff[k] >= 0 && i0 + g * 4 + c < i_end) ? xv[k][g * 4 + c] * sc[c] : 0.f;
             }
         }
     };
 
-    load_chunk(i_begin);
-    store_chunk();
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin);
+    __syncthreads();                 // scale table visible
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) piece_store(j, i_begin, 0);
+    if (DB && i_begin + KC < i_end) {
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin + KC);
+    }
     __syncthreads();
 
-    for (int i0 = i_begin; i0 < i_end; i0 += KC) {
-        const bool more = i0 + KC < i_end;
-        if (more) load_chunk(i0 + KC);      // global loads stay in flight across the MFMA block
+    int cur = 0;
+    for (int i0 = i_begin; i0 < i_end; i0 += KC, cur ^= (DB ? 1 : 0)) {
+        const bool more = i0 + KC < i_end;          // DB: registers hold chunk i0+KC (loads issued one chunk ago)
+        const bool more2 = i0 + 2 * KC < i_end;
+        if (!DB && more) {                           // single buffer: prefetch the next chunk into registers now
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) piece_load(j, i0 + KC);
+        }
+        const float* wa_c = wa + cur * WSZ;
+        const float* xb_c[NP];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) xb_c[np] = xbase[np] + cur * XSZ;
+        // hand-over: park the prefetched chunk i0+KC in the other LDS buffer, then reuse the staging registers
+        // for chunk i0+2KC.  It is a VALU/LDS/VMEM-heavy block during which this wave issues no MFMA; with
+        // two waves per SIMD (8-wave workgroups) the two wave groups do it at different points of the chunk,
+        // so the partner wave's MFMAs keep the pipe busy meanwhile.
+        auto handover = [&]() __attribute__((always_inline)) {
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < NPIECE; ++j) piece_store(j, i0 + KC, cur ^ 1);
+            }
+            if (more2) {
+#pragma unroll
+                for (int j = 0; j < NPIECE; ++j) piece_load(j, i0 + 2 * KC);
+            }
+        };
+        constexpr bool TWO_GROUPS = DB && (WO * WP == 8);
+        const int grp = wave >> 2;                   // waves w and w+4 share a SIMD
 
         if constexpr (!UP) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
+            // operands of step s+1 are read from LDS while the MFMAs of step s execute (explicit register
+            // double buffering: a single wave per SIMD then never stalls on LDS latency)
+            constexpr int NSTEP = NTAPS * (KC / 2);
+            float a[2][MO], b[2][NP];
+            auto fetch = [&](int step, int buf) __attribute__((always_inline)) {
+                const int t = step / (KC / 2), c2 = step % (KC / 2);
                 const int toff = p.tap_off[t] * XP;
 #pragma unroll
-                for (int c2 = 0; c2 < KC / 2; ++c2) {
-                    float a[MO], b[NP];
+                for (int mo = 0; mo < MO; ++mo) a[buf][mo] = wa_c[((c2 * 2) * NTAPS + t) * BO + mo * 32];
 #pragma unroll
-                    for (int mo = 0; mo < MO; ++mo) a[mo] = wa[((c2 * 2) * NTAPS + t) * BO + mo * 32];
+                for (int np = 0; np < NP; ++np) b[buf][np] = xb_c[np][toff + c2 * 2];
+            };
+            fetch(0, 0);
 #pragma unroll
-                    for (int np = 0; np < NP; ++np) b[np] = xbase[np][toff + c2 * 2];
+            for (int step = 0; step < NSTEP; ++step) {
+                if (step + 1 < NSTEP) fetch(step + 1, (step + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
-                    for (int mo = 0; mo < MO; ++mo)
+                for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
-                        for (int np = 0; np < NP; ++np)
-                            acc[0][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mo], b[np], acc[0][mo][np], 0, 0, 0);
+                    for (int np = 0; np < NP; ++np)
+                        acc[0][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][mo], b[step & 1][np], acc[0][mo][np], 0, 0, 0);
+                if (DB && (TWO_GROUPS ? (step == NSTEP / 4 || step == (3 * NSTEP) / 4) : (step == NSTEP / 2))) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!TWO_GROUPS || grp == (step == NSTEP / 4 ? 0 : 1)) handover();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
             // tap t = ky*3+kx feeds phase (ky&1, kx&1) from the input pixel shifted by (ky==2 ? -1 : 0, kx==2 ? -1 : 0);
             // the patch origin is (u0-1, v0-1), so shift (sy,sx) sits at patch offset (1+sy)*PW + (1+sx)
-            const int s00 = (p.PW + 1) * XP, s01 = p.PW * XP, s10 = XP, s11 = 0;
+            const int sh[4] = {(p.PW + 1) * XP, p.PW * XP, XP, 0};     // (0,0) (0,-1) (-1,0) (-1,-1)
+            constexpr int PHASE[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
+            constexpr int SHIFT[9] = {0, 0, 1, 0, 0, 1, 2, 2, 3};
+            constexpr int NSLOT = 9 * (KC / 2);
+            float a[2][MO], b[2][4][NP];
+            auto fetch_a = [&](int slot, int buf) __attribute__((always_inline)) {
+                const int c2 = slot / 9, t = slot % 9;
 #pragma unroll
-            for (int c2 = 0; c2 < KC / 2; ++c2) {
-                float b[4][NP];
+                for (int mo = 0; mo < MO; ++mo) a[buf][mo] = wa_c[((c2 * 2) * 9 + t) * BO + mo * 32];
+            };
+            auto fetch_b = [&](int c2, int buf) __attribute__((always_inline)) {
 #pragma unroll
-                for (int np = 0; np < NP; ++np) {
-                    b[0][np] = xbase[np][s00 + c2 * 2];   // ( 0, 0)
-                    b[1][np] = xbase[np][s01 + c2 * 2];   // ( 0,-1)
-                    b[2][np] = xbase[np][s10 + c2 * 2];   // (-1, 0)
-                    b[3][np] = xbase[np][s11 + c2 * 2];   // (-1,-1)
-                }
+                for (int np = 0; np < NP; ++np)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    constexpr int PHASE[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
-                    constexpr int SHIFT[9] = {0, 0, 1, 0, 0, 1, 2, 2, 3};
+                    for (int q = 0; q < 4; ++q) b[buf][q][np] = xb_c[np][sh[q] + c2 * 2];
+            };
+            fetch_b(0, 0);
+            fetch_a(0, 0);
 #pragma unroll
-                    for (int mo = 0; mo < MO; ++mo) {
-                        const float a = wa[((c2 * 2) * 9 + t) * BO + mo * 32];
+            for (int slot = 0; slot < NSLOT; ++slot) {
+                const int c2 = slot / 9, t = slot % 9;
+                if (slot + 1 < NSLOT) fetch_a(slot + 1, (slot + 1) & 1);
+                if (t == 4 && c2 + 1 < KC / 2) fetch_b(c2 + 1, (c2 + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int np = 0; np < NP; ++np)
-                            acc[PHASE[t]][mo][np] =
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[SHIFT[t]][np], acc[PHASE[t]][mo][np], 0, 0, 0);
-                    }
+                for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                    for (int np = 0; np < NP; ++np)
+                        acc[PHASE[t]][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            a[slot & 1][mo], b[c2 & 1][SHIFT[t]][np], acc[PHASE[t]][mo][np], 0, 0, 0);
+                if (DB && (TWO_GROUPS ? (slot == NSLOT / 4 || slot == (3 * NSLOT) / 4) : (slot == NSLOT / 2))) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!TWO_GROUPS || grp == (slot == NSLOT / 4 ? 0 : 1)) handover();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        __syncthreads();
-        if (more) {
-            store_chunk();
+        if (!(p.dbg & 8)) __syncthreads();
+        if (!DB && more) {                           // single buffer: everyone is done reading -> overwrite, publish
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) piece_store(j, i0 + KC, 0);
             __syncthreads();
         }
     }
+    if (p.dbg & 16) return;
 
     // ---- epilogue: D[row = out channel][col = pixel]; row = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
@@ -295,14 +388,31 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void conv_mfma_kernel(const ConvPa
             }
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) {
+                const int ob = o0 + (wo * MO + mo) * 32 + 4 * half;        // channel of register r: ob + (r&3) + 8*(r>>2)
+                if (p.ksplit > 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ob + (r & 3) + 8 * (r >> 2);
+                        if (o < p.O) p.part[(long)kslice * p.part_stride + base + (long)o * plane] = acc[ph][mo][np][r];
+                    }
+                    continue;
+                }
+                // gather the per-channel operands first (independent loads, one wait), then compute and store
+                float osc[16], bs[16], rs[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int o = o0 + (wo * MO + mo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int o = min(ob + (r & 3) + 8 * (r >> 2), p.O - 1);
+                    osc[r] = p.out_scale ? p.out_scale[n * p.O + o] : 1.f;
+                    bs[r] = p.bias ? p.bias[o] : 0.f;
+                    rs[r] = p.residual ? p.residual[base + (long)o * plane] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ob + (r & 3) + 8 * (r >> 2);
                     if (o >= p.O) continue;
-                    const long idx = base + (long)o * plane;
-                    const float v = acc[ph][mo][np][r];
-                    if (p.ksplit > 1) p.part[(long)kslice * p.part_stride + idx] = v;
-                    else p.y[idx] = conv_epilogue(p, v, n, o, idx, nz);
+                    float v = acc[ph][mo][np][r] * osc[r] + nz + bs[r];
+                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
+                    p.y[base + (long)o * plane] = v + rs[r];
                 }
             }
         }
@@ -357,7 +467,7 @@ static ConvPlan conv_plan(int NB, int I, int O, int OHp, int OWp, int BO, int BP
     return c;
 }
 
-template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP>
+template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP, bool DB, int OCC>
 static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStream_t s) {
     constexpr int BO = MO * 32 * WO, BP = NP * 32 * WP, NT = WO * WP * 64;
     const long out_elems = (UP && p.out_mode == 1) ? 4L * p.NB * p.O * (p.H + 1) * (p.W + 1) : (long)p.NB * p.O * p.OHt * p.OWt;
@@ -382,8 +492,8 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
             const int dyr = p.tap_off[t] >> 6, dxr = p.tap_off[t] & 63;   // packed (dy-dy0, dx-dx0)
             p.tap_off[t] = dyr * p.PW + dxr;
         }
-    const size_t lds = sizeof(float) * ((size_t)KC * NTAPS * BO + (size_t)(KC + 1) * p.PATCH);
-    auto kern = conv_mfma_kernel<NTAPS, KC, MO, NP, WO, WP, XQ, UP>;
+    const size_t lds = sizeof(float) * ((DB ? 2 : 1) * ((size_t)KC * NTAPS * BO + (size_t)(KC + 1) * p.PATCH) + (p.in_scale ? (size_t)c.tn * p.i_per_slice : 0));
+    auto kern = conv_mfma_kernel<NTAPS, KC, MO, NP, WO, WP, XQ, UP, DB, OCC>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) { shg_set_error("conv: LDS request %zu exceeds 160 KiB", lds); return SHG_ERR_UNSUPPORTED; }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -403,13 +513,20 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
 
 static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, size_t ws_bytes, hipStream_t s) {
     const bool narrow = p.O <= 64;    // 64 x 256 tile instead of 128 x 128
-    if (up) return launch_conv<9, 8, 2, 1, 1, 4, 1, true>(p, workspace, ws_bytes, s);   // 64 channels x 128 low-res pixels x 4 phases
-    if (K == 9 && S == 1) return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 2, false>(p, workspace, ws_bytes, s)
-                                        : launch_conv<9, 8, 2, 2, 2, 2, 2, false>(p, workspace, ws_bytes, s);
-    if (K == 9 && S == 2) return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 5, false>(p, workspace, ws_bytes, s)
-                                        : launch_conv<9, 8, 2, 2, 2, 2, 3, false>(p, workspace, ws_bytes, s);
-    if (K == 1 && S == 1) return narrow ? launch_conv<1, 32, 2, 2, 1, 4, 1, false>(p, workspace, ws_bytes, s)
-                                        : launch_conv<1, 32, 2, 2, 2, 2, 1, false>(p, workspace, ws_bytes, s);
+    // SHG_CONV_VARIANT (tuning knob): 0 = default heuristics, 1 = force the single-buffer 4-wave kernels everywhere
+    static const int variant = getenv("SHG_CONV_VARIANT") ? atoi(getenv("SHG_CONV_VARIANT")) : 0;
+    if (up) return launch_conv<9, 8, 2, 1, 1, 4, 1, true, false, 2>(p, workspace, ws_bytes, s);   // 64 ch x 128 low-res px x 4 phases
+    if (K == 9 && S == 1) {
+        // large images, many channels: 8-wave 128 x 256 tile, double-buffered LDS, staggered hand-over
+        if (!narrow && variant == 0 && p.OWp >= 32 && p.OHp >= 8 && p.wgroups == 1)
+            return launch_conv<9, 8, 2, 2, 2, 4, 1, false, true, 2>(p, workspace, ws_bytes, s);
+        return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 2, false, false, 3>(p, workspace, ws_bytes, s)
+                      : launch_conv<9, 8, 2, 2, 2, 2, 2, false, false, 2>(p, workspace, ws_bytes, s);
+    }
+    if (K == 9 && S == 2) return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 5, false, false, 2>(p, workspace, ws_bytes, s)
+                                        : launch_conv<9, 8, 2, 2, 2, 2, 3, false, false, 2>(p, workspace, ws_bytes, s);
+    if (K == 1 && S == 1) return narrow ? launch_conv<1, 32, 2, 2, 1, 4, 1, false, false, 3>(p, workspace, ws_bytes, s)
+                                        : launch_conv<1, 32, 2, 2, 2, 2, 1, false, false, 3>(p, workspace, ws_bytes, s);
     shg_set_error("conv2d: 1x1 stride-2 convolution is not implemented (decimate with upfirdn2d first)");
     return SHG_ERR_UNSUPPORTED;
 }
@@ -421,7 +538,7 @@ static int conv_fill(ConvParams& p, const float* x, const float* wt, float* y, i
     SHG_CHECK_ARG(x && wt && y, "conv2d: null pointer");
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d: empty tensor");
     SHG_CHECK_ARG((kh == 3 && kw == 3) || (kh == 1 && kw == 1), "conv2d: only 3x3 and 1x1 kernels (got %dx%d)", kh, kw);
-    SHG_CHECK_ARG(OP % 4 == 0 && OP >= O, "conv2d: OP must be a multiple of 4 and >= O");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d: OP must be a multiple of 64 and >= O");
     SHG_CHECK_ARG(mode >= 0 && mode <= 2, "conv2d: bad mode %d", mode);
     SHG_CHECK_ARG(mode != 2 || (kh == 3 && pad == 0), "conv2d: transposed mode supports 3x3, padding 0");
     SHG_CHECK_ARG(pad >= 0 && pad < 32, "conv2d: bad padding");
@@ -430,9 +547,11 @@ static int conv_fill(ConvParams& p, const float* x, const float* wt, float* y, i
     p.x = x; p.wt = wt; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
+    p.IPK = (I + 31) / 32 * 32 * kh * kw;
     p.wgroups = wgroups < 1 ? 1 : wgroups; p.wstride = wstride;
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.out_mode = out_mode; p.ksplit = 1;
+    { const char* d = getenv("SHG_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
     if (mode == 2) {
         // transposed stride 2 (conv2d_resample.py:130-137): Y = 2u+a, X = 2v+b over u in [0,H], v in [0,W]
         p.OHt = 2 * H + 1; p.OWt = 2 * W + 1; p.OHp = H + 1; p.OWp = W + 1; p.S = 1;
@@ -502,38 +621,42 @@ __global__ __launch_bounds__(256) void weight_scale_kernel(const float* w, float
     if (threadIdx.x == 0) scale[o] = demod ? gain * rsqrtf(acc / (float)IK) : gain;
 }
 
-// wt[(i*KK + t')*OP + o], t' = flip ? KK-1-t : t   (flip = w.flip([2,3]), conv2d_resample.py:32-33)
+// wt[((o/64)*IP*KK + i*KK + t')*64 + o%64], t' = flip ? KK-1-t : t   (flip = w.flip([2,3]), conv2d_resample.py:32-33):
+// 64-column blocks, so the [KC*KK][BO] slice a workgroup stages per chunk is one contiguous run of memory (a row-major
+// [I*KK][OP] matrix would put every row of a tile on the same two L2 channels).  Rows for i in [I, IP) and columns
+// in [O, OP) are zeros (IP = I rounded up to 32: the conv kernel reads whole chunks).
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* w, const float* scale, float* wt, int O, int I,
-                                                               int KK, int OP, int flip) {
+                                                               int IP, int KK, int OP, int flip) {
     __shared__ float tile[32][33];
     const int IK = I * KK;
+    const int IPK = IP * KK;
     const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         const int o = o0 + r, k = k0 + tx;
-        tile[r][tx] = (o < O && k < IK) ? w[(long)o * IK + k] * scale[o] : 0.f;
+        tile[r][tx] = (o < O && k < IK) ? w[(long)o * IK + k] * scale[o] : 0.f;      // zero beyond I*KK
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int k = k0 + r, o = o0 + tx;
-        if (k >= IK || o >= OP) continue;
+        if (k >= IPK || o >= OP) continue;
         const int i = k / KK, t = k - i * KK;
         const int tt = flip ? KK - 1 - t : t;
-        wt[((long)i * KK + tt) * OP + o] = tile[tx][r];
+        wt[((long)(o >> 6) * IPK + (long)i * KK + tt) * 64 + (o & 63)] = tile[tx][r];
     }
 }
 
-// wsq[i][o] = sum_t wt[i][t][o]^2   (for the demodulation coefficients, stylegan.py:155)
-__global__ __launch_bounds__(256) void weight_sq_kernel(const float* wt, float* wsq, int I, int KK, int OP) {
+// wsq[i][o] = sum_t wt[i][t][o]^2   (for the demodulation coefficients, stylegan.py:155); row pitch OP
+__global__ __launch_bounds__(256) void weight_sq_kernel(const float* wt, float* wsq, int I, int IPK, int KK, int OP) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)I * OP) return;
     const int i = (int)(e / OP), o = (int)(e - (long)i * OP);
     float acc = 0.f;
-    for (int t = 0; t < KK; ++t) { const float v = wt[((long)i * KK + t) * OP + o]; acc += v * v; }
+    for (int t = 0; t < KK; ++t) { const float v = wt[((long)(o >> 6) * IPK + (long)i * KK + t) * 64 + (o & 63)]; acc += v * v; }
     wsq[e] = acc;
 }
 
-// w: [O,I,KH,KW] fp32.  wt: [I*KK*OP] out.  wscale: [O] scratch/out.  wsq: [I*OP] out or null.
+// w: [O,I,KH,KW] fp32.  wt: [OP/64][IP*KK][64] out (OP = O rounded up to 64, IP = I rounded up to 32, padding zero).  wscale: [O] scratch/out.  wsq: [I*OP] out or null.
 // demod=1 reproduces stylegan.py:146 (per-output-channel RMS normalisation) times `gain`;
 // demod=0 multiplies by `gain` (conv2d_layer weight_gain, stylegan.py:227).
 // One layout serves all three convolution modes (the transposed kernel indexes taps as ky*3+kx).
@@ -541,16 +664,17 @@ extern "C" int shg_conv_weight_prep_f32(const float* w, float* wt, float* wscale
                                         int OP, int demod, float gain, int flip, void* stream) {
     SHG_CHECK_ARG(w && wt && wscale, "weight_prep: null pointer");
     SHG_CHECK_ARG(O >= 1 && I >= 1 && KH >= 1 && KW >= 1, "weight_prep: empty weight");
-    SHG_CHECK_ARG(OP % 4 == 0 && OP >= O, "weight_prep: OP must be a multiple of 4 and >= O");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "weight_prep: OP must be a multiple of 64 and >= O");
     hipStream_t s = (hipStream_t)stream;
     const int KK = KH * KW, IK = I * KK;
     hipLaunchKernelGGL(weight_scale_kernel, dim3(O), dim3(256), 0, s, w, wscale, IK, demod, gain);
     SHG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3(shg_cdiv(IK, 32), shg_cdiv(OP, 32)), dim3(256), 0, s, w, wscale, wt, O, I, KK,
-                       OP, flip);
+    const int IP = (I + 31) / 32 * 32;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(shg_cdiv((long)IP * KK, 32), shg_cdiv(OP, 32)), dim3(256), 0, s, w, wscale, wt, O,
+                       I, IP, KK, OP, flip);
     SHG_CHECK_LAUNCH();
     if (wsq) {
-        hipLaunchKernelGGL(weight_sq_kernel, dim3(shg_cdiv((long)I * OP, 256)), dim3(256), 0, s, wt, wsq, I, KK, OP);
+        hipLaunchKernelGGL(weight_sq_kernel, dim3(shg_cdiv((long)I * OP, 256)), dim3(256), 0, s, wt, wsq, I, IP * KK, KK, OP);
         SHG_CHECK_LAUNCH();
     }
     return SHG_OK;

@@ -162,9 +162,10 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
     w = _req(w, 'w')
     o_all, i, kh, kw = w.shape
     o = o_all // groups
-    op = (o + 3) // 4 * 4
+    op = (o + 63) // 64 * 64                     # 64-column weight blocks
     kk = kh * kw
-    wt = torch.empty((groups, i * kk * op), device=w.device, dtype=torch.float32)
+    ip = (i + 31) // 32 * 32                     # channel rows are zero padded to whole K-chunks
+    wt = torch.empty((groups, ip * kk * op), device=w.device, dtype=torch.float32)
     wsq = torch.empty((groups, i * op), device=w.device, dtype=torch.float32) if demod else None
     wscale = torch.empty((o,), device=w.device, dtype=torch.float32)
     lib = _lib.get_lib()

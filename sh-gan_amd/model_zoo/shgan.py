@@ -90,17 +90,16 @@ class heterogeneous_filter(nn.Module):
             nn.init.ones_(self.weight)
 
     def prepped(self):
-        # weight is already [I][O*B] = the GEMM layout of a single-tap convolution
+        # weight is [I][O*B]; as a single-tap convolution its [O*B, I, 1, 1] form goes through the usual weight prep
         def build():
             i, ob = self.weight.shape
-            w = self.weight.detach().contiguous()
-            return kernels.PreppedWeight(w.reshape(1, -1), None, ob, i, ob, 1, 1, 1)
+            return kernels.conv_weight_prep(self.weight.detach().t().contiguous().reshape(ob, i, 1, 1))
         return _cache_of(self).get('w', [self.weight], build)
 
     def band_conv(self, x):
         n, c, h, w = x.shape
-        if (h * w) % 32 != 0 or (self.weight.shape[1] % 4) != 0:
-            raise NotImplementedError('heterogeneous_filter: H*W must be a multiple of 32 and C*bands of 4')
+        if (h * w) % 32 != 0:
+            raise NotImplementedError('heterogeneous_filter: H*W must be a multiple of 32')
         y = kernels.conv2d(x.reshape(n, c, (h * w) // 32, 32), self.prepped(), mode=kernels.MODE_SAME, pad=0)
         return y.reshape(n, -1, h, w)
 

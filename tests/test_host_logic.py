@@ -103,7 +103,7 @@ def test_bad_arguments_are_reported_by_the_c_abi():
     assert (oh.value, ow.value) == (17, 17)
     rc = lib.shg_upfirdn2d_f32(None, None, None, 1, 1, 4, 4, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None)
     assert rc == -1 and b'null' in lib.shg_last_error()
-    rc = lib.shg_conv2d_f32(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 4, 4, 4, 8, 8, 5, 5, 0, 2, 1, 0,
+    rc = lib.shg_conv2d_f32(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 4, 4, 64, 8, 8, 5, 5, 0, 2, 1, 0,
                             None, None, None, None, 0, 0.0, 0, 0.0, 1.0, -1.0, None, 0, None, 0, None)
     assert rc == -1 and b'3x3' in lib.shg_last_error()
     # split-K planning is a pure host function: tiny spatial grids split, big ones do not

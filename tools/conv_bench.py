@@ -22,7 +22,11 @@ LAYERS = [
     ('syn256.up 256->128', 256, 128, 128, 2, True), ('syn256.conv1', 128, 128, 256, 0, True),
     ('syn512.up 128->64', 128, 64, 256, 2, True), ('syn512.conv1', 64, 64, 512, 0, True),
 ]
+for ci in (8, 16, 32, 64, 128, 256):
+    LAYERS.append((f'fit64 I={ci} O=512', ci, 512, 64, 0, False))
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
+if not flt:
+    LAYERS = [l for l in LAYERS if not l[0].startswith('fit')]
 dev = 'cuda'
 tot_ms = tot_fl = 0.0
 for name, ci, co, h, mode, mod in LAYERS:
