@@ -50,7 +50,7 @@ struct ConvParams {
     int S;                   // input stride
     int dy0, dx0;            // patch origin = (oy0*S + dy0, ox0*S + dx0)
     int PH, PW, PATCH;       // patch rows/cols per image; PATCH = TN*PH*PW
-    int tw_log2, th_log2, tn_log2;
+    int TW, TH, TN;          // pixel tile: TW x TH pixels of TN images (TW*TH*TN <= BP, any integers)
     int tiles_x, tiles_y, n_ptiles, n_otiles;
     int wgroups;
     long wstride;
@@ -62,6 +62,7 @@ struct ConvParams {
     int act;
     float alpha, gain, clamp;
     int tap_off[9];          // LDS patch offset (in patch elements) of tap t
+    int raw_reduce;          // split-K tail only sums the slices (transposed conv: its epilogue lives in the FIR kernel)
     int dbg;                 // ablation bits for kernel timing studies (SHG_CONV_DBG, default 0): 1 skip W loads, 2 skip X loads,
                              // 4 skip LDS stores, 8 skip barriers, 16 skip epilogue
 };
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     constexpr int NBUF = DB ? 2 : 1;
     float* Wl = smem;
     float* Sl = smem + NBUF * WSZ;
-    float* Xl = Sl + (p.in_scale ? (1 << p.tn_log2) * p.i_per_slice : 0);
+    float* Xl = Sl + (p.in_scale ? p.TN * p.i_per_slice : 0);
     const int XSZ = XP * p.PATCH;
 
     const int tid = threadIdx.x;
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     const int txb = ptile % p.tiles_x;
     const int tyb = (ptile / p.tiles_x) % p.tiles_y;
     const int tnb = ptile / (p.tiles_x * p.tiles_y);
-    const int TN = 1 << p.tn_log2;
-    const int n0 = tnb << p.tn_log2, oy0 = tyb << p.th_log2, ox0 = txb << p.tw_log2;
+    const int TN = p.TN, THW = p.TH * p.TW;
+    const int n0 = tnb * p.TN, oy0 = tyb * p.TH, ox0 = txb * p.TW;
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
     const int PHW = p.PH * p.PW;
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
         const int j = (wp * NP + np) * 32 + l31;
-        const int tx = j & ((1 << p.tw_log2) - 1);
-        const int ty = (j >> p.tw_log2) & ((1 << p.th_log2) - 1);
-        int tn = j >> (p.tw_log2 + p.th_log2);
+        int tn = j / THW;
+        const int rem = j - tn * THW;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
         tn = tn < TN ? tn : 0;   // out-of-tile lanes read image 0 of the tile (masked on store)
         xbase[np] = Xl + (tn * PHW + ty * p.S * p.PW + tx * p.S) * XP + half;
     }
@@ -287,8 +288,7 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
                 for (int np = 0; np < NP; ++np) b[buf][np] = xb_c[np][toff + c2 * 2];
             };
             fetch(0, 0);
-#pragma unroll
-            for (int step = 0; step < NSTEP; ++step) {
+            auto step_body = [&](int step) __attribute__((always_inline)) {
                 if (step + 1 < NSTEP) fetch(step + 1, (step + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
@@ -296,12 +296,27 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
 #pragma unroll
                     for (int np = 0; np < NP; ++np)
                         acc[0][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step & 1][mo], b[step & 1][np], acc[0][mo][np], 0, 0, 0);
-                if (DB && (TWO_GROUPS ? (step == NSTEP / 4 || step == (3 * NSTEP) / 4) : (step == NSTEP / 2))) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!TWO_GROUPS || grp == (step == NSTEP / 4 ? 0 : 1)) handover();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            };
+            // three fully unrolled segments; the hand-over blocks sit between them (kept out of the unrolled
+            // bodies so that every index stays a compile-time constant)
+            constexpr int Q1 = DB ? (TWO_GROUPS ? NSTEP / 4 : NSTEP / 2) : NSTEP;
+            constexpr int Q2 = DB ? (TWO_GROUPS ? (3 * NSTEP) / 4 : NSTEP / 2) : NSTEP;
+#pragma unroll
+            for (int step = 0; step < Q1; ++step) step_body(step);
+            if (DB) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!TWO_GROUPS || grp == 0) handover();
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int step = Q1; step < Q2; ++step) step_body(step);
+            if (DB && TWO_GROUPS) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 1) handover();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int step = Q2; step < NSTEP; ++step) step_body(step);
         } else {
             // tap t = ky*3+kx feeds phase (ky&1, kx&1) from the input pixel shifted by (ky==2 ? -1 : 0, kx==2 ? -1 : 0);
             // the patch origin is (u0-1, v0-1), so shift (sy,sx) sits at patch offset (1+sy)*PW + (1+sx)
@@ -323,8 +338,7 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
             };
             fetch_b(0, 0);
             fetch_a(0, 0);
-#pragma unroll
-            for (int slot = 0; slot < NSLOT; ++slot) {
+            auto slot_body = [&](int slot) __attribute__((always_inline)) {
                 const int c2 = slot / 9, t = slot % 9;
                 if (slot + 1 < NSLOT) fetch_a(slot + 1, (slot + 1) & 1);
                 if (t == 4 && c2 + 1 < KC / 2) fetch_b(c2 + 1, (c2 + 1) & 1);
@@ -335,12 +349,25 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
                     for (int np = 0; np < NP; ++np)
                         acc[PHASE[t]][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             a[slot & 1][mo], b[c2 & 1][SHIFT[t]][np], acc[PHASE[t]][mo][np], 0, 0, 0);
-                if (DB && (TWO_GROUPS ? (slot == NSLOT / 4 || slot == (3 * NSLOT) / 4) : (slot == NSLOT / 2))) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!TWO_GROUPS || grp == (slot == NSLOT / 4 ? 0 : 1)) handover();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            };
+            constexpr int Q1 = DB ? (TWO_GROUPS ? NSLOT / 4 : NSLOT / 2) : NSLOT;
+            constexpr int Q2 = DB ? (TWO_GROUPS ? (3 * NSLOT) / 4 : NSLOT / 2) : NSLOT;
+#pragma unroll
+            for (int slot = 0; slot < Q1; ++slot) slot_body(slot);
+            if (DB) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!TWO_GROUPS || grp == 0) handover();
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int slot = Q1; slot < Q2; ++slot) slot_body(slot);
+            if (DB && TWO_GROUPS) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 1) handover();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int slot = Q2; slot < NSLOT; ++slot) slot_body(slot);
         }
         if (!(p.dbg & 8)) __syncthreads();
         if (!DB && more) {                           // single buffer: everyone is done reading -> overwrite, publish
@@ -355,9 +382,9 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
         const int j = (wp * NP + np) * 32 + l31;
-        const int tx = j & ((1 << p.tw_log2) - 1);
-        const int ty = (j >> p.tw_log2) & ((1 << p.th_log2) - 1);
-        const int tn = j >> (p.tw_log2 + p.th_log2);
+        const int tn = j / THW;
+        const int rem = j - tn * THW;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
         const int n = n0 + tn, oy = oy0 + ty, ox = ox0 + tx;
         if (tn >= TN || n >= p.NB || oy >= p.OHp || ox >= p.OWp) continue;
 #pragma unroll
@@ -425,6 +452,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
         float v = 0.f;
         for (int s = 0; s < p.ksplit; ++s) v += p.part[(long)s * p.part_stride + e];
+        if (p.raw_reduce) { p.y[e] = v; continue; }
         const long no = e / plane;
         const int pix = (int)(e - no * plane);
         const int n = (int)(no / p.O), o = (int)(no - (long)n * p.O);
@@ -439,21 +467,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
 // Host side
 // ------------------------------------------------------------------------------------------------
 
-static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct ConvPlan { int tw, th, tn, n_ptiles, n_otiles, ksplit, i_per_slice; };
 
-// Tile shape and split-K factor for a launch: BP pixels per tile as TW x TH x TN (powers of two).
-static ConvPlan conv_plan(int NB, int I, int O, int OHp, int OWp, int BO, int BP, int KC, int wgroups, bool allow_split) {
+// Tile shape and split-K factor for a launch.  The BP pixels of a tile are TW x TH pixels of TN images; any
+// integers with TW*TH*TN <= BP are allowed, so grids such as 33 x 33 or 257 x 257 (the transposed conv) are
+// covered without the 2x padding waste of power-of-two tiles.  Chosen: the shape with the fewest tiles whose
+// input patch fits the staging capacity; ties go to rows that are multiples of 32 pixels (full 128-byte store
+// segments), then to the smallest patch (least halo traffic).
+static ConvPlan conv_plan(int NB, int I, int O, int OHp, int OWp, int BO, int BP, int KC, int wgroups, bool allow_split,
+                          int S = 1, int span_y = 1, int span_x = 1, int patch_cap = 1 << 30) {
     ConvPlan c;
-    int tw = 32; while (tw > 1 && tw / 2 >= OWp) tw >>= 1;
-    if (tw > BP) tw = BP;
-    int th = BP / tw; while (th > 1 && th / 2 >= OHp) th >>= 1;
-    int tn = BP / (tw * th);
-    if (wgroups > 1) tn = 1;                    // per-slot weights: one image per tile
-    while (tn > 1 && tn / 2 >= NB) tn >>= 1;
-    c.tw = tw; c.th = th; c.tn = tn;
-    c.n_ptiles = shg_cdiv(OWp, tw) * shg_cdiv(OHp, th) * shg_cdiv(NB, tn);
+    long best = -1, bpatch = 0;
+    int btw = 1, bth = 1, btn = 1, bfull = 0;
+    const int tw_max = OWp < BP ? OWp : BP;
+    for (int tw = 1; tw <= tw_max; ++tw) {
+        if (tw < 8 && tw != OWp && OWp >= 8) continue;          // keep rows reasonably long
+        int th = BP / tw; if (th > OHp) th = OHp;
+        int tn = BP / (tw * th); if (tn > NB) tn = NB;
+        if (wgroups > 1) tn = 1;                                 // per-slot weights: one image per tile
+        if (tn < 1) tn = 1;
+        const long patch = (long)tn * ((th - 1) * S + span_y) * ((tw - 1) * S + span_x);
+        if (patch > patch_cap) continue;
+        const long tiles = (long)shg_cdiv(OWp, tw) * shg_cdiv(OHp, th) * shg_cdiv(NB, tn);
+        const int full = (tw % 32 == 0) ? 1 : 0;                // whole 128-byte store segments per (channel, row)
+        if (best < 0 || tiles < best || (tiles == best && (full > bfull || (full == bfull && patch < bpatch)))) {
+            best = tiles; bpatch = patch; btw = tw; bth = th; btn = tn; bfull = full;
+        }
+    }
+    if (best < 0) {    // nothing fits the staging capacity: fall back to a single row segment
+        btw = OWp < 32 ? OWp : 32; bth = 1; btn = 1;
+        best = (long)shg_cdiv(OWp, btw) * OHp * NB;
+    }
+    c.tw = btw; c.th = bth; c.tn = btn;
+    c.n_ptiles = (int)best;
     c.n_otiles = shg_cdiv(O, BO);
     const int chunks = shg_cdiv(I, KC);
     int ks = 1;
@@ -471,11 +518,12 @@ template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP, bo
 static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStream_t s) {
     constexpr int BO = MO * 32 * WO, BP = NP * 32 * WP, NT = WO * WP * 64;
     const long out_elems = (UP && p.out_mode == 1) ? 4L * p.NB * p.O * (p.H + 1) * (p.W + 1) : (long)p.NB * p.O * p.OHt * p.OWt;
-    ConvPlan c = conv_plan(p.NB, p.I, p.O, p.OHp, p.OWp, BO, BP, KC, p.wgroups, workspace != nullptr && !UP);
+    ConvPlan c = conv_plan(p.NB, p.I, p.O, p.OHp, p.OWp, BO, BP, KC, p.wgroups, workspace != nullptr, p.S, p.PH, p.PW, XQ * NT);
+    p.raw_reduce = UP ? 1 : 0;
     if (c.ksplit > 1 && (size_t)c.ksplit * out_elems * sizeof(float) > ws_bytes) {   // workspace too small: no split
         c.ksplit = 1; c.i_per_slice = shg_cdiv(p.I, KC) * KC;
     }
-    p.tw_log2 = ilog2(c.tw); p.th_log2 = ilog2(c.th); p.tn_log2 = ilog2(c.tn);
+    p.TW = c.tw; p.TH = c.th; p.TN = c.tn;
     p.tiles_x = shg_cdiv(p.OWp, c.tw); p.tiles_y = shg_cdiv(p.OHp, c.th);
     p.n_ptiles = c.n_ptiles; p.n_otiles = c.n_otiles;
     p.ksplit = c.ksplit; p.i_per_slice = c.i_per_slice;
@@ -515,7 +563,14 @@ static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, 
     const bool narrow = p.O <= 64;    // 64 x 256 tile instead of 128 x 128
     // SHG_CONV_VARIANT (tuning knob): 0 = default heuristics, 1 = force the single-buffer 4-wave kernels everywhere
     static const int variant = getenv("SHG_CONV_VARIANT") ? atoi(getenv("SHG_CONV_VARIANT")) : 0;
-    if (up) return launch_conv<9, 8, 2, 1, 1, 4, 1, true, false, 2>(p, workspace, ws_bytes, s);   // 64 ch x 128 low-res px x 4 phases
+    if (up) {
+        // all-phase transposed conv: large grids use 8-wave double-buffered tiles (128 ch x 128 px, or 64 ch x 256 px),
+        // small ones the 4-wave 64 ch x 128 px tile (+ split-K)
+        const bool big = variant == 0 && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1;
+        if (big) return narrow ? launch_conv<9, 8, 2, 1, 1, 8, 1, true, true, 2>(p, workspace, ws_bytes, s)
+                               : launch_conv<9, 8, 2, 1, 2, 4, 1, true, true, 2>(p, workspace, ws_bytes, s);
+        return launch_conv<9, 8, 2, 1, 1, 4, 1, true, false, 2>(p, workspace, ws_bytes, s);
+    }
     if (K == 9 && S == 1) {
         // large images, many channels: 8-wave 128 x 256 tile, double-buffered LDS, staggered hand-over
         if (!narrow && variant == 0 && p.OWp >= 32 && p.OHp >= 8 && p.wgroups == 1)
@@ -589,13 +644,19 @@ extern "C" int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB,
 
 // Bytes of split-K workspace that shg_conv2d_f32 can use for this problem (0 = it will not split).
 extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W, int kh, int kw, int mode, int pad, int wgroups) {
-    if (mode == 2 || NB < 1 || I < 1 || O < 1) return 0;
+    if (NB < 1 || I < 1 || O < 1) return 0;
+    if (mode == 2) {   // small transposed convs (the 4-wave 64 x 128 tile) may split; planar output of 4 phase planes
+        if (W + 1 >= 32 && H + 1 >= 16) return 0;
+        ConvPlan c = conv_plan(NB, I, O, H + 1, W + 1, 64, 128, 8, wgroups < 1 ? 1 : wgroups, true, 1, 2, 2, 256);
+        return c.ksplit > 1 ? (size_t)c.ksplit * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
+    }
     const int S = mode == 0 ? 1 : 2;
     const int OH = (H + 2 * pad - kh) / S + 1, OW = (W + 2 * pad - kw) / S + 1;
     if (OH < 1 || OW < 1) return 0;
     const bool narrow = O <= 64;
     const int KC = kh * kw == 9 ? 8 : 32;
-    ConvPlan c = conv_plan(NB, I, O, OH, OW, narrow ? 64 : 128, narrow ? 256 : 128, KC, wgroups < 1 ? 1 : wgroups, true);
+    const int xq = kh * kw == 1 ? 1 : (S == 1 ? 2 : (narrow ? 5 : 3));
+    ConvPlan c = conv_plan(NB, I, O, OH, OW, narrow ? 64 : 128, narrow ? 256 : 128, KC, wgroups < 1 ? 1 : wgroups, true, S, kh, kw, xq * 256);
     return c.ksplit > 1 ? (size_t)c.ksplit * NB * O * OH * OW * sizeof(float) : 0;
 }
 

@@ -8,47 +8,46 @@
 // while the activations of the whole batch sit in LDS.
 #include "shg_common.h"
 
-#define DENSE_MAXN 32     // samples per pass (batch is processed in chunks of DENSE_MAXN)
-#define DENSE_KC 512      // K chunk staged in LDS: DENSE_MAXN * DENSE_KC * 4 B = 64 KiB
+#define DENSE_MAXN 16     // samples per pass (larger batches are processed in slabs of DENSE_MAXN rows)
 
+// One wave per output feature: lane l walks k = l, l+64, ... of the weight row (coalesced 256 B) and of the
+// DENSE_MAXN activation rows (the whole activation matrix is a few hundred KB and stays in L2); all loads
+// of an iteration are independent, so the compiler keeps 1 + N of them in flight per lane.
 __global__ __launch_bounds__(256) void dense_kernel(const float* x, const float* w, const float* b, float* y, int N, int K, int O,
                                                     int ldx, int ldy, float wgain, float bgain, int act, float alpha, float gain,
                                                     float clamp) {
-    extern __shared__ float xs[];   // [nb][DENSE_KC]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= O) return;
     const int n0 = blockIdx.y * DENSE_MAXN;
     const int nb = min(DENSE_MAXN, N - n0);
-    const int o = blockIdx.x * 4 + wave;
+    const float* wr = w + (long)o * K;
+    const float* xr = x + (long)n0 * ldx;
     float acc[DENSE_MAXN];
 #pragma unroll
     for (int n = 0; n < DENSE_MAXN; ++n) acc[n] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += DENSE_KC) {
-        const int kc = min(DENSE_KC, K - k0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < nb * DENSE_KC; e += 256) {
-            const int n = e / DENSE_KC, k = e - n * DENSE_KC;
-            xs[e] = k < kc ? x[(long)(n0 + n) * ldx + k0 + k] : 0.f;
-        }
-        __syncthreads();
-        if (o < O) {
-            const float* wr = w + (long)o * K + k0;
-            for (int k = lane; k < kc; k += 64) {
-                const float wv = wr[k];
+    if (nb == DENSE_MAXN) {
+#pragma unroll 2
+        for (int k = lane; k < K; k += 64) {
+            const float wv = wr[k];
 #pragma unroll
-                for (int n = 0; n < DENSE_MAXN; ++n)
-                    if (n < nb) acc[n] += wv * xs[n * DENSE_KC + k];
-            }
+            for (int n = 0; n < DENSE_MAXN; ++n) acc[n] += wv * xr[(long)n * ldx + k];
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int n = 0; n < DENSE_MAXN; ++n)
+                if (n < nb) acc[n] += wv * xr[(long)n * ldx + k];
         }
     }
-    if (o >= O) return;
     const float bias = b ? b[o] * bgain : 0.f;
 #pragma unroll
     for (int n = 0; n < DENSE_MAXN; ++n) {
-        if (n >= nb) break;
         float v = acc[n];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) {
+        if (lane == 0 && n < nb) {
             v = v * wgain + bias;
             if (act) v = shg_lrelu_agc(v, alpha, gain, clamp);
             y[(long)(n0 + n) * ldy + o] = v;
@@ -62,8 +61,7 @@ extern "C" int shg_dense_f32(const float* x, const float* w, const float* b, flo
     SHG_CHECK_ARG(x && w && y, "dense: null pointer");
     SHG_CHECK_ARG(N >= 1 && K >= 1 && O >= 1 && ldx >= K && ldy >= O, "dense: bad shape");
     dim3 grid(shg_cdiv(O, 4), shg_cdiv(N, DENSE_MAXN));
-    const size_t lds = sizeof(float) * DENSE_MAXN * DENSE_KC;
-    hipLaunchKernelGGL(dense_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, b, y, N, K, O, ldx, ldy, wgain, bgain, act,
+    hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, N, K, O, ldx, ldy, wgain, bgain, act,
                        alpha, gain, clamp);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
@@ -92,15 +90,16 @@ extern "C" int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int
     return SHG_OK;
 }
 
-// One block per sample.  styles [N,I] (row pitch lds_), s_out [N,I], dcoef [N,O] (may be null when !demod).
+// Block (n, oc): sample n, output channels oc*64 .. oc*64+63.  styles [N,I] (row pitch ld), s_out [N,I],
+// dcoef [N,O] (null when !demod).  256 threads = 64 channels x 4 interleaved slices of the I reduction.
 __global__ __launch_bounds__(256) void modconv_style_prep_kernel(const float* styles, int ld, const float* wsq, float* s_out,
                                                                  float* dcoef, int N, int I, int O, int OP, int demod,
                                                                  float pre_gain) {
-    extern __shared__ float s2[];   // [I] squared normalised styles
+    extern __shared__ float s2[];   // [I] squared normalised styles of sample n
     __shared__ float red[256];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, oc = blockIdx.y;
     float snorm = 1.f;
-    if (demod) {
+    if (demod) {      // batch-global RMS of the styles (stylegan.py:147); every block computes the same value
         float acc = 0.f;
         for (int e = threadIdx.x; e < N * I; e += 256) {
             const float v = styles[(long)(e / I) * ld + (e % I)] * pre_gain;
@@ -113,19 +112,23 @@ __global__ __launch_bounds__(256) void modconv_style_prep_kernel(const float* st
             __syncthreads();
         }
         snorm = rsqrtf(red[0] / (float)(N * I));
+        __syncthreads();
     }
     for (int i = threadIdx.x; i < I; i += 256) {
         const float v = styles[(long)n * ld + i] * pre_gain * snorm;
-        s_out[(long)n * I + i] = v;
+        if (oc == 0) s_out[(long)n * I + i] = v;
         s2[i] = v * v;
     }
     if (!demod || !dcoef) return;
     __syncthreads();
-    for (int o = threadIdx.x; o < O; o += 256) {
-        float acc = 0.f;
-        for (int i = 0; i < I; ++i) acc += s2[i] * wsq[(long)i * OP + o];
-        dcoef[(long)n * O + o] = rsqrtf(acc + 1e-8f);
-    }
+    const int oo = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int o = oc * 64 + oo;
+    float acc = 0.f;
+    if (o < O)
+        for (int i = sl; i < I; i += 4) acc += s2[i] * wsq[(long)i * OP + o];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && o < O) dcoef[(long)n * O + o] = rsqrtf(red[oo] + red[64 + oo] + red[128 + oo] + red[192 + oo] + 1e-8f);
 }
 
 extern "C" int shg_modconv_style_prep_f32(const float* styles, int ld, const float* wsq, float* s_out, float* dcoef, int N, int I,
@@ -134,7 +137,7 @@ extern "C" int shg_modconv_style_prep_f32(const float* styles, int ld, const flo
     SHG_CHECK_ARG(!demod || (wsq && dcoef), "style_prep: demodulation needs wsq and dcoef");
     SHG_CHECK_ARG(N >= 1 && I >= 1 && ld >= I, "style_prep: bad shape");
     SHG_CHECK_ARG((size_t)I * 4 <= 64 * 1024, "style_prep: I too large");
-    hipLaunchKernelGGL(modconv_style_prep_kernel, dim3(N), dim3(256), sizeof(float) * I, (hipStream_t)stream, styles, ld, wsq,
+    hipLaunchKernelGGL(modconv_style_prep_kernel, dim3(N, demod ? shg_cdiv(O, 64) : 1), dim3(256), sizeof(float) * I, (hipStream_t)stream, styles, ld, wsq,
                        s_out, dcoef, N, I, O, OP, demod, pre_gain);
     SHG_CHECK_LAUNCH();
     return SHG_OK;

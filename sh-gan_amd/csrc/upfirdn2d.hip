@@ -47,8 +47,34 @@ __device__ __forceinline__ float ufd_epilogue(const UfdParams& p, float v, int n
     return v;
 }
 
-template <int FH, int FW, int TY>
+// up = down = 1, FH x FW filter.  One workgroup = a 16 x 64 output tile of one (n,c) plane at a time: the
+// (16+FH-1) x (64+FW-1) input window is staged in LDS with coalesced row loads (1.2 loads per output instead
+// of FH*FW), then every lane produces 4 vertically adjacent outputs from a register window.
+// Per-plane part of the epilogue, evaluated once per (n,c) plane instead of once per output.
+struct UfdPlane { float sc, bs; const float* nz; const float* res; };
+__device__ __forceinline__ UfdPlane ufd_plane(const UfdParams& p, int nc) {
+    UfdPlane q;
+    const int n = nc / p.C, c = nc - n * p.C;
+    q.sc = (p.has_epilogue && p.scale) ? p.scale[nc] : 1.f;
+    q.bs = (p.has_epilogue && p.bias) ? p.bias[c] : 0.f;
+    q.nz = !p.has_epilogue || p.noise_mode == 0 ? nullptr : (p.noise_mode == 1 ? p.noise : p.noise + (long)n * p.OH * p.OW);
+    q.res = (p.has_epilogue && p.residual) ? p.residual + (long)nc * p.OH * p.OW : nullptr;
+    return q;
+}
+__device__ __forceinline__ float ufd_finish(const UfdParams& p, const UfdPlane& q, float v, int pix) {
+    if (!p.has_epilogue) return v;
+    v *= q.sc;
+    if (q.nz) v += q.nz[pix] * p.noise_strength;
+    v += q.bs;
+    if (p.act) v = shg_lrelu_agc(v, p.alpha, p.act_gain, p.clamp);
+    if (q.res) v += q.res[pix];
+    return v;
+}
+
+template <int FH, int FW>
 __global__ __launch_bounds__(256) void fir_same_kernel(const UfdParams p) {
+    constexpr int TH = 16, TW = 64, IH = TH + FH - 1, IW = TW + FW - 1, PITCH = IW + 1;
+    __shared__ float tile[IH * PITCH];
     __shared__ float sf[FH * FW];
     if (threadIdx.x < FH * FW) {
         // stored so that sf[ky][kx] multiplies x[oy + ky - py0][ox + kx - px0]
@@ -60,34 +86,34 @@ __global__ __launch_bounds__(256) void fir_same_kernel(const UfdParams p) {
     float fr[FH * FW];
 #pragma unroll
     for (int k = 0; k < FH * FW; ++k) fr[k] = sf[k];
-
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oyb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * TY;
-    if (ox >= p.OW || oyb >= p.OH) return;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) * 4;
     for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
         const float* xp = p.x + (long)nc * p.H * p.W;
-        float win[TY + FH - 1][FW];
-#pragma unroll
-        for (int r = 0; r < TY + FH - 1; ++r) {
-            const int iy = oyb + r - p.py0;
-            const bool rok = iy >= 0 && iy < p.H;
-#pragma unroll
-            for (int k = 0; k < FW; ++k) {
-                const int ix = ox + k - p.px0;
-                win[r][k] = (rok && ix >= 0 && ix < p.W) ? xp[(long)iy * p.W + ix] : 0.f;
-            }
+        const UfdPlane pl = ufd_plane(p, nc);
+        for (int e = threadIdx.x; e < IH * IW; e += 256) {
+            const int r = e / IW, c = e - r * IW;
+            const int iy = oy0 + r - p.py0, ix = ox0 + c - p.px0;
+            tile[r * PITCH + c] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(long)iy * p.W + ix] : 0.f;
         }
+        __syncthreads();
+        float win[4 + FH - 1][FW];
 #pragma unroll
-        for (int t = 0; t < TY; ++t) {
-            const int oy = oyb + t;
-            if (oy >= p.OH) break;
+        for (int r = 0; r < 4 + FH - 1; ++r)
+#pragma unroll
+            for (int k = 0; k < FW; ++k) win[r][k] = tile[(ty + r) * PITCH + tx + k];
+        const int ox = ox0 + tx;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oy = oy0 + ty + t;
             float v = 0.f;
 #pragma unroll
             for (int ky = 0; ky < FH; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < FW; ++kx) v += win[t + ky][kx] * fr[ky * FW + kx];
-            p.y[((long)nc * p.OH + oy) * p.OW + ox] = ufd_epilogue(p, v, nc, oy, ox);
+            if (oy < p.OH && ox < p.OW) p.y[((long)nc * p.OH + oy) * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
         }
+        __syncthreads();
     }
 }
 
@@ -126,8 +152,12 @@ __global__ __launch_bounds__(256) void upfirdn_generic_kernel(const UfdParams p)
 // FIR after the all-phase transposed convolution (conv_mfma.hip, out_mode 1): the (2H+1)x(2W+1)
 // intermediate lives as four phase planes mid[(a*2+b)][nc][u][v] = full[2u+a][2v+b], each (H+1)x(W+1).
 // y[Y,X] = sum_{ky,kx<4} fk[ky][kx] * full[Y+ky-1][X+kx-1]   (pad [1,1,1,1], conv2d_resample.py:138).
-// One lane owns the 2x2 output block of low-res pixel (u,v): 25 coalesced plane loads -> 4 outputs.
+// One workgroup = an 8 x 64 tile of low-resolution pixels (16 x 128 outputs) of one (n,c) plane at a time:
+// the four 10 x 66 phase windows are staged in LDS with coalesced row loads, each lane then assembles the
+// 5 x 5 neighbourhood of its pixel (u,v) from LDS and writes the 2 x 2 outputs it owns as two float2.
 __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
+    constexpr int TU = 8, TV = 64, PU = TU + 2, PV = TV + 2, PITCH = PV + 1;   // odd planes need rows u0-1 .. u0+TU
+    __shared__ float tile[4][PU * PITCH];
     __shared__ float sf[16];
     if (threadIdx.x < 16) {
         const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
@@ -138,55 +168,67 @@ __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
     float fr[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) fr[k] = sf[k];
-    const int v = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int u = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= p.H || v >= p.W) return;
-    const int PW = p.W + 1;
-    const long P = (long)(p.H + 1) * PW;
-    int roff[5], coff[5];          // element offsets inside a plane; plane index contribution separately
-    int rpl[5], cpl[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int Y = 2 * u - 1 + r, X = 2 * v - 1 + r;
-        rpl[r] = (Y >= 0 && Y <= 2 * p.H) ? (Y & 1) : -1;
-        cpl[r] = (X >= 0 && X <= 2 * p.W) ? (X & 1) : -1;
-        roff[r] = (Y >> 1) * PW;
-        coff[r] = X >> 1;
-    }
+    const int v0 = blockIdx.x * TV, u0 = blockIdx.y * TU;
+    const int tv = threadIdx.x & 63, tu0 = (threadIdx.x >> 6) * 2;      // each lane: low-res rows tu0, tu0+1
+    const int PWg = p.W + 1;
+    const long P = (long)(p.H + 1) * PWg;
     for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
-        float m[5][5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                float val = 0.f;
-                if (rpl[r] >= 0 && cpl[c] >= 0)
-                    val = p.x[((long)(rpl[r] * 2 + cpl[c]) * p.NC + nc) * P + roff[r] + coff[c]];
-                m[r][c] = val;
-            }
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            float o2[2];
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                float acc = 0.f;
-#pragma unroll
-                for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
-                o2[dx] = ufd_epilogue(p, acc, nc, 2 * u + dy, 2 * v + dx);
-            }
-            *reinterpret_cast<float2*>(p.y + ((long)nc * p.OH + 2 * u + dy) * p.OW + 2 * v) = make_float2(o2[0], o2[1]);
+        const UfdPlane plq = ufd_plane(p, nc);
+        // plane (a,b) window: rows u0-a .. u0-a+TU, cols v0-b .. v0-b+TV  (full row Y = 2u+a, col X = 2v+b)
+        for (int e = threadIdx.x; e < 4 * PU * PV; e += 256) {
+            const int pl = e / (PU * PV), rem = e - pl * (PU * PV);
+            const int r = rem / PV, c = rem - r * PV;
+            const int a = pl >> 1, b = pl & 1;
+            const int u = u0 - a + r, v = v0 - b + c;
+            // valid full-resolution rows: Y = 2u+a in [0, 2H]  <=>  u in [0, H-a]
+            const bool ok = u >= 0 && u <= p.H - a && v >= 0 && v <= p.W - b;
+            tile[pl][r * PITCH + c] = ok ? p.x[((long)pl * p.NC + nc) * P + (long)u * PWg + v] : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int tu = tu0 + q;
+            const int u = u0 + tu, v = v0 + tv;
+            // neighbourhood rows Y = 2u-1 .. 2u+3: (a=1,u-1) (a=0,u) (a=1,u) (a=0,u+1) (a=1,u+1); window row of
+            // plane a for low-res row u' is u' - (u0 - a)
+            float m[5][5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int a = (r + 1) & 1;                 // r=0 -> Y odd
+                const int ur = tu + (r >> 1) - (a ? 1 : 0) + a;   // = (u-1,u,u,u+1,u+1) - (u0 - a)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int b = (c + 1) & 1;
+                    const int vc = tv + (c >> 1) - (b ? 1 : 0) + b;
+                    m[r][c] = tile[a * 2 + b][ur * PITCH + vc];
+                }
+            }
+            if (u < p.H && v < p.W) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    float o2[2];
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
+                        o2[dx] = ufd_finish(p, plq, acc, (2 * u + dy) * p.OW + 2 * v + dx);
+                    }
+                    *reinterpret_cast<float2*>(p.y + ((long)nc * p.OH + 2 * u + dy) * p.OW + 2 * v) = make_float2(o2[0], o2[1]);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
 static int ufd_launch(UfdParams& p, hipStream_t s) {
     const int gz = p.NC < 32768 ? p.NC : 32768;
     if (p.upx == 1 && p.upy == 1 && p.dnx == 1 && p.dny == 1 && p.fh == 4 && p.fw == 4) {
-        constexpr int TY = 4;
-        dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 4 * TY), gz);
-        hipLaunchKernelGGL((fir_same_kernel<4, 4, TY>), grid, dim3(256), 0, s, p);
+        dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 16), gz);
+        hipLaunchKernelGGL((fir_same_kernel<4, 4>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 4), gz);
         hipLaunchKernelGGL(upfirdn_generic_kernel, grid, dim3(256), sizeof(float) * p.fh * p.fw, s, p);
@@ -268,7 +310,7 @@ extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, 
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
     const int gz = p.NC < 32768 ? p.NC : 32768;
-    hipLaunchKernelGGL(fir_up_planar_kernel, dim3(shg_cdiv(W, 64), shg_cdiv(H, 4), gz), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(fir_up_planar_kernel, dim3(shg_cdiv(W, 64), shg_cdiv(H, 8), gz), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -237,7 +237,7 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.ShgError('conv2d: residual shape mismatch')
     ws, ws_bytes = None, 0
-    if mode != MODE_UP2T:
+    if mode != MODE_UP2T or planar:      # split-K of the transposed conv is wired for the planar output only
         ws_bytes = int(lib.shg_conv2d_workspace_bytes(nb, i, pw.o, h, w, pw.kh, pw.kw, mode, pad, pw.groups))
         if ws_bytes:
             ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
