@@ -29,6 +29,19 @@ GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MA
 CONV_GFLOP_PER_IMAGE = {256: 180.3, 512: 238.3}   # the 3x3 convolutions alone
 
 
+def pmc_traffic(resolution, batch):
+    """HBM bytes per conv_mfma launch from the committed PMC summary (tools/gpu_traffic.sh: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside the process, so the number is attached from profiles/ when it matches the workload."""
+    path = os.path.join(ROOT, 'profiles', f'traffic_{resolution}x{batch}.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get('conv_mfma_kernel')
+    if not d:
+        return None
+    return round((d['read_bytes_per_launch'] + d['write_bytes_per_launch']) / 1e9, 4)
+
+
 def cpu_baseline(resolution, n_images, seed):
     """Time the CPU oracle (torch fp32 CPU ops, all host threads) on a bounded sample."""
     import torch
@@ -77,7 +90,8 @@ def main():
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run even a 1-rank job joins RCCL
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -95,18 +109,18 @@ def main():
         step()
     timer = kernels.KernelTimer()
     kernels.set_timer(timer)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     kernels.set_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -126,7 +140,8 @@ def main():
                        'parallelism': f'batch-shard x{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all 3x3/1x1 implicit-GEMM launches)',
                          'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(res, batch),
+                         'traffic_unit': 'GB per launch (HBM read+write, PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/traffic_*.json)',
                          'launches_per_step': summ['calls'] // max(a.steps, 1),
                          'kernel_ms_per_step': round(summ['ms'] / max(a.steps, 1), 3),
                          'gflop_per_step': round(summ['work'] / max(a.steps, 1) / 1e9, 1),
@@ -142,7 +157,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
