@@ -50,9 +50,19 @@ struct ConvParams {
     int OHt, OWt;            // full output tensor extent
     int S;                   // input stride
     int dy0, dx0;            // patch origin = (oy0*S + dy0, ox0*S + dx0)
-    int PH, PW, PATCH;       // patch rows/cols per image; PATCH = TN*PH*PW
-    int TW, TH, TN;          // pixel tile: TW x TH pixels of TN images (TW*TH*TN <= BP, any integers)
-    int tiles_x, tiles_y, n_ptiles, n_otiles;
+    int span_y, span_x;      // tap span: patch rows = (TH-1)*S + span_y, cols = (TW-1)*S + span_x
+    // Pixel tiles come in up to three classes, each a rectangular region of the launch grid with its own tile
+    // shape: the transposed conv covers u < H, v < W with well-shaped tiles and the extra row u = H / column
+    // v = W of its (H+1) x (W+1) grid with thin strips; every other convolution has one class.
+    struct TileClass {
+        int n_tiles;             // tiles of this class (per o-tile, per K-slice)
+        int TW, TH, TN;          // TW x TH pixels of TN images per tile (TW*TH*TN <= BP)
+        int tiles_x, tiles_y;
+        int oy_base, ox_base, rows, cols;   // region [oy_base, oy_base+rows) x [ox_base, ox_base+cols)
+        int PH, PW, PATCH;       // input patch of a tile: PATCH = TN*PH*PW elements per channel
+    } cls[3];
+    int patch_max, tn_max;   // LDS sizing
+    int n_ptiles, n_otiles;
     int wgroups;
     long wstride;
     int ksplit, i_per_slice;
@@ -118,8 +128,8 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     constexpr int NBUF = DB ? 2 : 1;
     float* Wl = smem;
     float* Sl = smem + NBUF * WSZ;
-    float* Xl = Sl + (p.in_scale ? p.TN * p.i_per_slice : 0);
-    const int XSZ = XP * p.PATCH;
+    float* Xl = Sl + (p.in_scale ? p.tn_max * p.i_per_slice : 0);
+    const int XSZ = XP * p.patch_max;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -130,15 +140,20 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     const int kslice = blockIdx.x / nwork;
     const int work = xcd_remap(blockIdx.x - kslice * nwork, nwork);
     const int otile = work / p.n_ptiles;
-    const int ptile = work - otile * p.n_ptiles;
-    const int txb = ptile % p.tiles_x;
-    const int tyb = (ptile / p.tiles_x) % p.tiles_y;
-    const int tnb = ptile / (p.tiles_x * p.tiles_y);
-    const int TN = p.TN, THW = p.TH * p.TW;
-    const int n0 = tnb * p.TN, oy0 = tyb * p.TH, ox0 = txb * p.TW;
+    int ptile = work - otile * p.n_ptiles;
+    int ci = 0;
+    if (ptile >= p.cls[0].n_tiles) { ptile -= p.cls[0].n_tiles; ci = 1; if (ptile >= p.cls[1].n_tiles) { ptile -= p.cls[1].n_tiles; ci = 2; } }
+    const ConvParams::TileClass& tc = p.cls[ci];
+    const int TW = tc.TW, TH = tc.TH, TN = tc.TN, PH_ = tc.PH, PW_ = tc.PW, PATCH = tc.PATCH;
+    const int txb = ptile % tc.tiles_x;
+    const int tyb = (ptile / tc.tiles_x) % tc.tiles_y;
+    const int tnb = ptile / (tc.tiles_x * tc.tiles_y);
+    const int THW = TH * TW;
+    const int n0 = tnb * TN, oy0 = tc.oy_base + tyb * TH, ox0 = tc.ox_base + txb * TW;
+    const int oy_end = tc.oy_base + tc.rows, ox_end = tc.ox_base + tc.cols;
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
-    const int PHW = p.PH * p.PW;
+    const int PHW = PH_ * PW_;
     const int i_begin = kslice * p.i_per_slice;
     const int i_end = min(p.I, i_begin + p.i_per_slice);
 
@@ -159,10 +174,10 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
         const int q = tid + k * NT;
         const int tn = q / PHW;
         const int rem = q - tn * PHW;
-        const int py = rem / p.PW, px = rem - py * p.PW;
+        const int py = rem / PW_, px = rem - py * PW_;
         const int n = n0 + tn;
         const int iy = oy0 * p.S + p.dy0 + py, ix = ox0 * p.S + p.dx0 + px;
-        const bool ok = (q < p.PATCH) && (n < p.NB) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
+        const bool ok = (q < PATCH) && (n < p.NB) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
         xoff[k] = ok ? (n * p.I * HW + iy * p.W + ix) : -1;
         xsn[k] = tn * p.i_per_slice;      // row of this element's image in the LDS scale table
     }
@@ -174,9 +189,10 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
         const int j = (wp * NP + np) * 32 + l31;
         int tn = j / THW;
         const int rem = j - tn * THW;
-        const int ty = rem / p.TW, tx = rem - ty * p.TW;
-        tn = tn < TN ? tn : 0;   // out-of-tile lanes read image 0 of the tile (masked on store)
-        xbase[np] = Xl + (tn * PHW + ty * p.S * p.PW + tx * p.S) * XP + half;
+        int ty = rem / TW;
+        const int tx = rem - ty * TW;
+        if (tn >= TN) { tn = 0; ty = 0; }   // out-of-tile lanes read pixel row 0 of image 0 (masked on store)
+        xbase[np] = Xl + (tn * PHW + ty * p.S * PW_ + tx * p.S) * XP + half;
     }
     const float* wa = Wl + wo * MO * 32 + l31 + half * NTAPS * BO;
 
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
             const int q = tid + k * NT;
             f32x4 sc = {1.f, 1.f, 1.f, 1.f};
             if (p.in_scale) sc = *reinterpret_cast<const f32x4*>(Sl + xsn[k] + (i0 - i_begin) + g * 4);
-            if (q < p.PATCH) {
+            if (q < PATCH) {
                 float* dst = Xl + buf * XSZ + q * XP + g * 4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -326,15 +342,19 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
         } else {
             // tap t = ky*3+kx feeds phase (ky&1, kx&1) from the input pixel shifted by (ky==2 ? -1 : 0, kx==2 ? -1 : 0);
             // the patch origin is (u0-1, v0-1), so shift (sy,sx) sits at patch offset (1+sy)*PW + (1+sx)
-            const int sh[4] = {(p.PW + 1) * XP, p.PW * XP, XP, 0};     // (0,0) (0,-1) (-1,0) (-1,-1)
+            const int sh[4] = {(PW_ + 1) * XP, PW_ * XP, XP, 0};     // (0,0) (0,-1) (-1,0) (-1,-1)
             constexpr int PHASE[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
             constexpr int SHIFT[9] = {0, 0, 1, 0, 0, 1, 2, 2, 3};
-            constexpr int NSLOT = 9 * (KC / 2);
-            float a[2][MO], b[2][4][NP];
+            // A slot = three taps (6 or 3*MO MFMAs): weight operands of slot s+1 are read while slot s multiplies, so
+            // LDS latency has >= 384 MFMA cycles of cover.
+            constexpr int NSLOT = 3 * (KC / 2);
+            float a[2][3][MO], b[2][4][NP];
             auto fetch_a = [&](int slot, int buf) __attribute__((always_inline)) {
-                const int c2 = slot / 9, t = slot % 9;
+                const int c2 = slot / 3, g = slot % 3;
 #pragma unroll
-                for (int mo = 0; mo < MO; ++mo) a[buf][mo] = wa_c[((c2 * 2) * 9 + t) * BO + mo * 32];
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int mo = 0; mo < MO; ++mo) a[buf][tt][mo] = wa_c[((c2 * 2) * 9 + g * 3 + tt) * BO + mo * 32];
             };
             auto fetch_b = [&](int c2, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -345,16 +365,20 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
             fetch_b(0, 0);
             fetch_a(0, 0);
             auto slot_body = [&](int slot) __attribute__((always_inline)) {
-                const int c2 = slot / 9, t = slot % 9;
+                const int c2 = slot / 3, g = slot % 3;
                 if (slot + 1 < NSLOT) fetch_a(slot + 1, (slot + 1) & 1);
-                if (t == 4 && c2 + 1 < KC / 2) fetch_b(c2 + 1, (c2 + 1) & 1);
+                if (g == 0 && c2 + 1 < KC / 2) fetch_b(c2 + 1, (c2 + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mo = 0; mo < MO; ++mo)
+                for (int tt = 0; tt < 3; ++tt) {
+                    const int t = g * 3 + tt;
 #pragma unroll
-                    for (int np = 0; np < NP; ++np)
-                        acc[PHASE[t]][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            a[slot & 1][mo], b[c2 & 1][SHIFT[t]][np], acc[PHASE[t]][mo][np], 0, 0, 0);
+                    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                        for (int np = 0; np < NP; ++np)
+                            acc[PHASE[t]][mo][np] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a[slot & 1][tt][mo], b[c2 & 1][SHIFT[t]][np], acc[PHASE[t]][mo][np], 0, 0, 0);
+                }
             };
             constexpr int Q1 = DB ? (TWO_GROUPS ? NSLOT / 4 : NSLOT / 2) : -1;
             constexpr int Q2 = (DB && TWO_GROUPS) ? (3 * NSLOT) / 4 : -1;
@@ -383,9 +407,9 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
         const int j = (wp * NP + np) * 32 + l31;
         const int tn = j / THW;
         const int rem = j - tn * THW;
-        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int ty = rem / TW, tx = rem - ty * TW;
         const int n = n0 + tn, oy = oy0 + ty, ox = ox0 + tx;
-        if (tn >= TN || n >= p.NB || oy >= p.OHp || ox >= p.OWp) continue;
+        if (tn >= TN || n >= p.NB || oy >= oy_end || ox >= ox_end) continue;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             long plane = (long)p.OHt * p.OWt;    // elements per (n,o) plane of the output
@@ -467,79 +491,93 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
 // ------------------------------------------------------------------------------------------------
 
 
-struct ConvPlan { int tw, th, tn, n_ptiles, n_otiles, ksplit, i_per_slice; };
-
-// Tile shape and split-K factor for a launch.  The BP pixels of a tile are TW x TH pixels of TN images; any
-// integers with TW*TH*TN <= BP are allowed, so grids such as 33 x 33 or 257 x 257 (the transposed conv) are
-// covered without the 2x padding waste of power-of-two tiles.  Chosen: the shape with the fewest tiles whose
-// input patch fits the staging capacity; ties go to rows that are multiples of 32 pixels (full 128-byte store
-// segments), then to the smallest patch (least halo traffic).
-static ConvPlan conv_plan(int NB, int I, int O, int OHp, int OWp, int BO, int BP, int KC, int wgroups, bool allow_split,
-                          int S = 1, int span_y = 1, int span_x = 1, int patch_cap = 1 << 30) {
-    ConvPlan c;
+// Tile shape for one rectangular region of `rows` x `cols` output pixels of NB images.  The BP pixels of a tile are
+// TW x TH pixels of TN images; any integers with TW*TH*TN <= BP are allowed, so odd extents do not pay the 2x padding
+// waste of power-of-two tiles.  Chosen: the shape with the fewest tiles whose input patch fits the staging capacity;
+// ties go to rows that are multiples of 32 pixels (full 128-byte store segments), then to the smallest patch.
+static void tile_search(ConvParams::TileClass& t, int NB, int rows, int cols, int BP, int wgroups, int S, int span_y, int span_x,
+                        int patch_cap) {
     long best = -1, bpatch = 0;
     int btw = 1, bth = 1, btn = 1, bfull = 0;
-    const int tw_max = OWp < BP ? OWp : BP;
+    const int tw_max = cols < BP ? cols : BP;
     for (int tw = 1; tw <= tw_max; ++tw) {
-        if (tw < 8 && tw != OWp && OWp >= 8) continue;          // keep rows reasonably long
-        int th = BP / tw; if (th > OHp) th = OHp;
+        if (tw < 8 && tw != cols && cols >= 8) continue;         // keep rows reasonably long
+        int th = BP / tw; if (th > rows) th = rows;
+        const long pw = (tw - 1) * S + span_x;
+        while (th > 1 && ((th - 1) * S + span_y) * pw > patch_cap) --th;   // shrink to the staging capacity
         int tn = BP / (tw * th); if (tn > NB) tn = NB;
         if (wgroups > 1) tn = 1;                                 // per-slot weights: one image per tile
         if (tn < 1) tn = 1;
-        const long patch = (long)tn * ((th - 1) * S + span_y) * ((tw - 1) * S + span_x);
+        while (tn > 1 && (long)tn * ((th - 1) * S + span_y) * pw > patch_cap) --tn;
+        const long patch = (long)tn * ((th - 1) * S + span_y) * pw;
         if (patch > patch_cap) continue;
-        const long tiles = (long)shg_cdiv(OWp, tw) * shg_cdiv(OHp, th) * shg_cdiv(NB, tn);
-        const int full = (tw % 32 == 0) ? 1 : 0;                // whole 128-byte store segments per (channel, row)
+        const long tiles = (long)shg_cdiv(cols, tw) * shg_cdiv(rows, th) * shg_cdiv(NB, tn);
+        const int full = (tw % 32 == 0) ? 1 : 0;
         if (best < 0 || tiles < best || (tiles == best && (full > bfull || (full == bfull && patch < bpatch)))) {
             best = tiles; bpatch = patch; btw = tw; bth = th; btn = tn; bfull = full;
         }
     }
-    if (best < 0) {    // nothing fits the staging capacity: fall back to a single row segment
-        btw = OWp < 32 ? OWp : 32; bth = 1; btn = 1;
-        best = (long)shg_cdiv(OWp, btw) * OHp * NB;
+    if (best < 0) { btw = cols < 32 ? cols : 32; bth = 1; btn = 1; }   // nothing fits: one row segment
+    t.TW = btw; t.TH = bth; t.TN = btn;
+    t.tiles_x = shg_cdiv(cols, btw); t.tiles_y = shg_cdiv(rows, bth);
+    t.n_tiles = t.tiles_x * t.tiles_y * shg_cdiv(NB, btn);
+    t.rows = rows; t.cols = cols;
+    t.PH = (bth - 1) * S + span_y; t.PW = (btw - 1) * S + span_x;
+    t.PATCH = btn * t.PH * t.PW;
+}
+
+// Fills p.cls / n_ptiles / n_otiles / patch_max / tn_max.  up: the (H+1) x (W+1) grid of the transposed conv is split
+// into the H x W body and the two one-pixel strips.
+static void conv_tiles(ConvParams& p, int BO, int BP, bool up, int patch_cap) {
+    for (int i = 0; i < 3; ++i) p.cls[i] = ConvParams::TileClass{};
+    if (!up) {
+        tile_search(p.cls[0], p.NB, p.OHp, p.OWp, BP, p.wgroups, p.S, p.span_y, p.span_x, patch_cap);
+    } else {
+        tile_search(p.cls[0], p.NB, p.H, p.W, BP, p.wgroups, 1, 2, 2, patch_cap);            // u < H, v < W
+        tile_search(p.cls[1], p.NB, 1, p.W + 1, BP, p.wgroups, 1, 2, 2, patch_cap);          // row u = H
+        p.cls[1].oy_base = p.H;
+        tile_search(p.cls[2], p.NB, p.H, 1, BP, p.wgroups, 1, 2, 2, patch_cap);              // column v = W
+        p.cls[2].ox_base = p.W;
     }
-    c.tw = btw; c.th = bth; c.tn = btn;
-    c.n_ptiles = (int)best;
-    c.n_otiles = shg_cdiv(O, BO);
-    const int chunks = shg_cdiv(I, KC);
+    p.n_ptiles = p.cls[0].n_tiles + p.cls[1].n_tiles + p.cls[2].n_tiles;
+    p.n_otiles = shg_cdiv(p.O, BO);
+    p.patch_max = 0; p.tn_max = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (p.cls[i].n_tiles == 0) continue;
+        if (p.cls[i].PATCH > p.patch_max) p.patch_max = p.cls[i].PATCH;
+        if (p.cls[i].TN > p.tn_max) p.tn_max = p.cls[i].TN;
+    }
+}
+
+// Split-K factor for a grid of `grid` workgroups over `chunks` K-chunks: aim at >= 2 workgroups per CU (512) while
+// keeping >= 4 chunks per slice.
+static int conv_ksplit(int grid, int chunks, bool allow) {
     int ks = 1;
-    if (allow_split) {
-        const int grid = c.n_ptiles * c.n_otiles;
-        // aim at >= 2 workgroups per CU (512) while keeping >= 4 chunks per slice
-        while (grid * ks < 512 && chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
-    }
-    c.i_per_slice = shg_cdiv(chunks, ks) * KC;
-    c.ksplit = shg_cdiv(I, c.i_per_slice);
-    return c;
+    if (allow) while (grid * ks < 512 && chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
+    return ks;
 }
 
 template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP, bool DB, int OCC>
 static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStream_t s) {
     constexpr int BO = MO * 32 * WO, BP = NP * 32 * WP, NT = WO * WP * 64;
     const long out_elems = (UP && p.out_mode == 1) ? 4L * p.NB * p.O * (p.H + 1) * (p.W + 1) : (long)p.NB * p.O * p.OHt * p.OWt;
-    ConvPlan c = conv_plan(p.NB, p.I, p.O, p.OHp, p.OWp, BO, BP, KC, p.wgroups, workspace != nullptr, p.S, p.PH, p.PW, XQ * NT);
+    conv_tiles(p, BO, BP, UP, XQ * NT);
+    const int chunks = shg_cdiv(p.I, KC);
+    int ks = conv_ksplit(p.n_ptiles * p.n_otiles, chunks, workspace != nullptr);
+    if (ks > 1 && (size_t)ks * out_elems * sizeof(float) > ws_bytes) ks = 1;      // workspace too small: no split
+    p.i_per_slice = shg_cdiv(chunks, ks) * KC;
+    p.ksplit = shg_cdiv(p.I, p.i_per_slice);
     p.raw_reduce = UP ? 1 : 0;
-    if (c.ksplit > 1 && (size_t)c.ksplit * out_elems * sizeof(float) > ws_bytes) {   // workspace too small: no split
-        c.ksplit = 1; c.i_per_slice = shg_cdiv(p.I, KC) * KC;
-    }
-    p.TW = c.tw; p.TH = c.th; p.TN = c.tn;
-    p.tiles_x = shg_cdiv(p.OWp, c.tw); p.tiles_y = shg_cdiv(p.OHp, c.th);
-    p.n_ptiles = c.n_ptiles; p.n_otiles = c.n_otiles;
-    p.ksplit = c.ksplit; p.i_per_slice = c.i_per_slice;
-    p.part = c.ksplit > 1 ? (float*)workspace : nullptr;
+    p.part = p.ksplit > 1 ? (float*)workspace : nullptr;
     p.part_stride = out_elems;
-    // patch extents: PH/PW hold the tap spans on entry
-    const int span_y = p.PH, span_x = p.PW;
-    p.PH = (c.th - 1) * p.S + span_y;
-    p.PW = (c.tw - 1) * p.S + span_x;
-    p.PATCH = c.tn * p.PH * p.PW;
-    if (p.PATCH > XQ * NT) { shg_set_error("conv: patch of %d elements exceeds the staging capacity %d", p.PATCH, XQ * NT); return SHG_ERR_UNSUPPORTED; }
+    if (p.patch_max > XQ * NT) { shg_set_error("conv: patch of %d elements exceeds the staging capacity %d", p.patch_max, XQ * NT); return SHG_ERR_UNSUPPORTED; }
     if (!UP)
         for (int t = 0; t < NTAPS; ++t) {
             const int dyr = p.tap_off[t] >> 6, dxr = p.tap_off[t] & 63;   // packed (dy-dy0, dx-dx0)
-            p.tap_off[t] = dyr * p.PW + dxr;
+            p.tap_off[t] = dyr * p.cls[0].PW + dxr;
         }
-    const size_t lds = sizeof(float) * ((DB ? 2 : 1) * ((size_t)KC * NTAPS * BO + (size_t)(KC + 1) * p.PATCH) + (p.in_scale ? (size_t)c.tn * p.i_per_slice : 0));
+    const size_t lds = sizeof(float) * ((DB ? 2 : 1) * ((size_t)KC * NTAPS * BO + (size_t)(KC + 1) * p.patch_max) +
+                                        (p.in_scale ? (size_t)p.tn_max * p.i_per_slice : 0));
     auto kern = conv_mfma_kernel<NTAPS, KC, MO, NP, WO, WP, XQ, UP, DB, OCC>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) { shg_set_error("conv: LDS request %zu exceeds 160 KiB", lds); return SHG_ERR_UNSUPPORTED; }
@@ -560,25 +598,34 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
 
 static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, size_t ws_bytes, hipStream_t s) {
     const bool narrow = p.O <= 64;    // 64 x 256 tile instead of 128 x 128
-    // SHG_CONV_VARIANT (tuning knob): 0 = default heuristics, 1 = force the single-buffer 4-wave kernels everywhere
+    // SHG_CONV_VARIANT (tuning knob, bit flags): 1 = force the single-buffer 4-wave kernels; 2 / 4 / 8 = try the 8-wave
+    // double-buffered variants for 64-channel layers / stride-2 (128 px) / stride-2 (256 px)
     static const int variant = getenv("SHG_CONV_VARIANT") ? atoi(getenv("SHG_CONV_VARIANT")) : 0;
     if (up) {
         // all-phase transposed conv: large grids use 8-wave double-buffered tiles (128 ch x 128 px, or 64 ch x 256 px),
         // small ones the 4-wave 64 ch x 128 px tile (+ split-K)
-        const bool big = variant == 0 && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1;
+        const bool big = !(variant & 1) && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1;
         if (big) return narrow ? launch_conv<9, 8, 2, 1, 1, 8, 1, true, true, 2>(p, workspace, ws_bytes, s)
                                : launch_conv<9, 8, 2, 1, 2, 4, 1, true, true, 2>(p, workspace, ws_bytes, s);
-        return launch_conv<9, 8, 2, 1, 1, 4, 1, true, false, 2>(p, workspace, ws_bytes, s);
+        return launch_conv<9, 8, 2, 1, 1, 4, 2, true, false, 2>(p, workspace, ws_bytes, s);
     }
     if (K == 9 && S == 1) {
         // large images, many channels: 8-wave 128 x 256 tile, double-buffered LDS, staggered hand-over
-        if (!narrow && variant == 0 && p.OWp >= 32 && p.OHp >= 8 && p.wgroups == 1)
+        if (!narrow && !(variant & 1) && p.OWp >= 32 && p.OHp >= 8 && p.wgroups == 1)
             return launch_conv<9, 8, 2, 2, 2, 4, 1, false, true, 2>(p, workspace, ws_bytes, s);
+        if (narrow && (variant & 2) && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1)
+            return launch_conv<9, 8, 2, 2, 1, 8, 2, false, true, 2>(p, workspace, ws_bytes, s);
         return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 2, false, false, 3>(p, workspace, ws_bytes, s)
                       : launch_conv<9, 8, 2, 2, 2, 2, 2, false, false, 2>(p, workspace, ws_bytes, s);
     }
-    if (K == 9 && S == 2) return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 5, false, false, 2>(p, workspace, ws_bytes, s)
-                                        : launch_conv<9, 8, 2, 2, 2, 2, 3, false, false, 2>(p, workspace, ws_bytes, s);
+    if (K == 9 && S == 2) {
+        if (!narrow && (variant & 4) && p.OWp >= 32 && p.OHp >= 4 && p.wgroups == 1)
+            return launch_conv<9, 8, 2, 1, 2, 4, 2, false, true, 2>(p, workspace, ws_bytes, s);
+        if (!narrow && !(variant & 1) && p.OWp >= 32 && p.OHp >= 8 && p.wgroups == 1 && !p.in_scale)
+            return launch_conv<9, 8, 2, 2, 2, 4, 3, false, true, 2>(p, workspace, ws_bytes, s);
+        return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 5, false, false, 2>(p, workspace, ws_bytes, s)
+                      : launch_conv<9, 8, 2, 2, 2, 2, 3, false, false, 2>(p, workspace, ws_bytes, s);
+    }
     if (K == 1 && S == 1) return narrow ? launch_conv<1, 32, 2, 2, 1, 4, 1, false, false, 3>(p, workspace, ws_bytes, s)
                                         : launch_conv<1, 32, 2, 2, 2, 2, 1, false, false, 3>(p, workspace, ws_bytes, s);
     shg_set_error("conv2d: 1x1 stride-2 convolution is not implemented (decimate with upfirdn2d first)");
@@ -609,7 +656,7 @@ static int conv_fill(ConvParams& p, const float* x, const float* wt, float* y, i
     if (mode == 2) {
         // transposed stride 2 (conv2d_resample.py:130-137): Y = 2u+a, X = 2v+b over u in [0,H], v in [0,W]
         p.OHt = 2 * H + 1; p.OWt = 2 * W + 1; p.OHp = H + 1; p.OWp = W + 1; p.S = 1;
-        p.dy0 = -1; p.dx0 = -1; p.PH = 2; p.PW = 2;    // taps reach rows u-1..u, cols v-1..v
+        p.dy0 = -1; p.dx0 = -1; p.span_y = 2; p.span_x = 2;    // taps reach rows u-1..u, cols v-1..v
         SHG_CHECK_ARG(4L * NB * O * (H + 1) * (W + 1) < 2147483647L, "conv2d: y is too large");
         return SHG_OK;
     }
@@ -618,7 +665,7 @@ static int conv_fill(ConvParams& p, const float* x, const float* wt, float* y, i
     SHG_CHECK_ARG(OH >= 1 && OW >= 1, "conv2d: output must be at least 1x1");
     SHG_CHECK_ARG((long)NB * O * OH * OW < 2147483647L, "conv2d: y is too large");
     p.OHp = p.OHt = OH; p.OWp = p.OWt = OW; p.S = S;
-    p.dy0 = -pad; p.dx0 = -pad; p.PH = kh; p.PW = kw;
+    p.dy0 = -pad; p.dx0 = -pad; p.span_y = kh; p.span_x = kw;
     for (int t = 0; t < kh * kw; ++t) p.tap_off[t] = ((t / kw) << 6) | (t % kw);
     return SHG_OK;
 }
@@ -644,10 +691,14 @@ extern "C" int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB,
 // Bytes of split-K workspace that shg_conv2d_f32 can use for this problem (0 = it will not split).
 extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W, int kh, int kw, int mode, int pad, int wgroups) {
     if (NB < 1 || I < 1 || O < 1) return 0;
+    ConvParams p{};
+    p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.wgroups = wgroups < 1 ? 1 : wgroups;
     if (mode == 2) {   // small transposed convs (the 4-wave 64 x 128 tile) may split; planar output of 4 phase planes
         if (W + 1 >= 32 && H + 1 >= 16) return 0;
-        ConvPlan c = conv_plan(NB, I, O, H + 1, W + 1, 64, 128, 8, wgroups < 1 ? 1 : wgroups, true, 1, 2, 2, 256);
-        return c.ksplit > 1 ? (size_t)c.ksplit * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
+        p.S = 1; p.span_y = 2; p.span_x = 2;
+        conv_tiles(p, 64, 128, true, 512);
+        const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, 8), true);
+        return ks > 1 ? (size_t)ks * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
     }
     const int S = mode == 0 ? 1 : 2;
     const int OH = (H + 2 * pad - kh) / S + 1, OW = (W + 2 * pad - kw) / S + 1;
@@ -655,8 +706,10 @@ extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W,
     const bool narrow = O <= 64;
     const int KC = kh * kw == 9 ? 8 : 32;
     const int xq = kh * kw == 1 ? 1 : (S == 1 ? 2 : (narrow ? 5 : 3));
-    ConvPlan c = conv_plan(NB, I, O, OH, OW, narrow ? 64 : 128, narrow ? 256 : 128, KC, wgroups < 1 ? 1 : wgroups, true, S, kh, kw, xq * 256);
-    return c.ksplit > 1 ? (size_t)c.ksplit * NB * O * OH * OW * sizeof(float) : 0;
+    p.OHp = OH; p.OWp = OW; p.S = S; p.span_y = kh; p.span_x = kw;
+    conv_tiles(p, narrow ? 64 : 128, narrow ? 256 : 128, false, xq * 256);
+    const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, KC), true);
+    return ks > 1 ? (size_t)ks * NB * O * OH * OW * sizeof(float) : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

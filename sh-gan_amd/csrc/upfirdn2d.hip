@@ -152,11 +152,13 @@ __global__ __launch_bounds__(256) void upfirdn_generic_kernel(const UfdParams p)
 // FIR after the all-phase transposed convolution (conv_mfma.hip, out_mode 1): the (2H+1)x(2W+1)
 // intermediate lives as four phase planes mid[(a*2+b)][nc][u][v] = full[2u+a][2v+b], each (H+1)x(W+1).
 // y[Y,X] = sum_{ky,kx<4} fk[ky][kx] * full[Y+ky-1][X+kx-1]   (pad [1,1,1,1], conv2d_resample.py:138).
-// One workgroup = an 8 x 64 tile of low-resolution pixels (16 x 128 outputs) of one (n,c) plane at a time:
-// the four 10 x 66 phase windows are staged in LDS with coalesced row loads, each lane then assembles the
-// 5 x 5 neighbourhood of its pixel (u,v) from LDS and writes the 2 x 2 outputs it owns as two float2.
+// One workgroup = an 8 x 128 tile of low-resolution pixels (16 x 256 outputs) of one (n,c) plane at a time:
+// the four 10 x 130 phase windows are staged in LDS with coalesced row loads; each lane owns two horizontally
+// adjacent low-res pixels, assembles their 5 x 7 neighbourhood from LDS and produces 2 x 4 outputs, so that the
+// skip tensor, the noise and the result move as 16-byte accesses.
+template <bool VEC>
 __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
-    constexpr int TU = 8, TV = 64, PU = TU + 2, PV = TV + 2, PITCH = PV + 1;   // odd planes need rows u0-1 .. u0+TU
+    constexpr int TU = 8, TV = 128, PU = TU + 2, PV = TV + 2, PITCH = PV + 1;
     __shared__ float tile[4][PU * PITCH];
     __shared__ float sf[16];
     if (threadIdx.x < 16) {
@@ -169,12 +171,12 @@ __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) fr[k] = sf[k];
     const int v0 = blockIdx.x * TV, u0 = blockIdx.y * TU;
-    const int tv = threadIdx.x & 63, tu0 = (threadIdx.x >> 6) * 2;      // each lane: low-res rows tu0, tu0+1
+    const int tv = (threadIdx.x & 63) * 2, tu0 = (threadIdx.x >> 6) * 2;   // lane: low-res cols tv, tv+1; rows tu0, tu0+1
     const int PWg = p.W + 1;
     const long P = (long)(p.H + 1) * PWg;
     for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
         const UfdPlane plq = ufd_plane(p, nc);
-        // plane (a,b) window: rows u0-a .. u0-a+TU, cols v0-b .. v0-b+TV  (full row Y = 2u+a, col X = 2v+b)
+        // plane (a,b) window: rows u0-a .. , cols v0-b ..   (full row Y = 2u+a, col X = 2v+b)
         for (int e = threadIdx.x; e < 4 * PU * PV; e += 256) {
             const int pl = e / (PU * PV), rem = e - pl * (PU * PV);
             const int r = rem / PV, c = rem - r * PV;
@@ -189,34 +191,58 @@ __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
         for (int q = 0; q < 2; ++q) {
             const int tu = tu0 + q;
             const int u = u0 + tu, v = v0 + tv;
-            // neighbourhood rows Y = 2u-1 .. 2u+3: (a=1,u-1) (a=0,u) (a=1,u) (a=0,u+1) (a=1,u+1); window row of
-            // plane a for low-res row u' is u' - (u0 - a)
-            float m[5][5];
+            // neighbourhood rows Y = 2u-1 .. 2u+3 and cols X = 2v-1 .. 2v+5; element (r,c) lives in plane
+            // (a,b) = ((r+1)&1, (c+1)&1) at window position (tu + (r>>1) + ..., tv + ...)
+            float m[5][7];
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                const int a = (r + 1) & 1;                 // r=0 -> Y odd
-                const int ur = tu + (r >> 1) - (a ? 1 : 0) + a;   // = (u-1,u,u,u+1,u+1) - (u0 - a)
+                const int a = (r + 1) & 1;
+                const int ur = tu + ((r + 1) >> 1) - 1 + a;
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
+                for (int c = 0; c < 7; ++c) {
                     const int b = (c + 1) & 1;
-                    const int vc = tv + (c >> 1) - (b ? 1 : 0) + b;
+                    const int vc = tv + ((c + 1) >> 1) - 1 + b;
                     m[r][c] = tile[a * 2 + b][ur * PITCH + vc];
                 }
             }
             if (u < p.H && v < p.W) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
-                    float o2[2];
+                    float o4[4];
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
+                    for (int dx = 0; dx < 4; ++dx) {
                         float acc = 0.f;
 #pragma unroll
                         for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
-                        o2[dx] = ufd_finish(p, plq, acc, (2 * u + dy) * p.OW + 2 * v + dx);
+                        o4[dx] = acc;
                     }
-                    *reinterpret_cast<float2*>(p.y + ((long)nc * p.OH + 2 * u + dy) * p.OW + 2 * v) = make_float2(o2[0], o2[1]);
+                    const int pix = (2 * u + dy) * p.OW + 2 * v;
+                    float* yp = p.y + (long)nc * p.OH * p.OW + pix;
+                    if (VEC && v + 1 < p.W) {
+                        // 16-byte path: scale / noise / bias / activation / skip on four outputs at once
+                        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.has_epilogue && plq.nz) nz = *reinterpret_cast<const float4*>(plq.nz + pix);
+                        if (p.has_epilogue && plq.res) rs = *reinterpret_cast<const float4*>(plq.res + pix);
+                        const float nzv[4] = {nz.x, nz.y, nz.z, nz.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                        float o[4];
+#pragma unroll
+                        for (int dx = 0; dx < 4; ++dx) {
+                            float t = o4[dx];
+                            if (p.has_epilogue) {
+                                t = t * plq.sc + nzv[dx] * p.noise_strength + plq.bs;
+                                if (p.act) t = shg_lrelu_agc(t, p.alpha, p.act_gain, p.clamp);
+                                t += rsv[dx];
+                            }
+                            o[dx] = t;
+                        }
+                        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+#pragma unroll
+                        for (int dx = 0; dx < 4; ++dx)
+                            if (2 * v + dx < p.OW) yp[dx] = ufd_finish(p, plq, o4[dx], pix + dx);
+                    }
                 }
             }
         }
@@ -310,7 +336,11 @@ extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, 
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
     const int gz = p.NC < 32768 ? p.NC : 32768;
-    hipLaunchKernelGGL(fir_up_planar_kernel, dim3(shg_cdiv(W, 64), shg_cdiv(H, 8), gz), dim3(256), 0, (hipStream_t)stream, p);
+    // 16-byte path needs 16-byte aligned rows of y / residual / noise: OW = 2W multiple of 4 and aligned bases
+    const bool vec = (W % 2 == 0) && (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)noise) % 16 == 0);
+    dim3 grid(shg_cdiv(W, 128), shg_cdiv(H, 8), gz);
+    if (vec) hipLaunchKernelGGL(fir_up_planar_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(fir_up_planar_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
