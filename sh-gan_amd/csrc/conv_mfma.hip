@@ -227,13 +227,18 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
 #pragma unroll
     for (int k = 0; k < XQ; ++k) xo[k] = xoff[k] >= 0 ? (unsigned)xoff[k] : 0u;
     constexpr int XG = KC / 4;                       // 4-channel groups per patch element
-    constexpr int NPIECE = PER + XQ * XG;
+    // Double-buffered variants move the weights global -> LDS directly (LDS-DMA, global_load_lds_dwordx4: the LDS
+    // image [ROWS][BO] is lane-linear, 1 KiB per wave instruction), so they need no staging registers or ds_writes;
+    // the single-buffer variants stage them through registers like the patch.
+    constexpr bool WDMA = DB;
+    constexpr int PW0 = WDMA ? 0 : PER;              // weight pieces in the register-staged list
+    constexpr int NPIECE = PW0 + XQ * XG;
 
     auto piece_load = [&](int j, int i0) __attribute__((always_inline)) {
-        if (j < PER) {
+        if (j < PW0) {
             if (!(p.dbg & 1)) wv[j] = *reinterpret_cast<const f32x4*>(wbase + (size_t)i0 * NTAPS * 64 + wl[j]);
         } else {
-            const int k = (j - PER) / XG, g = (j - PER) % XG;
+            const int k = (j - PW0) / XG, g = (j - PW0) % XG;
             if (!(p.dbg & 2)) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -245,11 +250,11 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     };
     auto piece_store = [&](int j, int i0, int buf) __attribute__((always_inline)) {
         if (p.dbg & 4) return;
-        if (j < PER) {
+        if (j < PW0) {
             const int e = tid + j * NT;
             if (e < V4) *reinterpret_cast<f32x4*>(Wl + buf * WSZ + e * 4) = wv[j];
         } else {
-            const int k = (j - PER) / XG, g = (j - PER) % XG;
+            const int k = (j - PW0) / XG, g = (j - PW0) % XG;
             const int q = tid + k * NT;
             f32x4 sc = {1.f, 1.f, 1.f, 1.f};
             if (p.in_scale) sc = *reinterpret_cast<const f32x4*>(Sl + xsn[k] + (i0 - i_begin) + g * 4);
@@ -262,6 +267,17 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
         }
     };
 
+    // weights of the chunk starting at channel i0 -> LDS buffer `buf` (whole waves: V4 is a multiple of 64)
+    auto w_dma = [&](int i0, int buf) __attribute__((always_inline)) {
+        if (p.dbg & 1) return;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if ((k + 1) * NT <= V4 || k * NT + wave * 64 < V4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (size_t)i0 * NTAPS * 64 + wl[k]),
+                                                 (__attribute__((address_space(3))) void*)(Wl + buf * WSZ + (k * NT + wave * 64) * 4), 16, 0, 0);
+        }
+    };
+    if (WDMA) w_dma(i_begin, 0);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin);
     __syncthreads();                 // scale table visible
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     for (int i0 = i_begin; i0 < i_end; i0 += KC, cur ^= (DB ? 1 : 0)) {
         const bool more = i0 + KC < i_end;          // DB: registers hold chunk i0+KC (loads issued one chunk ago)
         const bool more2 = i0 + 2 * KC < i_end;
+        if (WDMA && more) w_dma(i0 + KC, cur ^ 1);   // the other buffer is free since the barrier that ended chunk i0-KC
         if (!DB && more) {                           // single buffer: prefetch the next chunk into registers now
 #pragma unroll
             for (int j = 0; j < NPIECE; ++j) piece_load(j, i0 + KC);
@@ -615,6 +632,8 @@ static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, 
             return launch_conv<9, 8, 2, 2, 2, 4, 1, false, true, 2>(p, workspace, ws_bytes, s);
         if (narrow && (variant & 2) && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1)
             return launch_conv<9, 8, 2, 2, 1, 8, 2, false, true, 2>(p, workspace, ws_bytes, s);
+        if (narrow && (variant & 8) && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1)
+            return launch_conv<9, 8, 2, 2, 1, 4, 2, false, true, 2>(p, workspace, ws_bytes, s);
         return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 2, false, false, 3>(p, workspace, ws_bytes, s)
                       : launch_conv<9, 8, 2, 2, 2, 2, 2, false, false, 2>(p, workspace, ws_bytes, s);
     }
