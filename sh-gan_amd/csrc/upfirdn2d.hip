@@ -15,6 +15,7 @@
 //    comodgan.py:326-327) a single pass over HBM.
 //  * upfirdn_generic_kernel: any up/down/padding/filter (RGB skip upsample, D's down path, tests).
 #include "shg_common.h"
+#include <stdlib.h>
 
 struct UfdParams {
     const float* x;
@@ -33,6 +34,7 @@ struct UfdParams {
     int act;                 // 0 none, 1 lrelu_agc
     float alpha, act_gain, clamp;
     int has_epilogue;
+    int dbg;                 // timing studies (SHG_FIR_DBG): 1 skip window loads, 2 skip FIR math, 4 skip stores
 };
 
 __device__ __forceinline__ float ufd_epilogue(const UfdParams& p, float v, int nc, int oy, int ox) {
@@ -72,46 +74,80 @@ __device__ __forceinline__ float ufd_finish(const UfdParams& p, const UfdPlane& 
 }
 
 template <int FH, int FW>
-__global__ __launch_bounds__(256) void fir_same_kernel(const UfdParams p) {
-    constexpr int TH = 16, TW = 64, IH = TH + FH - 1, IW = TW + FW - 1, PITCH = IW + 1;
+__global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
+    constexpr int TH = 32, TW = 64, IH = TH + FH - 1, IW = TW + FW - 1, PITCH = IW + 1;
+    constexpr int RPT = (IH + 3) / 4;          // window rows staged per thread (4 row groups x 64 columns)
+    constexpr int NX = IH * (FW - 1);          // elements of the FW-1 extra window columns
+    static_assert(NX <= 256, "extra window columns must fit one pass");
     __shared__ float tile[IH * PITCH];
-    __shared__ float sf[FH * FW];
-    if (threadIdx.x < FH * FW) {
-        // stored so that sf[ky][kx] multiplies x[oy + ky - py0][ox + kx - px0]
-        const int ky = threadIdx.x / FW, kx = threadIdx.x % FW;
-        const int sy = p.flip ? ky : FH - 1 - ky, sx = p.flip ? kx : FW - 1 - kx;
-        sf[threadIdx.x] = p.f[sy * FW + sx] * p.gain;
-    }
-    __syncthreads();
+    // taps: uniform addresses -> scalar loads; fr[ky][kx] multiplies x[oy + ky - py0][ox + kx - px0]
     float fr[FH * FW];
 #pragma unroll
-    for (int k = 0; k < FH * FW; ++k) fr[k] = sf[k];
+    for (int k = 0; k < FH * FW; ++k) {
+        const int ky = k / FW, kx = k % FW;
+        const int sy = p.flip ? ky : FH - 1 - ky, sx = p.flip ? kx : FW - 1 - kx;
+        fr[k] = p.f[sy * FW + sx] * p.gain;
+    }
+    const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
-    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) * 4;
-    for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
-        const float* xp = p.x + (long)nc * p.H * p.W;
-        const UfdPlane pl = ufd_plane(p, nc);
-        for (int e = threadIdx.x; e < IH * IW; e += 256) {
-            const int r = e / IW, c = e - r * IW;
-            const int iy = oy0 + r - p.py0, ix = ox0 + c - p.px0;
-            tile[r * PITCH + c] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(long)iy * p.W + ix] : 0.f;
+    const int tx = tid & 63, rg = tid >> 6;          // compute: column tx, rows rg*8 .. rg*8+7; staging: column tx, rows rg, rg+4, ...
+    const int xr = tid / (FW - 1), xc = TW + tid % (FW - 1);
+    const bool xact = tid < NX;
+    const int ix0 = ox0 - p.px0 + tx, iy0 = oy0 - p.py0;
+    const int ixe = ox0 - p.px0 + xc, iye = iy0 + xr;
+    const bool xok = xact && iye >= 0 && iye < p.H && ixe >= 0 && ixe < p.W;
+    const long plane = (long)p.H * p.W;
+    float tvr[RPT + 1];
+    // unconditional loads from clamped 32-bit byte offsets off the uniform plane base, masked afterwards
+    auto load_tile = [&](int nc) __attribute__((always_inline)) {
+        int ix_i = ix0, rg_i = rg;
+        asm volatile("" : "+v"(ix_i), "+v"(rg_i));     // keep the per-load offsets / masks out of the loop-invariant set
+        const char* pb = reinterpret_cast<const char*>(p.x + nc * plane);
+        const bool okx = ix_i >= 0 && ix_i < p.W;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = rg_i + 4 * k;
+            const int iy = iy0 + r;
+            const bool ok = okx && r < IH && iy >= 0 && iy < p.H;
+            const unsigned boff = ok ? (unsigned)(iy * p.W + ix_i) * 4u : 0u;
+            const float val = *reinterpret_cast<const float*>(pb + boff);
+            tvr[k] = ok ? val : 0.f;
         }
+        const unsigned eoff = xok ? (unsigned)(iye * p.W + ixe) * 4u : 0u;
+        const float val = *reinterpret_cast<const float*>(pb + eoff);
+        tvr[RPT] = xok ? val : 0.f;
+    };
+    int nc = blockIdx.z;
+    if (nc < p.NC) load_tile(nc);
+    for (; nc < p.NC; nc += gridDim.z) {
+        const UfdPlane pl = ufd_plane(p, nc);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (rg + 4 * k < IH) tile[(rg + 4 * k) * PITCH + tx] = tvr[k];
+        if (xact) tile[xr * PITCH + xc] = tvr[RPT];
         __syncthreads();
-        float win[4 + FH - 1][FW];
-#pragma unroll
-        for (int r = 0; r < 4 + FH - 1; ++r)
-#pragma unroll
-            for (int k = 0; k < FW; ++k) win[r][k] = tile[(ty + r) * PITCH + tx + k];
+        if (nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);      // next plane's window, in flight during the FIR
         const int ox = ox0 + tx;
+        float* yp = p.y + (long)nc * p.OH * p.OW;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int oy = oy0 + ty + t;
-            float v = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int ty = rg * 8 + half * 4;
+            float win[4 + FH - 1][FW];
 #pragma unroll
-            for (int ky = 0; ky < FH; ++ky)
+            for (int r = 0; r < 4 + FH - 1; ++r)
 #pragma unroll
-                for (int kx = 0; kx < FW; ++kx) v += win[t + ky][kx] * fr[ky * FW + kx];
-            if (oy < p.OH && ox < p.OW) p.y[((long)nc * p.OH + oy) * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
+                for (int k = 0; k < FW; ++k) win[r][k] = tile[(ty + r) * PITCH + tx + k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int oy = oy0 + ty + t;
+                float v = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < FH; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < FW; ++kx) v += win[t + ky][kx] * fr[ky * FW + kx];
+                if (oy < p.OH && ox < p.OW) yp[oy * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
+            }
         }
         __syncthreads();
     }
@@ -156,93 +192,143 @@ __global__ __launch_bounds__(256) void upfirdn_generic_kernel(const UfdParams p)
 // the four 10 x 130 phase windows are staged in LDS with coalesced row loads; each lane owns two horizontally
 // adjacent low-res pixels, assembles their 5 x 7 neighbourhood from LDS and produces 2 x 4 outputs, so that the
 // skip tensor, the noise and the result move as 16-byte accesses.
-template <bool VEC>
-__global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
-    constexpr int TU = 8, TV = 128, PU = TU + 2, PV = TV + 2, PITCH = PV + 1;
+template <bool VEC, int TV>
+__global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p) {
+    // tile = TU x TV low-resolution pixels (TV = 128 / 64 / 32 for wide / medium / narrow images), 2 x 2 of them per lane
+    constexpr int LR = TV / 2, TU = 2 * (256 / LR), PU = TU + 2, PV = TV + 2, PITCH = PV + 1;
+    constexpr int G = 256 / TV;                // staging row groups
+    constexpr int NLD = 4 * PU / G;            // window rows staged per thread
+    constexpr int NXE = 8 * PU, NXS = (NXE + 255) / 256;   // elements of the two extra window columns, slots per thread
+    static_assert(4 * PU % G == 0, "window rows must split evenly over the staging groups");
     __shared__ float tile[4][PU * PITCH];
-    __shared__ float sf[16];
-    if (threadIdx.x < 16) {
-        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
-        const int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
-        sf[threadIdx.x] = p.f[sy * 4 + sx] * p.gain;
-    }
-    __syncthreads();
+    // filter taps: uniform addresses -> scalar loads, the 16 taps live in SGPRs
     float fr[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) fr[k] = sf[k];
+    for (int k = 0; k < 16; ++k) {
+        const int ky = k >> 2, kx = k & 3;
+        const int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
+        fr[k] = p.f[sy * 4 + sx] * p.gain;
+    }
+    const int tid = threadIdx.x;
     const int v0 = blockIdx.x * TV, u0 = blockIdx.y * TU;
-    const int tv = (threadIdx.x & 63) * 2, tu0 = (threadIdx.x >> 6) * 2;   // lane: low-res cols tv, tv+1; rows tu0, tu0+1
+    const int tv = (tid % LR) * 2, tu0 = (tid / LR) * 2;   // compute role: low-res cols tv, tv+1; rows tu0, tu0+1
     const int PWg = p.W + 1;
     const long P = (long)(p.H + 1) * PWg;
-    for (int nc = blockIdx.z; nc < p.NC; nc += gridDim.z) {
-        const UfdPlane plq = ufd_plane(p, nc);
-        // plane (a,b) window: rows u0-a .. , cols v0-b ..   (full row Y = 2u+a, col X = 2v+b)
-        for (int e = threadIdx.x; e < 4 * PU * PV; e += 256) {
-            const int pl = e / (PU * PV), rem = e - pl * (PU * PV);
-            const int r = rem / PV, c = rem - r * PV;
-            const int a = pl >> 1, b = pl & 1;
-            const int u = u0 - a + r, v = v0 - b + c;
+    // staging role: thread (g, col) fetches window column `col` of window rows g*NLD .. g*NLD+NLD-1, the rows of the
+    // four planes being numbered pl*PU + r.  Plane (a,b) holds full rows Y = 2u+a, cols X = 2v+b, and its window
+    // starts at (u0-a, v0-b).  The plane of every staged row is wave-uniform.  The two extra window columns are
+    // fetched one element per slot.
+    const int g = tid / TV, col = tid % TV;
+    const int gu = __builtin_amdgcn_readfirstlane(TV >= 64 ? g : (g >> 1));     // TV = 32: lanes of a wave span groups 2w, 2w+1
+    auto row_plane = [&](int k) __attribute__((always_inline)) {               // plane of staged row k (uniform)
+        return TV == 128 ? 2 * gu + k / PU : gu;
+    };
+    auto row_r = [&](int k) __attribute__((always_inline)) {                   // its row inside the plane window
+        return TV == 128 ? k % PU : (TV == 64 ? k : (g & 1) * NLD + k);
+    };
+    float tvr[NLD + NXS];
+    // unconditional loads from clamped 32-bit byte offsets off a uniform plane base (scalar base + vector offset
+    // addressing), masked afterwards: no divergent branches, one address register per load
+    auto load_tile = [&](int nc) __attribute__((always_inline)) {
+        // (opaque copies: keeps the per-load offsets and masks from being hoisted out of the plane loop, where they
+        // would occupy ~60 registers for the whole kernel)
+        int col_i = col, g_i = g, t_i = tid;
+        asm volatile("" : "+v"(col_i), "+v"(g_i), "+v"(t_i));
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int pl = row_plane(k);
+            const int r = TV == 32 ? (g_i & 1) * NLD + k : row_r(k);
+            const int pa = pl >> 1, pb_ = pl & 1;
+            const char* pb = reinterpret_cast<const char*>(p.x + ((long)pl * p.NC + nc) * P);   // uniform
+            const int u = u0 - pa + r, v = v0 - pb_ + col_i;
             // valid full-resolution rows: Y = 2u+a in [0, 2H]  <=>  u in [0, H-a]
-            const bool ok = u >= 0 && u <= p.H - a && v >= 0 && v <= p.W - b;
-            tile[pl][r * PITCH + c] = ok ? p.x[((long)pl * p.NC + nc) * P + (long)u * PWg + v] : 0.f;
+            const bool ok = v >= 0 && v <= p.W - pb_ && u >= 0 && u <= p.H - pa;
+            const unsigned boff = ok ? (unsigned)(u * PWg + v) * 4u : 0u;
+            const float val = (p.dbg & 1) ? 1.f : *reinterpret_cast<const float*>(pb + boff);
+            tvr[k] = ok ? val : 0.f;
+        }
+#pragma unroll
+        for (int x = 0; x < NXS; ++x) {
+            const int e = t_i + 256 * x;                 // extra element: window row e/2 (of 4*PU), column TV + (e&1)
+            const int R = e >> 1, pl = R / PU, r = R - pl * PU, c = TV + (e & 1);
+            const int u = u0 - (pl >> 1) + r, v = v0 - (pl & 1) + c;
+            const bool ok = e < NXE && u >= 0 && u <= p.H - (pl >> 1) && v <= p.W - (pl & 1);
+            const unsigned long eoff = ok ? ((unsigned long)((long)pl * p.NC + nc) * P + (unsigned)(u * PWg + v)) * 4ul : 0ul;
+            const float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.x) + eoff);
+            tvr[NLD + x] = ok ? val : 0.f;
+        }
+    };
+    int nc = blockIdx.z;
+    if (nc < p.NC) load_tile(nc);
+    for (; nc < p.NC; nc += gridDim.z) {
+        const UfdPlane plq = ufd_plane(p, nc);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) tile[row_plane(k)][row_r(k) * PITCH + col] = tvr[k];
+#pragma unroll
+        for (int x = 0; x < NXS; ++x) {
+            const int e = tid + 256 * x;
+            const int R = e >> 1, pl = R / PU, r = R - pl * PU;
+            if (e < NXE) tile[pl][r * PITCH + TV + (e & 1)] = tvr[NLD + x];
         }
         __syncthreads();
+        const int u = u0 + tu0, v = v0 + tv;
+        // next plane's window: in flight while this one is filtered
+        if (nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);
+        // neighbourhood of the lane's 2 x 2 low-res pixels: rows Y = 2u-1 .. 2u+5, cols X = 2v-1 .. 2v+5; element (r,c)
+        // lives in plane (ra,cb) = ((r+1)&1, (c+1)&1)
+        float m[7][7];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int tu = tu0 + q;
-            const int u = u0 + tu, v = v0 + tv;
-            // neighbourhood rows Y = 2u-1 .. 2u+3 and cols X = 2v-1 .. 2v+5; element (r,c) lives in plane
-            // (a,b) = ((r+1)&1, (c+1)&1) at window position (tu + (r>>1) + ..., tv + ...)
-            float m[5][7];
+        for (int r = 0; r < 7; ++r) {
+            const int ra = (r + 1) & 1;
+            const int ur = tu0 + ((r + 1) >> 1) - 1 + ra;
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int a = (r + 1) & 1;
-                const int ur = tu + ((r + 1) >> 1) - 1 + a;
-#pragma unroll
-                for (int c = 0; c < 7; ++c) {
-                    const int b = (c + 1) & 1;
-                    const int vc = tv + ((c + 1) >> 1) - 1 + b;
-                    m[r][c] = tile[a * 2 + b][ur * PITCH + vc];
-                }
+            for (int c = 0; c < 7; ++c) {
+                const int cb = (c + 1) & 1;
+                const int vc = tv + ((c + 1) >> 1) - 1 + cb;
+                m[r][c] = tile[ra * 2 + cb][ur * PITCH + vc];
             }
-            if (u < p.H && v < p.W) {
+        }
+        if (v < p.W) {
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    float o4[4];
+            for (int dy = 0; dy < 4; ++dy) {
+                __builtin_amdgcn_sched_barrier(0);     // one output row at a time: keeps the live set small
+                if (2 * u + dy >= p.OH) continue;
+                float o4[4];
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
+                    o4[dx] = (p.dbg & 2) ? m[dy][dx] : acc;
+                }
+                const int pix = (2 * u + dy) * p.OW + 2 * v;
+                float* yp = p.y + (long)nc * p.OH * p.OW + pix;
+                if (VEC && v + 1 < p.W) {
+                    // 16-byte path: scale / noise / bias / activation / skip on four outputs at once
+                    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.has_epilogue && plq.nz) nz = *reinterpret_cast<const float4*>(plq.nz + pix);
+                    const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+                    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.has_epilogue && plq.res) rs = *reinterpret_cast<const float4*>(plq.res + pix);
+                    const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                    float o[4];
 #pragma unroll
                     for (int dx = 0; dx < 4; ++dx) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-                            for (int kx = 0; kx < 4; ++kx) acc += m[dy + ky][dx + kx] * fr[ky * 4 + kx];
-                        o4[dx] = acc;
-                    }
-                    const int pix = (2 * u + dy) * p.OW + 2 * v;
-                    float* yp = p.y + (long)nc * p.OH * p.OW + pix;
-                    if (VEC && v + 1 < p.W) {
-                        // 16-byte path: scale / noise / bias / activation / skip on four outputs at once
-                        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (p.has_epilogue && plq.nz) nz = *reinterpret_cast<const float4*>(plq.nz + pix);
-                        if (p.has_epilogue && plq.res) rs = *reinterpret_cast<const float4*>(plq.res + pix);
-                        const float nzv[4] = {nz.x, nz.y, nz.z, nz.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-                        float o[4];
-#pragma unroll
-                        for (int dx = 0; dx < 4; ++dx) {
-                            float t = o4[dx];
-                            if (p.has_epilogue) {
-                                t = t * plq.sc + nzv[dx] * p.noise_strength + plq.bs;
-                                if (p.act) t = shg_lrelu_agc(t, p.alpha, p.act_gain, p.clamp);
-                                t += rsv[dx];
-                            }
-                            o[dx] = t;
+                        float t = o4[dx];
+                        if (p.has_epilogue) {
+                            t = t * plq.sc + nzv[dx] * p.noise_strength + plq.bs;
+                            if (p.act) t = shg_lrelu_agc(t, p.alpha, p.act_gain, p.clamp);
+                            t += rsv[dx];
                         }
-                        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
-                    } else {
-#pragma unroll
-                        for (int dx = 0; dx < 4; ++dx)
-                            if (2 * v + dx < p.OW) yp[dx] = ufd_finish(p, plq, o4[dx], pix + dx);
+                        o[dx] = t;
                     }
+                    if (!(p.dbg & 4) || o[0] == 12345.f) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx)
+                        if (2 * v + dx < p.OW) yp[dx] = ufd_finish(p, plq, o4[dx], pix + dx);
                 }
             }
         }
@@ -253,7 +339,10 @@ __global__ __launch_bounds__(256) void fir_up_planar_kernel(const UfdParams p) {
 static int ufd_launch(UfdParams& p, hipStream_t s) {
     const int gz = p.NC < 32768 ? p.NC : 32768;
     if (p.upx == 1 && p.upy == 1 && p.dnx == 1 && p.dny == 1 && p.fh == 4 && p.fw == 4) {
-        dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 16), gz);
+        // each workgroup walks several planes with the next window prefetched; ~8k workgroups in total
+        const int tiles = shg_cdiv(p.OW, 64) * shg_cdiv(p.OH, 32);
+        int gzs = 8192 / tiles; if (gzs < 1) gzs = 1; if (gzs > p.NC) gzs = p.NC;
+        dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 32), gzs);
         hipLaunchKernelGGL((fir_same_kernel<4, 4>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 4), gz);
@@ -335,12 +424,19 @@ extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, 
     p.scale = scale; p.bias = bias; p.noise = noise; p.residual = residual;
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
-    const int gz = p.NC < 32768 ? p.NC : 32768;
+    { const char* d = getenv("SHG_FIR_DBG"); p.dbg = d ? atoi(d) : 0; }
+    // each workgroup walks several (n,c) planes with the next window prefetched; ~8k workgroups keep 256 CUs busy
+    const int TV = W >= 96 ? 128 : (W >= 48 ? 64 : 32), TU = 1024 / TV;
+    const int tiles = shg_cdiv(W, TV) * shg_cdiv(H, TU);
+    int gz = 8192 / tiles; if (gz < 1) gz = 1; if (gz > p.NC) gz = p.NC;
     // 16-byte path needs 16-byte aligned rows of y / residual / noise: OW = 2W multiple of 4 and aligned bases
     const bool vec = (W % 2 == 0) && (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)noise) % 16 == 0);
-    dim3 grid(shg_cdiv(W, 128), shg_cdiv(H, 8), gz);
-    if (vec) hipLaunchKernelGGL(fir_up_planar_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(fir_up_planar_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    dim3 grid(shg_cdiv(W, TV), shg_cdiv(H, TU), gz);
+    void (*kern)(const UfdParams) =
+        TV == 128 ? (vec ? fir_up_planar_kernel<true, 128> : fir_up_planar_kernel<false, 128>)
+      : TV == 64  ? (vec ? fir_up_planar_kernel<true, 64> : fir_up_planar_kernel<false, 64>)
+                  : (vec ? fir_up_planar_kernel<true, 32> : fir_up_planar_kernel<false, 32>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

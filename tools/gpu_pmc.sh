@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 900 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $OUT -o pmc -- python tools/conv_bench.py "$FLT" > $OUT/stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $OUT -o pmc -- python ${PMC_SCRIPT:-tools/conv_bench.py} "$FLT" > $OUT/stdout.log 2>&1
 echo "exit $?" >> $OUT/stdout.log
 tail -5 $OUT/stdout.log
 ls $OUT
