@@ -98,6 +98,24 @@ int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float e
 int shg_modconv_style_prep_f32(const float* styles, int ld, const float* wsq, float* s_out, float* dcoef, int N, int I, int O,
                                int OP, int demod, float pre_gain, void* stream);
 
+/* Grouped forms (at most 32 groups per call): every style affine of a synthesis pass in one launch, and every
+ * normalisation / demodulation-coefficient computation in a second one.  Group g of shg_dense_grouped_f32 computes
+ * y = [x1 | x2] @ (w*wgain)^T + b*bgain with w [O, K1+K2] -- the concatenated input cat([w_i, x_global]) of
+ * comodgan.py:245-262,316-338 is read from its two sources; K2 = 0 -> plain dense.  The descriptor arrays are host
+ * memory (copied into the kernel arguments); the pointers inside are device pointers. */
+typedef struct {
+    const float* x1; const float* x2; const float* w; const float* b; float* y;
+    int ld1, ld2, K1, K2, O, ldy;
+    float wgain, bgain;
+} shg_dense_group;
+int shg_dense_grouped_f32(const shg_dense_group* groups, int G, int N, void* stream);
+typedef struct {
+    const float* styles; const float* wsq; float* s_out; float* dcoef;
+    int ld, I, O, OP, demod;
+    float pre_gain;
+} shg_style_group;
+int shg_modconv_style_prep_grouped_f32(const shg_style_group* groups, int G, int N, void* stream);
+
 /* ---- A16-A19: Spectral Hint Unit (shgan.py:312-336).
  * rfft2(norm='forward') + row shift of [C] planes of 64x64 per sample (x + n*x_batch_stride) -> T [N,2C,64,33]. */
 int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N, int C, void* stream);

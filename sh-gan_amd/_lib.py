@@ -10,13 +10,26 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
 c_f = ctypes.c_float
 c_l = ctypes.c_long
 c_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+
+class DenseGroup(ctypes.Structure):          # shg_dense_group
+    _fields_ = [('x1', c_fp), ('x2', c_fp), ('w', c_fp), ('b', c_fp), ('y', c_fp),
+                ('ld1', c_i), ('ld2', c_i), ('K1', c_i), ('K2', c_i), ('O', c_i), ('ldy', c_i),
+                ('wgain', c_f), ('bgain', c_f)]
+
+
+class StyleGroup(ctypes.Structure):          # shg_style_group
+    _fields_ = [('styles', c_fp), ('wsq', c_fp), ('s_out', c_fp), ('dcoef', c_fp),
+                ('ld', c_i), ('I', c_i), ('O', c_i), ('OP', c_i), ('demod', c_i), ('pre_gain', c_f)]
+
 
 # name -> argtypes (restype is int unless noted); mirrors include/shgan_hip.h one to one
 _SIGS = {
@@ -38,6 +51,8 @@ _SIGS = {
     'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_normalize_2nd_moment_f32': [c_fp, c_fp, c_i, c_i, c_f, c_fp],
     'shg_modconv_style_prep_f32': [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'shg_dense_grouped_f32': [ctypes.POINTER(DenseGroup), c_i, c_i, c_fp],
+    'shg_modconv_style_prep_grouped_f32': [ctypes.POINTER(StyleGroup), c_i, c_i, c_fp],
     'shg_shu_rfft2_shift_f32': [c_fp, c_l, c_fp, c_i, c_i, c_fp],
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],

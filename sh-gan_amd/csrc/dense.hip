@@ -7,6 +7,7 @@
 // streaming kernels: one wave per output feature walks a weight row with coalesced 256 B reads
 // while the activations of the whole batch sit in LDS.
 #include "shg_common.h"
+#include "../../include/shgan_hip.h"
 
 #define DENSE_MAXN 16     // samples per pass (larger batches are processed in slabs of DENSE_MAXN rows)
 
@@ -139,6 +140,140 @@ extern "C" int shg_modconv_style_prep_f32(const float* styles, int ld, const flo
     SHG_CHECK_ARG((size_t)I * 4 <= 64 * 1024, "style_prep: I too large");
     hipLaunchKernelGGL(modconv_style_prep_kernel, dim3(N, demod ? shg_cdiv(O, 64) : 1), dim3(256), sizeof(float) * I, (hipStream_t)stream, styles, ld, wsq,
                        s_out, dcoef, N, I, O, OP, demod, pre_gain);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped forms: all the style affines of a synthesis pass in one launch, then all their
+// normalisation / demodulation coefficients in a second one (23 + 23 + 23 small launches -> 2).
+// ------------------------------------------------------------------------------------------------
+#define SHG_MAX_GROUPS 32
+struct DenseGroupArgs {
+    shg_dense_group g[SHG_MAX_GROUPS];
+    int first_block[SHG_MAX_GROUPS + 1];   // prefix sum of ceil(O/4)
+    int G, N;
+};
+
+// Same mapping as dense_kernel (one wave per output feature); the input row is the concatenation [x1 | x2]
+// (comodgan.py:245-262,316-338: cat([w_i, x_global])) read from its two sources.
+__global__ __launch_bounds__(256) void dense_grouped_kernel(const DenseGroupArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int gi = 0;
+    while (gi + 1 < a.G && (int)blockIdx.x >= a.first_block[gi + 1]) ++gi;
+    const shg_dense_group& g = a.g[gi];
+    const int o = ((int)blockIdx.x - a.first_block[gi]) * 4 + wave;
+    if (o >= g.O) return;
+    const int n0 = blockIdx.y * DENSE_MAXN;
+    const int nb = min(DENSE_MAXN, a.N - n0);
+    const int K = g.K1 + g.K2;
+    const float* wr = g.w + (long)o * K;
+    float acc[DENSE_MAXN];
+#pragma unroll
+    for (int n = 0; n < DENSE_MAXN; ++n) acc[n] = 0.f;
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* xr = (seg == 0 ? g.x1 + (long)n0 * g.ld1 : g.x2 + (long)n0 * g.ld2);
+        const int ld = seg == 0 ? g.ld1 : g.ld2, Ks = seg == 0 ? g.K1 : g.K2;
+        const float* ws = wr + (seg == 0 ? 0 : g.K1);
+        if (Ks == 0) continue;
+#pragma unroll 2
+        for (int k = lane; k < Ks; k += 64) {
+            const float wv = ws[k];
+#pragma unroll
+            for (int n = 0; n < DENSE_MAXN; ++n) acc[n] += wv * xr[(long)min(n, nb - 1) * ld + k];
+        }
+    }
+    const float bias = g.b ? g.b[o] * g.bgain : 0.f;
+#pragma unroll
+    for (int n = 0; n < DENSE_MAXN; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && n < nb) g.y[(long)(n0 + n) * g.ldy + o] = v * g.wgain + bias;
+    }
+}
+
+extern "C" int shg_dense_grouped_f32(const shg_dense_group* groups, int G, int N, void* stream) {
+    SHG_CHECK_ARG(groups && G >= 1 && G <= SHG_MAX_GROUPS && N >= 1, "dense_grouped: bad arguments (at most %d groups)", SHG_MAX_GROUPS);
+    DenseGroupArgs a;
+    a.G = G; a.N = N; a.first_block[0] = 0;
+    for (int i = 0; i < G; ++i) {
+        const shg_dense_group& g = groups[i];
+        SHG_CHECK_ARG(g.x1 && g.w && g.y && g.K1 >= 1 && g.K2 >= 0 && (g.K2 == 0 || g.x2) && g.O >= 1 && g.ld1 >= g.K1 && g.ld2 >= g.K2 && g.ldy >= g.O,
+                      "dense_grouped: bad group %d", i);
+        a.g[i] = g;
+        a.first_block[i + 1] = a.first_block[i] + shg_cdiv(g.O, 4);
+    }
+    dim3 grid(a.first_block[G], shg_cdiv(N, DENSE_MAXN));
+    hipLaunchKernelGGL(dense_grouped_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+struct StyleGroupArgs {
+    shg_style_group g[SHG_MAX_GROUPS];
+    int first_block[SHG_MAX_GROUPS + 1];   // prefix sum of N * (demod ? ceil(O/64) : 1)
+    int G, N;
+};
+
+// modconv_style_prep_kernel for a list of layers: block -> (layer, sample n, 64-channel slab oc)
+__global__ __launch_bounds__(256) void modconv_style_prep_grouped_kernel(const StyleGroupArgs a) {
+    extern __shared__ float s2[];   // [I] squared normalised styles of sample n
+    __shared__ float red[256];
+    int gi = 0;
+    while (gi + 1 < a.G && (int)blockIdx.x >= a.first_block[gi + 1]) ++gi;
+    const shg_style_group& g = a.g[gi];
+    const int local = (int)blockIdx.x - a.first_block[gi];
+    const int n = local % a.N, oc = local / a.N;
+    const int N = a.N, I = g.I;
+    float snorm = 1.f;
+    if (g.demod) {      // batch-global RMS of the styles (stylegan.py:147)
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < N * I; e += 256) {
+            const float v = g.styles[(long)(e / I) * g.ld + (e % I)] * g.pre_gain;
+            acc += v * v;
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        snorm = rsqrtf(red[0] / (float)(N * I));
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < I; i += 256) {
+        const float v = g.styles[(long)n * g.ld + i] * g.pre_gain * snorm;
+        if (oc == 0) g.s_out[(long)n * I + i] = v;
+        s2[i] = v * v;
+    }
+    if (!g.demod || !g.dcoef) return;
+    __syncthreads();
+    const int oo = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int o = oc * 64 + oo;
+    float acc = 0.f;
+    if (o < g.O)
+        for (int i = sl; i < I; i += 4) acc += s2[i] * g.wsq[(long)i * g.OP + o];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && o < g.O) g.dcoef[(long)n * g.O + o] = rsqrtf(red[oo] + red[64 + oo] + red[128 + oo] + red[192 + oo] + 1e-8f);
+}
+
+extern "C" int shg_modconv_style_prep_grouped_f32(const shg_style_group* groups, int G, int N, void* stream) {
+    SHG_CHECK_ARG(groups && G >= 1 && G <= SHG_MAX_GROUPS && N >= 1, "style_prep_grouped: bad arguments (at most %d groups)", SHG_MAX_GROUPS);
+    StyleGroupArgs a;
+    a.G = G; a.N = N; a.first_block[0] = 0;
+    int imax = 1;
+    for (int i = 0; i < G; ++i) {
+        const shg_style_group& g = groups[i];
+        SHG_CHECK_ARG(g.styles && g.s_out && g.I >= 1 && g.ld >= g.I, "style_prep_grouped: bad group %d", i);
+        SHG_CHECK_ARG(!g.demod || (g.wsq && g.dcoef && g.O >= 1 && g.OP >= g.O), "style_prep_grouped: group %d: demodulation needs wsq and dcoef", i);
+        SHG_CHECK_ARG((size_t)g.I * 4 <= 64 * 1024, "style_prep_grouped: I too large");
+        a.g[i] = g;
+        a.first_block[i + 1] = a.first_block[i] + N * (g.demod ? shg_cdiv(g.O, 64) : 1);
+        if (g.I > imax) imax = g.I;
+    }
+    hipLaunchKernelGGL(modconv_style_prep_grouped_kernel, dim3(a.first_block[G]), dim3(256), sizeof(float) * imax, (hipStream_t)stream, a);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -18,6 +18,10 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _addr(t):
+    return t.data_ptr() if t is not None else None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -30,6 +34,15 @@ def _req(t, name, dtype=torch.float32):
     if t.dtype != dtype:
         raise _lib.ShgError(f'{name} must be {dtype} (got {t.dtype})')
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _req_rows(t, name):
+    """Like _req, but accepts 2-D views with a row stride (the C entry point takes a row pitch): never copies."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.ndim != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise _lib.ShgError(f'{name} must be a float32 HIP matrix with contiguous rows')
+    return t
 
 
 def _act_args(act, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0):
@@ -339,6 +352,51 @@ def modconv_style_prep(styles, pw=None, demod=True, pre_gain=1.0):
     check(_lib.get_lib().shg_modconv_style_prep_f32(_ptr(styles), styles.stride(0), _ptr(wsq), _ptr(s), _ptr(d), n, i, o, op,
                                                     int(bool(demod)), float(pre_gain), _stream()), 'modconv_style_prep')
     return s, d
+
+
+MAX_GROUPS = 32
+
+
+def dense_grouped(items):
+    """items: list of dicts(x1, x2|None, w, b|None, y, wgain, bgain): y = [x1 | x2] @ (w*wgain)^T + b*bgain, all in one
+    launch per 32 groups.  Rows of x1 / x2 / y may be strided (views); all share the batch size."""
+    if not items:
+        return
+    n = items[0]['x1'].shape[0]
+    for lo in range(0, len(items), MAX_GROUPS):
+        chunk = items[lo:lo + MAX_GROUPS]
+        arr = (_lib.DenseGroup * len(chunk))()
+        for g, it in zip(arr, chunk):
+            x1, x2, w, y = _req_rows(it['x1'], 'x1'), _req_rows(it.get('x2'), 'x2'), _req(it['w'], 'w'), _req_rows(it['y'], 'y')
+            k1 = x1.shape[1]
+            k2 = 0 if x2 is None else x2.shape[1]
+            if x1.shape[0] != n or y.shape[0] != n or w.shape[1] != k1 + k2 or y.shape[1] != w.shape[0]:
+                raise _lib.ShgError('dense_grouped: inconsistent shapes')
+            g.x1, g.x2, g.w, g.b, g.y = _addr(x1), _addr(x2), _addr(w), _addr(it.get('b')), _addr(y)
+            g.ld1, g.ld2, g.K1, g.K2, g.O, g.ldy = x1.stride(0), (x2.stride(0) if x2 is not None else 0), k1, k2, w.shape[0], y.stride(0)
+            g.wgain, g.bgain = float(it.get('wgain', 1.0)), float(it.get('bgain', 1.0))
+        check(_lib.get_lib().shg_dense_grouped_f32(arr, len(chunk), n, _stream()), 'dense_grouped')
+
+
+def modconv_style_prep_grouped(items):
+    """items: list of dicts(styles [N,I], pw|None, demod, pre_gain, s [N,I] out, d [N,O] out|None) -- one launch per 32."""
+    if not items:
+        return
+    n = items[0]['styles'].shape[0]
+    for lo in range(0, len(items), MAX_GROUPS):
+        chunk = items[lo:lo + MAX_GROUPS]
+        arr = (_lib.StyleGroup * len(chunk))()
+        for g, it in zip(arr, chunk):
+            st, s_out = _req_rows(it['styles'], 'styles'), _req(it['s'], 's')
+            demod = bool(it.get('demod', True))
+            pw = it.get('pw')
+            g.styles, g.s_out = _addr(st), _addr(s_out)
+            g.wsq = _addr(pw.wsq) if demod else None
+            g.dcoef = _addr(_req(it['d'], 'd')) if demod else None
+            g.ld, g.I = st.stride(0), st.shape[1]
+            g.O, g.OP = (pw.o, pw.op) if demod else (0, 0)
+            g.demod, g.pre_gain = int(demod), float(it.get('pre_gain', 1.0))
+        check(_lib.get_lib().shg_modconv_style_prep_grouped_f32(arr, len(chunk), n, _stream()), 'modconv_style_prep_grouped')
 
 
 # ------------------------------------------------------------------------------------------------

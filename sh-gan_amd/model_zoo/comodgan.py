@@ -106,6 +106,18 @@ class Encoder(nn.Module):
         return x, feats
 
 
+def _style_of(cache, layer):
+    return None if cache is None else cache.get(id(layer))
+
+
+def _style_in(cache, layer, w_iter, w0):
+    """The layer's style input cat([w_i, x_global]) (comodgan.py:253,258) -- skipped when its styles come from the cache."""
+    w = next(w_iter)
+    if cache is not None and id(layer) in cache:
+        return None
+    return torch.cat([w, w0], dim=1)
+
+
 class synthesis_block_first(nn.Module):
     """4x4 block: fc(x_global) reshaped + encoder feature, one modulated conv, torgb (comodgan.py:207-262)."""
 
@@ -122,15 +134,15 @@ class synthesis_block_first(nn.Module):
             self.torgb = torgb_layer(oc_n, rgb_n, 1, w0_dim + w_dim, activation=None)
             self.num_torgb += 1
 
-    def forward(self, x, x0, ws, fused_modconv=None, noise_mode='random'):
+    def forward(self, x, x0, ws, fused_modconv=None, noise_mode='random', style_cache=None):
         w0 = x.to(torch.float32)
         x = self.fc(w0).view(w0.size(0), -1, self.resolution, self.resolution)
         x = kernels.bias_act(x, residual=x0, act=False)
         w_iter = iter(ws.unbind(dim=1))
-        x = self.conv(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode)
+        x = self.conv(x, _style_in(style_cache, self.conv, w_iter, w0), noise_mode=noise_mode, styles_sd=_style_of(style_cache, self.conv))
         img = None
         if self.torgb is not None:
-            img = self.torgb(x, torch.cat([next(w_iter), w0], dim=1))
+            img = self.torgb(x, _style_in(style_cache, self.torgb, w_iter, w0), styles_sd=_style_of(style_cache, self.torgb))
         return x, img
 
 
@@ -149,17 +161,21 @@ class synthesis_block(stylegan_synthesis_block):
         if self.torgb is not None:
             self.torgb = torgb_layer(oc_n, rgb_n, 1, w_dim=w_dim + w0_dim, activation=None)
 
-    def forward(self, x, x0, img, ws, w0, fused_modconv=None, noise_mode='random'):
+    def forward(self, x, x0, img, ws, w0, fused_modconv=None, noise_mode='random', style_cache=None):
         w_iter = iter(ws.unbind(dim=1))
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
-        x = self.conv0(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode, residual=x0)
+        x = self.conv0(x, _style_in(style_cache, self.conv0, w_iter, w0), noise_mode=noise_mode, residual=x0,
+                       styles_sd=_style_of(style_cache, self.conv0))
         if self.res_link:
-            x = self.conv1(x, torch.cat([next(w_iter), w0], dim=1), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y)
+            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y,
+                           styles_sd=_style_of(style_cache, self.conv1))
         else:
-            x = self.conv1(x, torch.cat([next(w_iter), w0], dim=1), noise_mode=noise_mode)
+            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), noise_mode=noise_mode,
+                           styles_sd=_style_of(style_cache, self.conv1))
         if self.torgb is not None:
-            img = self.torgb(x, torch.cat([next(w_iter), w0], dim=1), base_img=img, base_filter=self.resample_filter)
+            img = self.torgb(x, _style_in(style_cache, self.torgb, w_iter, w0), base_img=img, base_filter=self.resample_filter,
+                             styles_sd=_style_of(style_cache, self.torgb))
         elif img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         return x, img
@@ -196,10 +212,54 @@ class Synthesis(nn.Module):
             block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
             w_idx += block.num_conv
         w0 = x
-        x, img = self.b4(x, feats[4], block_ws[0], noise_mode=noise_mode)
+        cache = self._all_styles(ws, w0.to(torch.float32))
+        x, img = self.b4(x, feats[4], block_ws[0], noise_mode=noise_mode, style_cache=cache)
         for res, cur_ws in zip(self.block_res[1:], block_ws[1:]):
-            x, img = getattr(self, f'b{res}')(x, feats[res], img, cur_ws, w0, noise_mode=noise_mode)
+            x, img = getattr(self, f'b{res}')(x, feats[res], img, cur_ws, w0, noise_mode=noise_mode, style_cache=cache)
         return img
+
+    def _all_styles(self, ws, w0):
+        """Every layer's styles = affine(cat[w_i, x_global]) (stylegan.py:284,327), their batch normalisation and the
+        demodulation coefficients (stylegan.py:147-155) in two grouped launches instead of three small ones per layer.
+        Returns {id(layer): (s [N,I], dcoef [N,O] | None)}."""
+        plan = []
+        w_idx = 0
+        for res in self.block_res:
+            block = getattr(self, f'b{res}')
+            layers = [block.conv] if res == self.block_res[0] else [block.conv0, block.conv1]
+            if block.torgb is not None:
+                layers.append(block.torgb)
+            for j, layer in enumerate(layers):
+                plan.append((layer, w_idx + j))
+            w_idx += block.num_conv
+        n, dev = ws.shape[0], ws.device
+        tot_i = sum(l.affine.weight.shape[0] for l, _ in plan)
+        tot_o = sum(l.weight.shape[0] for l, _ in plan if not isinstance(l, torgb_layer))
+        raw = torch.empty((n, tot_i), device=dev, dtype=torch.float32)
+        s_all = torch.empty(n * tot_i, device=dev, dtype=torch.float32)
+        d_all = torch.empty(max(n * tot_o, 1), device=dev, dtype=torch.float32)
+        dense_items, prep_items, cache = [], [], {}
+        oi = od = 0
+        for layer, wi in plan:
+            i_n = layer.affine.weight.shape[0]
+            aff = layer.affine
+            st = raw[:, oi:oi + i_n]
+            dense_items.append(dict(x1=ws[:, wi, :], x2=w0, w=aff.weight.detach(), b=None if aff.bias is None else aff.bias.detach(),
+                                    y=st, wgain=aff.weight_gain, bgain=aff.bias_gain))
+            s = s_all[n * oi:n * (oi + i_n)].view(n, i_n)
+            if isinstance(layer, torgb_layer):
+                prep_items.append(dict(styles=st, pw=None, demod=False, pre_gain=layer.weight_gain, s=s, d=None))
+                cache[id(layer)] = (s, None)
+            else:
+                o_n = layer.weight.shape[0]
+                d = d_all[n * od:n * (od + o_n)].view(n, o_n)
+                od += o_n
+                prep_items.append(dict(styles=st, pw=layer.prepped(), demod=True, pre_gain=1.0, s=s, d=d))
+                cache[id(layer)] = (s, d)
+            oi += i_n
+        kernels.dense_grouped(dense_items)
+        kernels.modconv_style_prep_grouped(prep_items)
+        return cache
 
 
 @register('comodgan_generator', version)

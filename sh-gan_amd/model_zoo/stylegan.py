@@ -264,10 +264,11 @@ class synthesis_layer(conv2d_layer):
     def _noise_strength_host(self):
         return _cache_of(self).get('ns', [self.noise_strength], lambda: float(self.noise_strength.detach().cpu()))
 
-    def forward(self, x, w, fused_modconv=True, gain=1, noise_mode='random', residual=None):
+    def forward(self, x, w, fused_modconv=True, gain=1, noise_mode='random', residual=None, styles_sd=None):
+        """``styles_sd`` (extension): the (normalised styles, demodulation coefficients) pair of this layer when the
+        caller has already computed it for all layers at once (comodgan.Synthesis); ``w`` is then unused."""
         if noise_mode not in ('random', 'const', 'none'):
             raise AssertionError(f'bad noise_mode {noise_mode!r}')
-        styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
@@ -278,7 +279,10 @@ class synthesis_layer(conv2d_layer):
             raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
         ns = self._noise_strength_host() if noise is not None else 0.0
         pw = self.prepped()
-        s, d = kernels.modconv_style_prep(styles, pw, demod=True)
+        if styles_sd is not None:
+            s, d = styles_sd
+        else:
+            s, d = kernels.modconv_style_prep(self.affine(w), pw, demod=True)
         b = self.bias.detach()
         if self.up == 1:
             return kernels.conv2d(x, pw, mode=kernels.MODE_SAME, pad=self.padding, in_scale=s, out_scale=d, noise=noise,
@@ -297,11 +301,13 @@ class torgb_layer(conv2d_layer):
                          resample_filter=None)
         self.affine = dense(w_dim, in_channels, bias=True, bias_init=1, activation=None)
 
-    def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None):
-        styles = self.affine(w)
+    def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None, styles_sd=None):
         if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
             raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
-        s, _ = kernels.modconv_style_prep(styles, None, demod=False, pre_gain=self.weight_gain)
+        if styles_sd is not None:
+            s = styles_sd[0]
+        else:
+            s, _ = kernels.modconv_style_prep(self.affine(w), None, demod=False, pre_gain=self.weight_gain)
         wmat = self.weight.detach().reshape(self.weight.shape[0], -1)
         return kernels.torgb(x, wmat, s, self.bias.detach(), base_up=base_img, f=base_filter)
 

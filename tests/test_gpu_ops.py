@@ -233,6 +233,46 @@ def test_dense_large_and_normalize(mods):
     assert rel_err(c(kk.normalize_2nd_moment(z.to(DEV))), ref.numpy()) < 1e-6
 
 
+def test_grouped_style_kernels(mods):
+    """shg_dense_grouped_f32 / shg_modconv_style_prep_grouped_f32 (all style affines of a pass in one launch, input
+    cat([w_i, x_global]) read from its two sources, strided output rows) == the per-layer calls == torch CPU."""
+    kk = mods['kernels']
+    rs = np.random.RandomState(21)
+    for n in (3, 16, 19):                      # 19 > DENSE_MAXN: second batch slab
+        ws = torch.from_numpy(rs.standard_normal((n, 5, 48)).astype(np.float32)).to(DEV)
+        w0 = torch.from_numpy(rs.standard_normal((n, 80)).astype(np.float32)).to(DEV)
+        dims = [(64, 96, True), (33, 70, True), (128, 3, False), (7, 200, True)]      # (I, O, demod)
+        raw = torch.empty((n, sum(d[0] for d in dims)), device=DEV)
+        d_items, p_items, refs = [], [], []
+        off = 0
+        for li, (i_n, o_n, demod) in enumerate(dims):
+            aw = torch.from_numpy(rs.standard_normal((i_n, 128)).astype(np.float32)).to(DEV)
+            ab = torch.from_numpy(rs.standard_normal(i_n).astype(np.float32)).to(DEV)
+            cw = torch.from_numpy(rs.standard_normal((o_n, i_n, 3, 3)).astype(np.float32)).to(DEV)
+            pw = kk.conv_weight_prep(cw, demod=True) if demod else None
+            st = raw[:, off:off + i_n]
+            off += i_n
+            d_items.append(dict(x1=ws[:, li, :], x2=w0, w=aw, b=ab, y=st, wgain=0.3, bgain=1.5))
+            s = torch.empty((n, i_n), device=DEV)
+            d = torch.empty((n, o_n), device=DEV) if demod else None
+            p_items.append(dict(styles=st, pw=pw, demod=demod, pre_gain=1.0 if demod else 0.25, s=s, d=d))
+            x = torch.cat([ws[:, li, :], w0], 1)
+            st_ref = kk.dense(x, aw, ab, wgain=0.3, bgain=1.5)
+            s_ref, d_ref = kk.modconv_style_prep(st_ref, pw, demod=demod, pre_gain=1.0 if demod else 0.25)
+            st_cpu = (x.cpu() @ (aw.cpu() * 0.3).t()) + ab.cpu() * 1.5
+            refs.append((st, st_ref, st_cpu, s, s_ref, d, d_ref))
+        kk.dense_grouped(d_items)
+        kk.modconv_style_prep_grouped(p_items)
+        for st, st_ref, st_cpu, s, s_ref, d, d_ref in refs:
+            assert rel_err(c(st), st_cpu.numpy()) < 1e-5
+            assert rel_err(c(st), c(st_ref)) < 1e-6          # (lane partial sums are grouped differently: not bit-equal)
+            assert rel_err(c(s), c(s_ref)) < 1e-5
+            if d is not None:
+                assert rel_err(c(d), c(d_ref)) < 1e-5
+    with pytest.raises(RuntimeError):
+        kk.dense_grouped([dict(x1=ws[:, 0, :], x2=w0, w=torch.zeros((4, 7), device=DEV), b=None, y=torch.zeros((n, 4), device=DEV))])
+
+
 def test_shu_golden(mods):
     """rFFT2 / heterogeneous filter / Gaussian split / irFFT2 kernels vs the reference's SHU (N=2)."""
     from shgan_amd.model_zoo import shgan
