@@ -75,6 +75,13 @@ int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB, int I, int
 /* Split-K workspace (bytes) shg_conv2d_f32 can use for this problem; 0 = no split.  Small grids (4x4..16x16 layers)
  * are split along the input channels so that they still fill 256 CUs. */
 size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W, int kh, int kw, int mode, int pad, int wgroups);
+/* Winograd F(2x2,3x3) form of the stride-1 3x3 'same' convolution (mode 0, pad 1 of shg_conv2d_f32; same fused operands and
+ * result up to fp32 round-off, 2.25x fewer MFMA flops).  Weights: w [O,I,3,3] with the per-output-channel factor wscale [O]
+ * (the `wscale` output of shg_conv_weight_prep_f32) -> wu [OP/64][ceil(I/8)][16][8][64] = G (w*wscale) G^T. */
+int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip, void* stream);
+int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                        const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
+                        float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* stream);
 /* mode 2 with out_mode 1 writes the four sub-pixel phases as planes [4][NB,O,H+1,W+1] (coalesced); this kernel applies the
  * 4x4 FIR of conv2d_resample.py:138 (pad 1) straight from the planes and fuses the synthesis-layer tail:
  * y [N,C,2H,2W] = lrelu_agc(FIR(mid)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.  H, W = low-res extents. */

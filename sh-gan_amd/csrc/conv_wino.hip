@@ -1,0 +1,364 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Alternative to conv_mfma.hip for the stride-1 3x3 'same' convolutions (pad 1) that dominate the generator forward
+// (conv2d_resample.py:145-147 as called from stylegan.py:226-238 and, modulated, stylegan.py:103-193): every 2x2 block
+// of outputs is computed from a 4x4 input block with 16 instead of 36 multiplications per (input, output) channel pair,
+//      Y = A^T [ (G g G^T) .* (B^T d B) ] A ,
+// still in exact fp32 arithmetic on the MFMA units (the transform matrices hold 0, +-1, +-1/2 only; measured
+// difference to the direct form ~1e-6 relative, tolerance of the path 1e-3).
+//
+// GEMM view: 16 independent products  M_xi[o, t] = sum_i U_xi[i, o] * V_xi[i, t]   (xi = position in the 4x4 block,
+// t = 2x2 output block).  One workgroup = 64 output channels x 64 blocks (4 x 16 blocks = 8 x 32 pixels of one image)
+// x all 16 positions: 64 accumulator tiles of 32x32 spread over 8 waves (wave w owns positions 2w, 2w+1).  K is
+// consumed in chunks of 8 input channels:
+//   * U chunk [16][8][64] (pre-transformed weights, prepared once per parameter version) arrives by LDS-DMA;
+//   * the raw 10 x 34 input patch of the chunk's 8 channels arrives by LDS-DMA (wave w: channel w), is transformed
+//     by the same wave (B^T d B, 32 add/sub per 4x4 block, per-sample style applied here) and written as V [16][8][64];
+//   * everything is double buffered: while chunk c is multiplied, U(c+1) / raw(c+2) are in flight and V(c+1) is built;
+//     one barrier per chunk.  The two wave groups build V at different points of the chunk so that one wave per SIMD
+//     always has MFMAs to issue.
+// Epilogue: the 16 M_xi of an (o, t) pair live in 8 different waves -> they are exchanged through LDS in four passes
+// of 32 channels x 32 blocks; each thread then applies A^T . A, the fused layer tail (demodulation coefficient, noise,
+// bias, lrelu_agc, skip) and stores two pixels at a time (128-byte row segments per 16 lanes).
+#include "shg_common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ float shg_wino_zeros[64];   // zero source for LDS-DMA lanes that fall into padding
+
+struct WinoParams {
+    const float* x;          // [NB, I, H, W]
+    const float* wu;         // transformed weights [OP/64][nchunk][16][8][64]
+    float* y;                // [NB, O, H, W]
+    const float* in_scale;   // [NB, I] or null
+    const float* out_scale;  // [NB, O] or null
+    const float* bias;       // [O] or null
+    const float* noise;      // see noise_mode
+    const float* residual;   // like y, added after the activation
+    int NB, I, O, OP, H, W;
+    int tiles_x, tiles_y;    // 32-pixel x 8-pixel tiles per image
+    int n_ttiles, n_otiles, nchunk;
+    int noise_mode;          // 0 none, 1 [H,W], 2 [NB,H,W]
+    float noise_strength;
+    int act;
+    float alpha, gain, clamp;
+    int dbg;                 // timing studies (SHG_WINO_DBG): 1 skip weight DMA, 2 skip patch DMA, 4 skip transform, 8 skip barriers, 16 skip epilogue
+};
+
+namespace wino {
+constexpr int KC = 8, BO = 64, TY = 4, TX = 16, BT = TY * TX;
+constexpr int PH = 2 * TY + 2, PW = 2 * TX + 2, PATCH = PH * PW;   // 10 x 34 raw patch
+constexpr int RP = 384;                                            // raw pitch per channel: 6 wave-wide DMA rows
+constexpr int U_SZ = 16 * KC * BO, V_SZ = 16 * KC * BT, R_SZ = KC * RP;
+constexpr int NT = 512;
+constexpr size_t LDS_BYTES = sizeof(float) * 2 * (U_SZ + V_SZ + R_SZ);
+}   // namespace wino
+
+__device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
+    using namespace wino;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ul = smem;                         // [2][16][8][64]
+    float* Vl = smem + 2 * U_SZ;              // [2][16][8][64]
+    float* Rl = Vl + 2 * V_SZ;                // [2][8][RP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int nwork = p.n_ttiles * p.n_otiles;
+    const int work = wino_xcd_remap(blockIdx.x, nwork);
+    const int otile = work / p.n_ttiles;
+    const int ttile = work - otile * p.n_ttiles;
+    const int txb = ttile % p.tiles_x;
+    const int tyb = (ttile / p.tiles_x) % p.tiles_y;
+    const int n = ttile / (p.tiles_x * p.tiles_y);
+    const int oy0 = tyb * (2 * TY), ox0 = txb * (2 * TX);
+    const int o0 = otile * BO;
+    const int HW = p.H * p.W;
+
+    // ---- LDS-DMA roles
+    // raw patch: wave w fetches channel w of the chunk, 6 rows of 64 patch elements (q = j*64 + lane)
+    const float* rsrc[6];
+    unsigned rstep[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = j * 64 + lane;
+        const int py = q / PW, px = q - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = q < PATCH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        rsrc[j] = ok ? p.x + ((long)n * p.I * HW + (long)iy * p.W + ix) : shg_wino_zeros;
+        rstep[j] = ok ? (unsigned)HW : 0u;
+    }
+    auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
+        if (p.dbg & 2) return;
+        const int ch = c * KC + wave;
+        const bool chok = ch < p.I;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float* src = chok ? rsrc[j] + (size_t)ch * rstep[j] : shg_wino_zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wave * RP + j * 64), 4, 0, 0);
+        }
+    };
+    // weights: 32 wave-wide 1 KiB pieces per chunk, 4 per wave
+    const float* ubase = p.wu + (size_t)otile * p.nchunk * U_SZ + lane * 4;
+    auto dma_u = [&](int c, int buf) __attribute__((always_inline)) {
+        if (p.dbg & 1) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 8 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + (size_t)c * U_SZ + piece * 256),
+                                             (__attribute__((address_space(3))) void*)(Ul + buf * U_SZ + piece * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- input transform role: channel `wave`, block `lane` (ty = lane/16, tx = lane%16)
+    const int tty = lane >> 4, ttx = lane & 15;
+    const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx;
+    float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
+    auto transform = [&](int c, int buf) __attribute__((always_inline)) {
+        if (p.dbg & 4) return;
+        const int ch = c * KC + wave;
+        const float sc = (p.in_scale && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;   // wave-uniform style of this channel
+        const float* rb = rbase + buf * R_SZ;
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(rb + r * PW);
+            const f32x2 hi = *reinterpret_cast<const f32x2*>(rb + r * PW + 2);
+            d[r][0] = lo[0] * sc; d[r][1] = lo[1] * sc; d[r][2] = hi[0] * sc; d[r][3] = hi[1] * sc;
+        }
+        // B^T d : rows
+        float e[4][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            e[0][cc] = d[0][cc] - d[2][cc];
+            e[1][cc] = d[1][cc] + d[2][cc];
+            e[2][cc] = d[2][cc] - d[1][cc];
+            e[3][cc] = d[1][cc] - d[3][cc];
+        }
+        float* vb = vbase + buf * V_SZ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vb[(r * 4 + 0) * KC * BT] = e[r][0] - e[r][2];
+            vb[(r * 4 + 1) * KC * BT] = e[r][1] + e[r][2];
+            vb[(r * 4 + 2) * KC * BT] = e[r][2] - e[r][1];
+            vb[(r * 4 + 3) * KC * BT] = e[r][1] - e[r][3];
+        }
+    };
+
+    // ---- MFMA role: positions 2*wave, 2*wave+1; 2 channel blocks x 2 pixel-block blocks each
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][ob][tb][r] = 0.f;
+    const float* abase = Ul + ((2 * wave) * KC + half) * BO + l31;    // + j*KC*BO + ks*2*BO + ob*32
+    const float* bbase = Vl + ((2 * wave) * KC + half) * BT + l31;
+
+    // ---- prologue
+    dma_raw(0, 0);
+    dma_u(0, 0);
+    if (p.nchunk > 1) dma_raw(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    transform(0, 0);
+    __syncthreads();
+
+    const int grp = wave >> 2;            // waves w and w+4 share a SIMD
+    for (int c = 0; c < p.nchunk; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < p.nchunk;
+        if (more) dma_u(c + 1, cur ^ 1);
+        if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
+        if (more && grp == 0) transform(c + 1, cur ^ 1);    // raw(c+1) landed before the previous barrier
+        const float* ab = abase + cur * U_SZ;
+        const float* bb = bbase + cur * V_SZ;
+        float a[2][2][2], b[2][2][2];
+        auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) a[buf][j][ob] = ab[(j * KC + ks * 2) * BO + ob * 32];
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) b[buf][j][tb] = bb[(j * KC + ks * 2) * BT + tb * 32];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            if (ks + 1 < KC / 2) fetch(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[j][ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks & 1][j][ob], b[ks & 1][j][tb], acc[j][ob][tb], 0, 0, 0);
+            if (ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && grp == 1) transform(c + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(p.dbg & 8)) __syncthreads();
+    }
+    if (p.dbg & 16) return;
+
+    // ---- epilogue: exchange through LDS (reusing the weight buffers), inverse transform, fused layer tail
+    float* Mx = Ul;                           // [16][32][32]
+    const long plane = (long)p.H * p.W;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int ob = pass >> 1, tb = pass & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                Mx[((2 * wave + j) * 32 + row) * 32 + l31] = acc[j][ob][tb][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + NT * q;
+            const int o_l = e >> 5, t_l = e & 31;
+            float m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 32 + t_l];
+            // A^T m A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+            float t0[4], t1[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                t0[cc] = m[0 * 4 + cc] + m[1 * 4 + cc] + m[2 * 4 + cc];
+                t1[cc] = m[1 * 4 + cc] - m[2 * 4 + cc] - m[3 * 4 + cc];
+            }
+            float yv[2][2];
+            yv[0][0] = t0[0] + t0[1] + t0[2]; yv[0][1] = t0[1] - t0[2] - t0[3];
+            yv[1][0] = t1[0] + t1[1] + t1[2]; yv[1][1] = t1[1] - t1[2] - t1[3];
+            const int t = tb * 32 + t_l;
+            const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
+            const int o = o0 + ob * 32 + o_l;
+            if (o >= p.O || oy >= p.H || ox >= p.W) continue;
+            const float osc = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
+            const float bs = p.bias ? p.bias[o] : 0.f;
+            const long base = ((long)n * p.O + o) * plane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (oy + i >= p.H) continue;
+                const int pix = (oy + i) * p.W + ox;
+                float out[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    float nz = 0.f;
+                    const bool okx = ox + jj < p.W;
+                    if (okx && p.noise_mode == 1) nz = p.noise[pix + jj] * p.noise_strength;
+                    else if (okx && p.noise_mode == 2) nz = p.noise[(long)n * plane + pix + jj] * p.noise_strength;
+                    float v = yv[i][jj] * osc + nz + bs;
+                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
+                    if (okx && p.residual) v += p.residual[base + pix + jj];
+                    out[jj] = v;
+                }
+                float* dst = p.y + base + pix;
+                if (ox + 1 < p.W && ((reinterpret_cast<uintptr_t>(dst) & 7) == 0)) {
+                    *reinterpret_cast<f32x2*>(dst) = f32x2{out[0], out[1]};
+                } else {
+                    dst[0] = out[0];
+                    if (ox + 1 < p.W) dst[1] = out[1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U = G g G^T per (o, i), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; g = w[o,i] * scale[o] (flip = true convolution).
+// Layout wu[otile][chunk][xi][k][64]: the [16][8][64] slice a workgroup needs per chunk is one contiguous 32 KiB run.
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* w, const float* scale, float* wu, int O, int I, int OP,
+                                                          int nchunk, int flip) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)OP * nchunk * 8;
+    if (e >= total) return;
+    const int o = (int)(e % OP);
+    const int i = (int)(e / OP);
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        g[t / 3][t % 3] = (o < O && i < I) ? w[((long)o * I + i) * 9 + tt] * scale[o] : 0.f;
+    }
+    float gg[4][3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        gg[0][cc] = g[0][cc];
+        gg[1][cc] = 0.5f * (g[0][cc] + g[1][cc] + g[2][cc]);
+        gg[2][cc] = 0.5f * (g[0][cc] - g[1][cc] + g[2][cc]);
+        gg[3][cc] = g[2][cc];
+    }
+    float* dst = wu + (((long)(o >> 6) * nchunk + (i >> 3)) * 16 * 8 + (i & 7)) * 64 + (o & 63);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dst[(long)(r * 4 + 0) * 8 * 64] = gg[r][0];
+        dst[(long)(r * 4 + 1) * 8 * 64] = 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]);
+        dst[(long)(r * 4 + 2) * 8 * 64] = 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]);
+        dst[(long)(r * 4 + 3) * 8 * 64] = gg[r][2];
+    }
+}
+
+// w [O,I,3,3], wscale [O] (per-output-channel factor: the demodulation pre-normalisation * gain of shg_conv_weight_prep_f32,
+// or all `gain`), wu [OP/64][ceil(I/8)][16][8][64] out (OP = O rounded up to 64; padding zero filled).
+extern "C" int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip,
+                                             void* stream) {
+    SHG_CHECK_ARG(w && wscale && wu, "weight_prep_wino: null pointer");
+    SHG_CHECK_ARG(O >= 1 && I >= 1 && OP % 64 == 0 && OP >= O, "weight_prep_wino: bad shape");
+    const int nchunk = shg_cdiv(I, 8);
+    const long total = (long)OP * nchunk * 8;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu, O, I, OP,
+                       nchunk, flip);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// y = act(out_scale[n,o] * conv3x3_same(x * in_scale[n,i], w) + noise*noise_strength + bias[o]) + residual, stride 1, pad 1.
+extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                   const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                   int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                   const float* residual, void* stream) {
+    SHG_CHECK_ARG(x && wu && y, "conv2d_wino: null pointer");
+    SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d_wino: empty tensor");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino: OP must be a multiple of 64 and >= O");
+    SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && (long)NB * O * H * W < 2147483647L, "conv2d_wino: tensor too large");
+    WinoParams p{};
+    p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
+    p.noise = noise_mode ? noise : nullptr; p.residual = residual;
+    p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
+    p.tiles_x = shg_cdiv(W, 2 * wino::TX); p.tiles_y = shg_cdiv(H, 2 * wino::TY);
+    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, 8);
+    p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)wino::LDS_BYTES);
+        if (e != hipSuccess) { shg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SHG_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel, dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), wino::LDS_BYTES, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

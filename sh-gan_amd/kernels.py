@@ -4,6 +4,7 @@ PyTorch is used for device memory and the current HIP stream only; every functio
 its tensors, allocates the output and enqueues exactly the HIP kernels of libshgan_hip.so on
 ``torch.cuda.current_stream()``.  CPU tensors are rejected (there is no CPU path in the product)."""
 import ctypes
+import os
 import math
 
 import torch
@@ -163,11 +164,24 @@ def composite_u8(x4, img):
 # ------------------------------------------------------------------------------------------------
 
 class PreppedWeight:
-    """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq)."""
-    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups')
+    """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq).  ``wu`` (Winograd
+    F(2x2,3x3) layout, shg_conv_weight_prep_wino_f32) is built on first use by a stride-1 3x3 convolution."""
+    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', '_w', '_wscale', '_flip')
 
-    def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1):
+    def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1, w=None, wscale=None, flip=False):
         self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.groups = wt, wsq, o, i, op, kh, kw, groups
+        self.wu, self._w, self._wscale, self._flip = None, w, wscale, flip
+
+    def wino(self):
+        if self.wu is None:
+            if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
+                raise _lib.ShgError('PreppedWeight.wino: needs an ungrouped 3x3 weight')
+            nchunk = (self.i + 7) // 8
+            self.wu = torch.empty((self.op // 64) * nchunk * 16 * 8 * 64, device=self.wt.device, dtype=torch.float32)
+            check(_lib.get_lib().shg_conv_weight_prep_wino_f32(_ptr(self._w), _ptr(self._wscale), _ptr(self.wu), self.o, self.i,
+                                                               self.op, int(bool(self._flip)), _stream()), 'conv_weight_prep_wino')
+            self._w = None          # the transformed copy is all that is needed from here on
+        return self.wu
 
 
 def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
@@ -186,7 +200,14 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
         wg = w[g * o:(g + 1) * o]
         check(lib.shg_conv_weight_prep_f32(_ptr(wg), _ptr(wt[g]), _ptr(wscale), _ptr(wsq[g]) if demod else None, o, i, kh, kw,
                                            op, int(bool(demod)), float(gain), int(bool(flip)), _stream()), 'conv_weight_prep')
-    return PreppedWeight(wt, wsq, o, i, op, kh, kw, groups)
+    keep = groups == 1 and kh == 3 and kw == 3
+    return PreppedWeight(wt, wsq, o, i, op, kh, kw, groups, w=w if keep else None, wscale=wscale if keep else None, flip=flip)
+
+
+# Winograd F(2x2,3x3) path for stride-1 3x3 'same' convolutions on images of at least WINO_MIN pixels per side
+# (SHG_WINO=0 keeps everything on the direct implicit-GEMM kernel).
+WINO = os.environ.get('SHG_WINO', '1') != '0'
+WINO_MIN = int(os.environ.get('SHG_WINO_MIN', '32'))
 
 
 MODE_SAME, MODE_DOWN2, MODE_UP2T = 0, 1, 2
@@ -254,6 +275,16 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
         ws_bytes = int(lib.shg_conv2d_workspace_bytes(nb, i, pw.o, h, w, pw.kh, pw.kw, mode, pad, pw.groups))
         if ws_bytes:
             ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
+    if (WINO and mode == MODE_SAME and pad == 1 and pw.kh == 3 and pw.kw == 3 and pw.groups == 1 and h >= WINO_MIN and w >= WINO_MIN
+            and (pw.wu is not None or pw._w is not None)):
+        wu = pw.wino()
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib.shg_conv2d_wino_f32(
+            _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(_req(in_scale, 'in_scale')), _ptr(_req(out_scale, 'out_scale')),
+            _ptr(_req(bias, 'bias')), _ptr(noise), nmode, float(noise_strength), a, al, g, cl, _ptr(residual), _stream()), 'conv2d_wino')
+        if t0 is not None:
+            _timer.end('conv_mfma', t0, 2.0 * nb * pw.o * i * 9 * oh * ow)      # direct-form (algorithmic) flops
+        return y
     t0 = _timer.begin() if _timer is not None else None
     check(lib.shg_conv2d_f32(
         _ptr(x), _ptr(pw.wt), _ptr(y), nb, i, pw.o, pw.op, h, w, pw.kh, pw.kw, mode, pad, pw.groups, pw.wt.shape[1],

@@ -144,6 +144,55 @@ def test_mfma_conv_vs_torch_cpu(mods, n, ci, co, h, w, k, mode, pad):
     assert rel_err(c(y), ref.numpy()) < 2e-5
 
 
+WINO_CASES = [
+    # n, ci, co, h, w : ragged channel counts (I % 8, O % 64), odd extents, several tiles per image, one-chunk K
+    (2, 64, 64, 32, 32), (1, 13, 70, 33, 37), (3, 8, 3, 40, 64), (2, 72, 130, 35, 66), (1, 128, 64, 64, 96), (2, 5, 5, 32, 33),
+]
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', WINO_CASES)
+def test_wino_conv_vs_torch_cpu_and_direct(mods, n, ci, co, h, w):
+    """Winograd F(2x2,3x3) kernel (shg_conv2d_wino_f32) vs torch CPU conv2d and vs the direct MFMA kernel, with the
+    whole fused tail (styles, demodulation coefficient, per-sample noise, bias, lrelu_agc, skip) and true-convolution
+    (flipped) weights."""
+    import torch.nn.functional as F
+    kk, orc = mods['kernels'], mods['orc']
+    rs = np.random.RandomState(n * 100 + ci + co + h)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = torch.from_numpy(rs.standard_normal((co, ci, 3, 3)).astype(np.float32))
+    s_in = torch.from_numpy(rs.rand(n, ci).astype(np.float32) + 0.5)
+    s_out = torch.from_numpy(rs.rand(n, co).astype(np.float32) + 0.5)
+    bias = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((n, 1, h, w)).astype(np.float32))
+    res = torch.from_numpy(rs.standard_normal((n, co, h, w)).astype(np.float32))
+    for flip in (False, True):
+        wref = wt.flip([2, 3]) if flip else wt
+        ref = F.conv2d(x * s_in[:, :, None, None], wref * 0.1, padding=1) * s_out[:, :, None, None] + noise * 0.25
+        ref = orc.lrelu_agc(ref + bias.view(1, -1, 1, 1), gain=0.5) + res
+        args = dict(mode=0, pad=1, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
+                    noise_strength=0.25, act=True, gain=0.5, residual=res.to(DEV))
+        old = kk.WINO
+        try:
+            kk.WINO = True
+            pw = kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip)
+            y = kk.conv2d(x.to(DEV), pw, **args)
+            assert pw.wu is not None, 'the Winograd path was not taken'
+            kk.WINO = False
+            yd = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip), **args)
+        finally:
+            kk.WINO = old
+        assert rel_err(c(y), ref.numpy()) < 2e-5
+        assert rel_err(c(y), c(yd)) < 2e-5
+    # plain form: no fused operands, linear output
+    kk_old = kk.WINO
+    try:
+        kk.WINO = True
+        y = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV)), mode=0, pad=1)
+    finally:
+        kk.WINO = kk_old
+    assert rel_err(c(y), F.conv2d(x, wt, padding=1).numpy()) < 2e-5
+
+
 def test_mfma_conv_fused_epilogue(mods):
     import torch.nn.functional as F
     kk, orc = mods['kernels'], mods['orc']
