@@ -12,7 +12,7 @@
 // x all 16 positions: 64 accumulator tiles of 32x32 spread over 8 waves (wave w owns positions 2w, 2w+1).  K is
 // consumed in chunks of 8 input channels:
 //   * U chunk [16][8][64] (pre-transformed weights, prepared once per parameter version) arrives by LDS-DMA;
-//   * the raw 10 x 34 input patch of the chunk's 8 channels arrives by LDS-DMA (wave w: channel w), is transformed
+//   * the raw 10 x 40 input window of the chunk's 8 channels arrives by 16-byte LDS-DMA (wave w: channel w), is transformed
 //     by the same wave (B^T d B, 32 add/sub per 4x4 block, per-sample style applied here) and written as V [16][8][64];
 //   * everything is double buffered: while chunk c is multiplied, U(c+1) / raw(c+2) are in flight and V(c+1) is built;
 //     one barrier per chunk.  The two wave groups build V at different points of the chunk so that one wave per SIMD
@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ float shg_wino_zeros[64];   // zero source for LDS-DMA lanes that fall into padding
+__device__ __attribute__((aligned(16))) float shg_wino_zeros[64];   // zero source for LDS-DMA lanes that fall into padding
 
 struct WinoParams {
     const float* x;          // [NB, I, H, W]
@@ -50,8 +50,10 @@ struct WinoParams {
 
 namespace wino {
 constexpr int KC = 8, BO = 64, TY = 4, TX = 16, BT = TY * TX;
-constexpr int PH = 2 * TY + 2, PW = 2 * TX + 2, PATCH = PH * PW;   // 10 x 34 raw patch
-constexpr int RP = 384;                                            // raw pitch per channel: 6 wave-wide DMA rows
+// raw window per channel: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35 (16-byte aligned in global memory when W % 4 == 0,
+// and every float4 is either inside the image or entirely padding) = 10 x 10 float4, fetched by two 16-byte LDS-DMAs
+constexpr int PH = 2 * TY + 2, PW = 2 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
+constexpr int RP = PH * PW;                                        // 400 floats per channel
 constexpr int U_SZ = 16 * KC * BO, V_SZ = 16 * KC * BT, R_SZ = KC * RP;
 constexpr int NT = 512;
 constexpr size_t LDS_BYTES = sizeof(float) * 2 * (U_SZ + V_SZ + R_SZ);
@@ -87,15 +89,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int HW = p.H * p.W;
 
     // ---- LDS-DMA roles
-    // raw patch: wave w fetches channel w of the chunk, 6 rows of 64 patch elements (q = j*64 + lane)
-    const float* rsrc[6];
-    unsigned rstep[6];
+    // raw window: wave w fetches channel w of the chunk as float4 q = j*64 + lane (j = 0, 1; q < 100)
+    const float* rsrc[2];
+    unsigned rstep[2];
+    bool ract[2];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const int q = j * 64 + lane;
-        const int py = q / PW, px = q - py * PW;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool ok = q < PATCH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int py = q / PW4, p4 = q - py * PW4;
+        const int iy = oy0 - 1 + py, ix = ox0 - 4 + 4 * p4;
+        const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
+        ract[j] = q < PATCH4;
         rsrc[j] = ok ? p.x + ((long)n * p.I * HW + (long)iy * p.W + ix) : shg_wino_zeros;
         rstep[j] = ok ? (unsigned)HW : 0u;
     }
@@ -104,10 +108,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         const int ch = c * KC + wave;
         const bool chok = ch < p.I;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const float* src = chok ? rsrc[j] + (size_t)ch * rstep[j] : shg_wino_zeros;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wave * RP + j * 64), 4, 0, 0);
+            if (ract[j])       // (inactive lanes write nothing: the window is 100 float4, the second piece 36 lanes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wave * RP + j * 256), 16, 0, 0);
         }
     };
     // weights: 32 wave-wide 1 KiB pieces per chunk, 4 per wave
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
 
     // ---- input transform role: channel `wave`, block `lane` (ty = lane/16, tx = lane%16)
     const int tty = lane >> 4, ttx = lane & 15;
-    const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx;
+    const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
     float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 4) return;
@@ -134,9 +139,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         float d[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x2 lo = *reinterpret_cast<const f32x2*>(rb + r * PW);
-            const f32x2 hi = *reinterpret_cast<const f32x2*>(rb + r * PW + 2);
-            d[r][0] = lo[0] * sc; d[r][1] = lo[1] * sc; d[r][2] = hi[0] * sc; d[r][3] = hi[1] * sc;
+            const f32x2 q0 = *reinterpret_cast<const f32x2*>(rb + r * PW);
+            const f32x2 q1 = *reinterpret_cast<const f32x2*>(rb + r * PW + 2);
+            const f32x2 q2 = *reinterpret_cast<const f32x2*>(rb + r * PW + 4);
+            d[r][0] = q0[1] * sc; d[r][1] = q1[0] * sc; d[r][2] = q1[1] * sc; d[r][3] = q2[0] * sc;
         }
         // B^T d : rows
         float e[4][4];
@@ -342,6 +348,7 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d_wino: empty tensor");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino: OP must be a multiple of 64 and >= O");
     SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && (long)NB * O * H * W < 2147483647L, "conv2d_wino: tensor too large");
+    SHG_CHECK_ARG(W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "conv2d_wino: needs W %% 4 == 0 and a 16-byte aligned x (use shg_conv2d_f32 otherwise)");
     WinoParams p{};
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;

@@ -146,7 +146,8 @@ def test_mfma_conv_vs_torch_cpu(mods, n, ci, co, h, w, k, mode, pad):
 
 WINO_CASES = [
     # n, ci, co, h, w : ragged channel counts (I % 8, O % 64), odd extents, several tiles per image, one-chunk K
-    (2, 64, 64, 32, 32), (1, 13, 70, 33, 37), (3, 8, 3, 40, 64), (2, 72, 130, 35, 66), (1, 128, 64, 64, 96), (2, 5, 5, 32, 33),
+    (2, 64, 64, 32, 32), (1, 13, 70, 33, 36), (3, 8, 3, 40, 64), (2, 72, 130, 35, 68), (1, 128, 64, 64, 96), (2, 5, 5, 32, 44),
+    (1, 16, 16, 32, 33),      # W % 4 != 0: the wrapper must fall back to the direct kernel
 ]
 
 
@@ -176,7 +177,7 @@ def test_wino_conv_vs_torch_cpu_and_direct(mods, n, ci, co, h, w):
             kk.WINO = True
             pw = kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip)
             y = kk.conv2d(x.to(DEV), pw, **args)
-            assert pw.wu is not None, 'the Winograd path was not taken'
+            assert (pw.wu is not None) == (w % 4 == 0), 'Winograd dispatch: taken iff the 16-byte window DMA applies'
             kk.WINO = False
             yd = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip), **args)
         finally:
