@@ -131,10 +131,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int tty = lane >> 4, ttx = lane & 15;
     const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
     float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
+    // styles of channel `wave` of every chunk, one lane per chunk (up to 128 chunks = 1024 input channels)
+    float scv[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int ch = (v * 64 + lane) * KC + wave;
+        scv[v] = (p.in_scale && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
+    }
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 4) return;
-        const int ch = c * KC + wave;
-        const float sc = (p.in_scale && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;   // wave-uniform style of this channel
+        // style of this wave's channel in chunk c: lane c%64 of the preloaded vector c/64
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
         const float* rb = rbase + buf * R_SZ;
         float d[4][4];
 #pragma unroll
@@ -228,6 +235,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     // ---- epilogue: exchange through LDS (reusing the weight buffers), inverse transform, fused layer tail
     float* Mx = Ul;                           // [16][32][32]
     const long plane = (long)p.H * p.W;
+    // per-thread items of a pass: e = tid + 512*q -> channel o_l = e/32 of the 32-channel block, pixel block t_l = e%32.
+    // The per-channel and per-pixel operands of all four passes are requested up front (one latency, not eight).
+    float osc[2][2], bsv[2][2];               // [ob][q]
+    f32x2 nzv[2][2][2];                       // [tb][q][row]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + NT * q;
+        const int o_l = e >> 5, t_l = e & 31;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const int o = min(o0 + ob * 32 + o_l, p.O - 1);
+            osc[ob][q] = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
+            bsv[ob][q] = p.bias ? p.bias[o] : 0.f;
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int t = tb * 32 + t_l;
+            const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                nzv[tb][q][i] = f32x2{0.f, 0.f};
+                if (p.noise_mode && oy + i < p.H && ox < p.W) {       // W % 4 == 0 and ox even: both pixels inside, 8-byte aligned
+                    const float* np_ = p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + (long)(oy + i) * p.W + ox;
+                    nzv[tb][q][i] = *reinterpret_cast<const f32x2*>(np_);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int ob = pass >> 1, tb = pass & 1;
@@ -260,32 +295,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
             const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
             const int o = o0 + ob * 32 + o_l;
             if (o >= p.O || oy >= p.H || ox >= p.W) continue;
-            const float osc = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
-            const float bs = p.bias ? p.bias[o] : 0.f;
             const long base = ((long)n * p.O + o) * plane;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (oy + i >= p.H) continue;
                 const int pix = (oy + i) * p.W + ox;
-                float out[2];
+                f32x2 rs = f32x2{0.f, 0.f};
+                if (p.residual) rs = *reinterpret_cast<const f32x2*>(p.residual + base + pix);
+                f32x2 out;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    float nz = 0.f;
-                    const bool okx = ox + jj < p.W;
-                    if (okx && p.noise_mode == 1) nz = p.noise[pix + jj] * p.noise_strength;
-                    else if (okx && p.noise_mode == 2) nz = p.noise[(long)n * plane + pix + jj] * p.noise_strength;
-                    float v = yv[i][jj] * osc + nz + bs;
+                    float v = yv[i][jj] * osc[ob][q] + nzv[tb][q][i][jj] * p.noise_strength + bsv[ob][q];
                     v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
-                    if (okx && p.residual) v += p.residual[base + pix + jj];
-                    out[jj] = v;
+                    out[jj] = v + rs[jj];
                 }
-                float* dst = p.y + base + pix;
-                if (ox + 1 < p.W && ((reinterpret_cast<uintptr_t>(dst) & 7) == 0)) {
-                    *reinterpret_cast<f32x2*>(dst) = f32x2{out[0], out[1]};
-                } else {
-                    dst[0] = out[0];
-                    if (ox + 1 < p.W) dst[1] = out[1];
-                }
+                *reinterpret_cast<f32x2*>(p.y + base + pix) = out;      // W % 4 == 0, ox even: aligned, both pixels inside
             }
         }
         __syncthreads();
@@ -348,7 +372,10 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d_wino: empty tensor");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino: OP must be a multiple of 64 and >= O");
     SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && (long)NB * O * H * W < 2147483647L, "conv2d_wino: tensor too large");
+    SHG_CHECK_ARG(I <= 1024, "conv2d_wino: at most 1024 input channels");
     SHG_CHECK_ARG(W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "conv2d_wino: needs W %% 4 == 0 and a 16-byte aligned x (use shg_conv2d_f32 otherwise)");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0,
+                  "conv2d_wino: y / noise / residual must be 8-byte aligned");
     WinoParams p{};
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;

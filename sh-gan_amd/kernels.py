@@ -275,7 +275,7 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
         ws_bytes = int(lib.shg_conv2d_workspace_bytes(nb, i, pw.o, h, w, pw.kh, pw.kw, mode, pad, pw.groups))
         if ws_bytes:
             ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
-    if (WINO and mode == MODE_SAME and pad == 1 and pw.kh == 3 and pw.kw == 3 and pw.groups == 1 and h >= WINO_MIN and w >= WINO_MIN and w % 4 == 0 and x.data_ptr() % 16 == 0
+    if (WINO and mode == MODE_SAME and pad == 1 and pw.kh == 3 and pw.kw == 3 and pw.groups == 1 and h >= WINO_MIN and w >= WINO_MIN and w % 4 == 0 and x.data_ptr() % 16 == 0 and i <= 1024
             and (pw.wu is not None or pw._w is not None)):
         wu = pw.wino()
         t0 = _timer.begin() if _timer is not None else None
