@@ -55,7 +55,7 @@ constexpr int KC = 8, BO = 64, TY = 4, TX = 16, BT = TY * TX;
 constexpr int PH = 2 * TY + 2, PW = 2 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
 constexpr int RP = PH * PW;                                        // 400 floats per channel
 constexpr int U_SZ = 16 * KC * BO, V_SZ = 16 * KC * BT, R_SZ = KC * RP;
-constexpr int NT = 512;
+constexpr int NT = 1024;                 // 16 waves: wave w multiplies position w
 constexpr size_t LDS_BYTES = sizeof(float) * 2 * (U_SZ + V_SZ + R_SZ);
 }   // namespace wino
 
@@ -66,7 +66,7 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
     return base + idx;
 }
 
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
+__global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     using namespace wino;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ul = smem;                         // [2][16][8][64]
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int HW = p.H * p.W;
 
     // ---- LDS-DMA roles
+    const int wk = wave & 7;                  // channel of the chunk this wave stages (waves 0-7 transform, waves 8-15 issue the DMAs)
     // raw window: wave w fetches channel w of the chunk as float4 q = j*64 + lane (j = 0, 1; q < 100)
     const float* rsrc[2];
     unsigned rstep[2];
@@ -105,14 +106,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     }
     auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 2) return;
-        const int ch = c * KC + wave;
+        const int ch = c * KC + wk;
         const bool chok = ch < p.I;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* src = chok ? rsrc[j] + (size_t)ch * rstep[j] : shg_wino_zeros;
             if (ract[j])       // (inactive lanes write nothing: the window is 100 float4, the second piece 36 lanes)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wave * RP + j * 256), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wk * RP + j * 256), 16, 0, 0);
         }
     };
     // weights: 32 wave-wide 1 KiB pieces per chunk, 4 per wave
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         if (p.dbg & 1) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int piece = j * 8 + wave;
+            const int piece = j * 8 + wk;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + (size_t)c * U_SZ + piece * 256),
                                              (__attribute__((address_space(3))) void*)(Ul + buf * U_SZ + piece * 256), 16, 0, 0);
         }
@@ -129,13 +130,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
 
     // ---- input transform role: channel `wave`, block `lane` (ty = lane/16, tx = lane%16)
     const int tty = lane >> 4, ttx = lane & 15;
-    const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
-    float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
+    const float* rbase = Rl + wk * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
+    float* vbase = Vl + wk * BT + lane;                     // + xi*KC*BT
     // styles of channel `wave` of every chunk, one lane per chunk (up to 128 chunks = 1024 input channels)
     float scv[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-        const int ch = (v * 64 + lane) * KC + wave;
+        const int ch = (v * 64 + lane) * KC + wk;
         scv[v] = (p.in_scale && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
     }
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
@@ -170,45 +171,46 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         }
     };
 
-    // ---- MFMA role: positions 2*wave, 2*wave+1; 2 channel blocks x 2 pixel-block blocks each
-    f32x16 acc[2][2][2];
+    // ---- MFMA role: position `wave`; 2 channel blocks x 2 pixel-block blocks
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][ob][tb][r] = 0.f;
-    const float* abase = Ul + ((2 * wave) * KC + half) * BO + l31;    // + j*KC*BO + ks*2*BO + ob*32
-    const float* bbase = Vl + ((2 * wave) * KC + half) * BT + l31;
+            for (int r = 0; r < 16; ++r) acc[ob][tb][r] = 0.f;
+    const float* abase = Ul + (wave * KC + half) * BO + l31;    // + ks*2*BO + ob*32
+    const float* bbase = Vl + (wave * KC + half) * BT + l31;
 
     // ---- prologue
-    dma_raw(0, 0);
-    dma_u(0, 0);
-    if (p.nchunk > 1) dma_raw(1, 1);
+    const bool loader = wave >= 8;
+    if (loader) {
+        dma_raw(0, 0);
+        dma_u(0, 0);
+        if (p.nchunk > 1) dma_raw(1, 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    transform(0, 0);
+    __syncthreads();
+    if (!loader) transform(0, 0);
     __syncthreads();
 
-    const int grp = wave >> 2;            // waves w and w+4 share a SIMD
     for (int c = 0; c < p.nchunk; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < p.nchunk;
-        if (more) dma_u(c + 1, cur ^ 1);
-        if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
-        if (more && grp == 0) transform(c + 1, cur ^ 1);    // raw(c+1) landed before the previous barrier
+        if (loader) {
+            if (more) dma_u(c + 1, cur ^ 1);
+            if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
+        } else if (more) {
+            transform(c + 1, cur ^ 1);                          // raw(c+1) landed before the previous barrier
+        }
         const float* ab = abase + cur * U_SZ;
         const float* bb = bbase + cur * V_SZ;
-        float a[2][2][2], b[2][2][2];
+        float a[2][2], b[2][2];
         auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int ob = 0; ob < 2; ++ob) a[buf][ob] = ab[(ks * 2) * BO + ob * 32];
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob) a[buf][j][ob] = ab[(j * KC + ks * 2) * BO + ob * 32];
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) b[buf][j][tb] = bb[(j * KC + ks * 2) * BT + tb * 32];
-            }
+            for (int tb = 0; tb < 2; ++tb) b[buf][tb] = bb[(ks * 2) * BT + tb * 32];
         };
         fetch(0, 0);
 #pragma unroll
@@ -216,17 +218,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
             if (ks + 1 < KC / 2) fetch(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                    for (int tb = 0; tb < 2; ++tb)
-                        acc[j][ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks & 1][j][ob], b[ks & 1][j][tb], acc[j][ob][tb], 0, 0, 0);
-            if (ks == 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && grp == 1) transform(c + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks & 1][ob], b[ks & 1][tb], acc[ob][tb], 0, 0, 0);
         }
         if (!(p.dbg & 8)) __syncthreads();
     }
@@ -237,10 +232,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const long plane = (long)p.H * p.W;
     // per-thread items of a pass: e = tid + 512*q -> channel o_l = e/32 of the 32-channel block, pixel block t_l = e%32.
     // The per-channel and per-pixel operands of all four passes are requested up front (one latency, not eight).
-    float osc[2][2], bsv[2][2];               // [ob][q]
-    f32x2 nzv[2][2][2];                       // [tb][q][row]
+    constexpr int NQ = 1;
+    float osc[2][NQ], bsv[2][NQ];             // [ob][q]
+    f32x2 nzv[2][NQ][2];                      // [tb][q][row]
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int e = tid + NT * q;
         const int o_l = e >> 5, t_l = e & 31;
 #pragma unroll
@@ -267,15 +263,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     for (int pass = 0; pass < 4; ++pass) {
         const int ob = pass >> 1, tb = pass & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                Mx[((2 * wave + j) * 32 + row) * 32 + l31] = acc[j][ob][tb][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            Mx[(wave * 32 + row) * 32 + l31] = acc[ob][tb][r];
+        }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = tid + NT * q;
             const int o_l = e >> 5, t_l = e & 31;
             float m[16];
