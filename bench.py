@@ -30,16 +30,21 @@ CONV_GFLOP_PER_IMAGE = {256: 180.3, 512: 238.3}   # the 3x3 convolutions alone
 
 
 def pmc_traffic(resolution, batch):
-    """HBM bytes per conv_mfma launch from the committed PMC summary (tools/gpu_traffic.sh: separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters
-    cannot be read from inside the process, so the number is attached from profiles/ when it matches the workload."""
+    """HBM bytes per convolution launch (conv_wino_kernel + conv_mfma_kernel, launch-weighted) from the committed PMC
+    summary (tools/gpu_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the process, so the number is
+    attached from profiles/ when it matches the workload."""
     path = os.path.join(ROOT, 'profiles', f'traffic_{resolution}x{batch}.json')
     if not os.path.exists(path):
         return None
-    d = json.load(open(path)).get('conv_mfma_kernel')
-    if not d:
-        return None
-    return round((d['read_bytes_per_launch'] + d['write_bytes_per_launch']) / 1e9, 4)
+    js = json.load(open(path))
+    tot = n = 0.0
+    for k in ('conv_wino_kernel', 'conv_mfma_kernel'):
+        d = js.get(k)
+        if d:
+            tot += (d['read_bytes_per_launch'] + d['write_bytes_per_launch']) * d['launches']
+            n += d['launches']
+    return round(tot / n / 1e9, 4) if n else None
 
 
 def cpu_baseline(resolution, n_images, seed):
@@ -129,8 +134,18 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         ips = world * batch * a.steps / dt
-        summ = timer.summary().get('conv_mfma', dict(calls=0, ms=0.0, work=0.0))
-        ach = summ['work'] / (summ['ms'] * 1e-3) / 1e12 if summ['ms'] > 0 else 0.0
+        tsum = timer.summary()
+        zero = dict(calls=0, ms=0.0, work=0.0)
+        sd, sw = tsum.get('conv_mfma', zero), tsum.get('conv_wino', zero)     # direct implicit-GEMM / Winograd F(2x2,3x3)
+        conv_ms = sd['ms'] + sw['ms']
+        conv_work = sd['work'] + sw['work']                 # algorithmic (direct-form) flops: 2*N*O*I*taps*pixels
+        issued = sd['work'] + sw['work'] * 16.0 / 36.0      # flops the MFMA units actually execute
+        ach = conv_work / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        iss = issued / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+
+        def cls(d):
+            return {'launches_per_step': d['calls'] // max(a.steps, 1), 'ms_per_step': round(d['ms'] / max(a.steps, 1), 3),
+                    'algorithmic_tflops': round(d['work'] / (d['ms'] * 1e-3) / 1e12, 2) if d['ms'] > 0 else None}
         line = {
             'metric': 'generator images/sec', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
@@ -138,13 +153,19 @@ def main():
             'config': {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU',
                        'resolution': res, 'batch_per_gpu': batch, 'global_batch': batch * world, 'noise_mode': a.noise_mode,
                        'parallelism': f'batch-shard x{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all 3x3/1x1 implicit-GEMM launches)',
+            # achieved = ALGORITHMIC (direct-form) convolution flops / HIP-event time of every convolution launch.  The
+            # stride-1 3x3 layers run as Winograd F(2x2,3x3) (16 instead of 36 multiplies per 2x2 outputs, exact fp32
+            # MFMA), so `achieved` can exceed what the matrix cores execute: `mfma_issued` is the executed rate.
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_wino_kernel + conv_mfma_kernel (every 3x3/1x1 convolution launch)',
                          'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(res, batch),
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'mfma_issued': round(iss, 3), 'frac_mfma_issued': round(iss / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'traffic': pmc_traffic(res, batch),
                          'traffic_unit': 'GB per launch (HBM read+write, PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/traffic_*.json)',
-                         'launches_per_step': summ['calls'] // max(a.steps, 1),
-                         'kernel_ms_per_step': round(summ['ms'] / max(a.steps, 1), 3),
-                         'gflop_per_step': round(summ['work'] / max(a.steps, 1) / 1e9, 1),
+                         'launches_per_step': (sd['calls'] + sw['calls']) // max(a.steps, 1),
+                         'kernel_ms_per_step': round(conv_ms / max(a.steps, 1), 3),
+                         'gflop_per_step': round(conv_work / max(a.steps, 1) / 1e9, 1),
+                         'classes': {'conv_wino': cls(sw), 'conv_mfma': cls(sd)},
                          'whole_forward_frac_of_fp32_mfma_peak': round(
                              ips / world * GFLOP_PER_IMAGE.get(res, 0) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
         }

@@ -283,7 +283,7 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
             _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(_req(in_scale, 'in_scale')), _ptr(_req(out_scale, 'out_scale')),
             _ptr(_req(bias, 'bias')), _ptr(noise), nmode, float(noise_strength), a, al, g, cl, _ptr(residual), _stream()), 'conv2d_wino')
         if t0 is not None:
-            _timer.end('conv_mfma', t0, 2.0 * nb * pw.o * i * 9 * oh * ow)      # direct-form (algorithmic) flops
+            _timer.end('conv_wino', t0, 2.0 * nb * pw.o * i * 9 * oh * ow)      # direct-form (algorithmic) flops
         return y
     t0 = _timer.begin() if _timer is not None else None
     check(lib.shg_conv2d_f32(
