@@ -17,8 +17,8 @@
 //   * everything is double buffered: while chunk c is multiplied, U(c+1) / raw(c+2) are in flight and V(c+1) is built;
 //     one barrier per chunk.  The two wave groups build V at different points of the chunk so that one wave per SIMD
 //     always has MFMAs to issue.
-// Epilogue: the 16 M_xi of an (o, t) pair live in 8 different waves -> they are exchanged through LDS in four passes
-// of 32 channels x 32 blocks; each thread then applies A^T . A, the fused layer tail (demodulation coefficient, noise,
+// Epilogue: the 16 M_xi of an (o, t) pair live in 16 different waves -> they are exchanged through LDS in two passes
+// of 32 channels x 64 blocks; each thread then applies A^T . A, the fused layer tail (demodulation coefficient, noise,
 // bias, lrelu_agc, skip) and stores two pixels at a time (128-byte row segments per 16 lanes).
 #include "shg_common.h"
 #include <stdlib.h>
@@ -227,54 +227,47 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     }
     if (p.dbg & 16) return;
 
-    // ---- epilogue: exchange through LDS (reusing the weight buffers), inverse transform, fused layer tail
-    float* Mx = Ul;                           // [16][32][32]
+    // ---- epilogue: exchange through LDS (reusing the weight + V buffers: 128 KiB), inverse transform, fused layer tail.
+    // Two passes of 32 channels x 64 blocks; per pass a thread owns pixel block t = tid%64 of channels tid/64 and tid/64+16.
+    float* Mx = Ul;                           // [16][32][64]  (Ul and Vl are adjacent)
     const long plane = (long)p.H * p.W;
-    // per-thread items of a pass: e = tid + 512*q -> channel o_l = e/32 of the 32-channel block, pixel block t_l = e%32.
-    // The per-channel and per-pixel operands of all four passes are requested up front (one latency, not eight).
-    constexpr int NQ = 1;
-    float osc[2][NQ], bsv[2][NQ];             // [ob][q]
-    f32x2 nzv[2][NQ][2];                      // [tb][q][row]
+    const int t_e = tid & 63;
+    const int oy = oy0 + 2 * (t_e >> 4), ox = ox0 + 2 * (t_e & 15);
+    // per-channel and per-pixel operands of both passes are requested up front (one latency, not four)
+    float osc[2][2], bsv[2][2];               // [ob][q]
+    f32x2 nzv[2];                             // [row]
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int e = tid + NT * q;
-        const int o_l = e >> 5, t_l = e & 31;
+    for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-            const int o = min(o0 + ob * 32 + o_l, p.O - 1);
+        for (int q = 0; q < 2; ++q) {
+            const int o = min(o0 + ob * 32 + (tid >> 6) + 16 * q, p.O - 1);
             osc[ob][q] = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
             bsv[ob][q] = p.bias ? p.bias[o] : 0.f;
         }
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const int t = tb * 32 + t_l;
-            const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                nzv[tb][q][i] = f32x2{0.f, 0.f};
-                if (p.noise_mode && oy + i < p.H && ox < p.W) {       // W % 4 == 0 and ox even: both pixels inside, 8-byte aligned
-                    const float* np_ = p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + (long)(oy + i) * p.W + ox;
-                    nzv[tb][q][i] = *reinterpret_cast<const f32x2*>(np_);
-                }
-            }
+    for (int i = 0; i < 2; ++i) {
+        nzv[i] = f32x2{0.f, 0.f};
+        if (p.noise_mode && oy + i < p.H && ox < p.W) {       // W % 4 == 0 and ox even: both pixels inside, 8-byte aligned
+            const float* np_ = p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + (long)(oy + i) * p.W + ox;
+            nzv[i] = *reinterpret_cast<const f32x2*>(np_);
         }
     }
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int ob = pass >> 1, tb = pass & 1;
+    for (int ob = 0; ob < 2; ++ob) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            Mx[(wave * 32 + row) * 32 + l31] = acc[ob][tb][r];
-        }
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                Mx[(wave * 32 + row) * 64 + tb * 32 + l31] = acc[ob][tb][r];
+            }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = tid + NT * q;
-            const int o_l = e >> 5, t_l = e & 31;
+        for (int q = 0; q < 2; ++q) {
+            const int o_l = (tid >> 6) + 16 * q;
             float m[16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 32 + t_l];
+            for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 64 + t_e];
             // A^T m A, A^T = [[1,1,1,0],[0,1,-1,-1]]
             float t0[4], t1[4];
 #pragma unroll
@@ -285,8 +278,6 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
             float yv[2][2];
             yv[0][0] = t0[0] + t0[1] + t0[2]; yv[0][1] = t0[1] - t0[2] - t0[3];
             yv[1][0] = t1[0] + t1[1] + t1[2]; yv[1][1] = t1[1] - t1[2] - t1[3];
-            const int t = tb * 32 + t_l;
-            const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
             const int o = o0 + ob * 32 + o_l;
             if (o >= p.O || oy >= p.H || ox >= p.W) continue;
             const long base = ((long)n * p.O + o) * plane;
@@ -299,14 +290,14 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
                 f32x2 out;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    float v = yv[i][jj] * osc[ob][q] + nzv[tb][q][i][jj] * p.noise_strength + bsv[ob][q];
+                    float v = yv[i][jj] * osc[ob][q] + nzv[i][jj] * p.noise_strength + bsv[ob][q];
                     v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
                     out[jj] = v + rs[jj];
                 }
                 *reinterpret_cast<f32x2*>(p.y + base + pix) = out;      // W % 4 == 0, ox even: aligned, both pixels inside
             }
         }
-        __syncthreads();
+        if (ob == 0) __syncthreads();
     }
 }
 
