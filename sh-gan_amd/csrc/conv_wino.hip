@@ -194,18 +194,22 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     if (!loader) transform(0, 0);
     __syncthreads();
 
+    // The MFMA stream is skewed by one k-step against the barriers: the operands of a chunk's last k-step are read
+    // before the barrier and multiplied after it, while the first operands of the next chunk are on their way from
+    // LDS -- the matrix pipe has work the moment the barrier releases.
+    float a[2][2], b[2][2];
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+                acc[ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][ob], b[buf][tb], acc[ob][tb], 0, 0, 0);
+    };
     for (int c = 0; c < p.nchunk; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < p.nchunk;
-        if (loader) {
-            if (more) dma_u(c + 1, cur ^ 1);
-            if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
-        } else if (more) {
-            transform(c + 1, cur ^ 1);                          // raw(c+1) landed before the previous barrier
-        }
         const float* ab = abase + cur * U_SZ;
         const float* bb = bbase + cur * V_SZ;
-        float a[2][2], b[2][2];
         auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) a[buf][ob] = ab[(ks * 2) * BO + ob * 32];
@@ -213,18 +217,27 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
             for (int tb = 0; tb < 2; ++tb) b[buf][tb] = bb[(ks * 2) * BT + tb * 32];
         };
         fetch(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            if (ks + 1 < KC / 2) fetch(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    acc[ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks & 1][ob], b[ks & 1][tb], acc[ob][tb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c > 0) mma(1);                                      // last k-step of the previous chunk (operands in registers)
+        __builtin_amdgcn_sched_barrier(0);
+        if (loader) {
+            if (more) dma_u(c + 1, cur ^ 1);
+            if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
+        } else if (more) {
+            transform(c + 1, cur ^ 1);                          // raw(c+1) landed before the previous barrier
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KC / 2 - 1; ++ks) {
+            fetch(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ks & 1);
+        }
+        // k-step 3 stays in a[1]/b[1]; its LDS reads must have completed before the buffers are handed back
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(p.dbg & 8)) __syncthreads();
     }
+    mma(1);
     if (p.dbg & 16) return;
 
     // ---- epilogue: exchange through LDS (reusing the weight + V buffers: 128 KiB), inverse transform, fused layer tail.
