@@ -99,6 +99,27 @@ def test_full_size_properties(env, resolution, batch):
     assert rel_err(c(sub[:1]), ref.numpy()) < 1e-3
 
 
+def test_winograd_and_direct_paths_agree_full_size(env):
+    """The stride-1 3x3 layers run on the Winograd F(2x2,3x3) kernel by default; the direct implicit-GEMM kernel is
+    the same function (SHG_WINO=0).  Full-width 256x256 generator, both routes, same weights and inputs."""
+    from shgan_amd import kernels as kk
+    orc, hz = env['orc'], env['harness']
+    sd = orc.init_state_dict(256, seed=61, noise_strength=0.05)
+    G = make_G(env, 256, sd)
+    x, z, _, _ = hz.synthetic_batch(4, 256, 512, seed=62, device=DEV, masks='bernoulli')
+    cnd = torch.zeros(4, 0, device=DEV)
+    old = kk.WINO
+    try:
+        kk.WINO = True
+        a = G(x=x, z=z, c=cnd, noise_mode='const')
+        kk.WINO = False
+        b = G(x=x, z=z, c=cnd, noise_mode='const')
+    finally:
+        kk.WINO = old
+    assert not torch.equal(a, b)                 # two different algorithms really ran
+    assert rel_err(c(a), c(b)) < 1e-5
+
+
 def test_sharded_eval_matches_unsharded(env):
     """Index path of the eval loop on one GPU: emulated 2-rank shards re-interleave to the 1-rank result."""
     orc, hz = env['orc'], env['harness']
