@@ -73,9 +73,14 @@ struct ConvParams {
     int act;
     float alpha, gain, clamp;
     int tap_off[9];          // LDS patch offset (in patch elements) of tap t
+    // Tail split (one-workgroup-per-CU kernels): the workgroups beyond the last full round over the CUs are cut into
+    // tail_ks K-slices each, so the last, partially filled round costs 1/tail_ks of a round; their raw accumulators go
+    // to tail_ws [tile][slice][reg][thread] and a second, tiny launch (fix = 1) sums them and runs the epilogue.
+    int tail_first, tail_ks, tail_ips, fix;
+    float* tail_ws;
     int raw_reduce;          // split-K tail only sums the slices (transposed conv: its epilogue lives in the FIR kernel)
     int dbg;                 // ablation bits for kernel timing studies (SHG_CONV_DBG, default 0): 1 skip W loads, 2 skip X loads,
-                             // 4 skip LDS stores, 8 skip barriers, 16 skip epilogue
+                             // 4 skip LDS stores, 8 skip barriers, 16 skip epilogue, 32 no tail split
 };
 
 // Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}).  Used for the MFMA
@@ -137,8 +142,13 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     const int wo = wave / WP, wp = wave % WP;
 
     const int nwork = p.n_ptiles * p.n_otiles;
-    const int kslice = blockIdx.x / nwork;
-    const int work = xcd_remap(blockIdx.x - kslice * nwork, nwork);
+    int kslice, work, tslice = -1;                  // tslice >= 0: this block is K-slice `tslice` of tail tile `work`
+    if (p.fix) { kslice = 0; work = p.tail_first + blockIdx.x; }
+    else if ((int)blockIdx.x >= p.tail_first && p.ksplit == 1) {
+        const int tb = blockIdx.x - p.tail_first;
+        kslice = 0; work = p.tail_first + tb / p.tail_ks; tslice = tb - (tb / p.tail_ks) * p.tail_ks;
+    } else if (p.ksplit == 1) { kslice = 0; work = xcd_remap(blockIdx.x, p.tail_first); }
+    else { kslice = blockIdx.x / nwork; work = xcd_remap(blockIdx.x - kslice * nwork, nwork); }
     const int otile = work / p.n_ptiles;
     int ptile = work - otile * p.n_ptiles;
     int ci = 0;
@@ -154,8 +164,8 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
     const int PHW = PH_ * PW_;
-    const int i_begin = kslice * p.i_per_slice;
-    const int i_end = min(p.I, i_begin + p.i_per_slice);
+    const int i_begin = tslice >= 0 ? tslice * p.tail_ips : kslice * p.i_per_slice;
+    const int i_end = p.fix ? i_begin : min(p.I, i_begin + (tslice >= 0 ? p.tail_ips : p.i_per_slice));
 
     // ---- input scales (styles) of the tile's images -> LDS, applied when the patch is written to LDS
     if (p.in_scale) {
@@ -277,17 +287,19 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
                                                  (__attribute__((address_space(3))) void*)(Wl + buf * WSZ + (k * NT + wave * 64) * 4), 16, 0, 0);
         }
     };
-    if (WDMA) w_dma(i_begin, 0);
+    if (!p.fix) {
+        if (WDMA) w_dma(i_begin, 0);
 #pragma unroll
-    for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin);
-    __syncthreads();                 // scale table visible
+        for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin);
+        __syncthreads();                 // scale table visible
 #pragma unroll
-    for (int j = 0; j < NPIECE; ++j) piece_store(j, i_begin, 0);
-    if (DB && i_begin + KC < i_end) {
+        for (int j = 0; j < NPIECE; ++j) piece_store(j, i_begin, 0);
+        if (DB && i_begin + KC < i_end) {
 #pragma unroll
-        for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin + KC);
+            for (int j = 0; j < NPIECE; ++j) piece_load(j, i_begin + KC);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     int cur = 0;
     for (int i0 = i_begin; i0 < i_end; i0 += KC, cur ^= (DB ? 1 : 0)) {
@@ -424,6 +436,12 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
     }
     if (p.dbg & 16) return;
 
+    // tail split: slice blocks park their raw accumulators in tail_ws [tile][slice][reg][thread]; the fix launch reads
+    // them back inside the epilogue loops below (same code path as an ordinary tile from there on)
+    constexpr int NREG = NPH * MO * NP * 16;
+    float* const tws = (tslice >= 0 || p.fix)
+        ? p.tail_ws + ((size_t)(work - p.tail_first) * p.tail_ks + (tslice >= 0 ? tslice : 0)) * NREG * NT + tid : nullptr;
+
     // ---- epilogue: D[row = out channel][col = pixel]; row = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
     for (int np = 0; np < NP; ++np) {
@@ -469,6 +487,17 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
                         if (o < p.O) p.part[(long)kslice * p.part_stride + base + (long)o * plane] = acc[ph][mo][np][r];
                     }
                     continue;
+                }
+                float* const tw = tws + (size_t)(((ph * MO + mo) * NP + np) * 16) * NT;
+                if (tslice >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tw[r * NT] = acc[ph][mo][np][r];
+                    continue;
+                }
+                if (p.fix) {
+                    for (int sl = 0; sl < p.tail_ks; ++sl)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[ph][mo][np][r] += tw[(size_t)sl * NREG * NT + r * NT];
                 }
                 // gather the per-channel operands first (independent loads, one wait), then compute and store
                 float osc[16], bs[16], rs[16];
@@ -580,6 +609,21 @@ static int conv_ksplit(int grid, int chunks, bool allow) {
     return ks;
 }
 
+static int conv_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// Upper bound of the tail-split workspace of the one-workgroup-per-CU kernels: < CU-count tile-slices of at most
+// 128 x 128 x 4 (transposed) or 128 x 256 accumulators.
+static size_t conv_tail_ws_bound(bool up) { return (size_t)256 * (up ? 128 * 128 * 4 : 128 * 256) * sizeof(float); }
+
 template <int NTAPS, int KC, int MO, int NP, int WO, int WP, int XQ, bool UP, bool DB, int OCC>
 static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStream_t s) {
     constexpr int BO = MO * 32 * WO, BP = NP * 32 * WP, NT = WO * WP * 64;
@@ -607,9 +651,32 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { shg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SHG_ERR_LAUNCH; }
     }
-    const int grid = p.n_ptiles * p.n_otiles * p.ksplit;
+    // tail split: one-workgroup-per-CU kernels only (the double-buffered variants), when the last round is < 60 % full
+    const int nwork = p.n_ptiles * p.n_otiles;
+    p.tail_first = nwork; p.tail_ks = 1; p.tail_ips = p.I; p.fix = 0; p.tail_ws = nullptr;
+    int n_tail = 0;
+    if (DB && p.ksplit == 1 && workspace && !(p.dbg & 32)) {
+        const int slots = conv_cu_count();
+        const int tail = nwork % slots;
+        if (nwork > slots && tail > 0 && tail * 10 < slots * 6) {
+            int tk = 1;
+            while (tk < 8 && tail * tk * 2 <= slots && chunks / (tk * 2) >= 4) tk *= 2;
+            const size_t need = (size_t)tail * tk * (BO * BP * (UP ? 4 : 1)) * sizeof(float);
+            if (tk > 1 && need <= ws_bytes) {
+                n_tail = tail; p.tail_first = nwork - tail; p.tail_ks = tk; p.tail_ips = shg_cdiv(chunks, tk) * KC;
+                p.tail_ws = (float*)workspace;
+            }
+        }
+    }
+    const int grid = p.ksplit > 1 ? nwork * p.ksplit : p.tail_first + n_tail * p.tail_ks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
     SHG_CHECK_LAUNCH();
+    if (n_tail) {
+        p.fix = 1;
+        hipLaunchKernelGGL(kern, dim3(n_tail), dim3(NT), lds, s, p);
+        SHG_CHECK_LAUNCH();
+        p.fix = 0;
+    }
     if (p.ksplit > 1) {
         const long plane = (long)p.OHt * p.OWt;
         int rg = shg_cdiv(out_elems, 256); if (rg > 2048) rg = 2048;
@@ -724,7 +791,7 @@ extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W,
     ConvParams p{};
     p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.wgroups = wgroups < 1 ? 1 : wgroups;
     if (mode == 2) {   // small transposed convs (the 4-wave 64 x 128 tile) may split; planar output of 4 phase planes
-        if (W + 1 >= 32 && H + 1 >= 16) return 0;
+        if (W + 1 >= 32 && H + 1 >= 16) return conv_tail_ws_bound(true);
         p.S = 1; p.span_y = 2; p.span_x = 2;
         conv_tiles(p, 64, 128, true, 512);
         const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, 8), true);
@@ -739,7 +806,8 @@ extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W,
     p.OHp = OH; p.OWp = OW; p.S = S; p.span_y = kh; p.span_x = kw;
     conv_tiles(p, narrow ? 64 : 128, narrow ? 256 : 128, false, xq * 256);
     const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, KC), true);
-    return ks > 1 ? (size_t)ks * NB * O * OH * OW * sizeof(float) : 0;
+    if (ks > 1) return (size_t)ks * NB * O * OH * OW * sizeof(float);
+    return (kh * kw == 9 && !narrow && OW >= 32 && OH >= 8) ? conv_tail_ws_bound(false) : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
