@@ -609,6 +609,12 @@ static int conv_ksplit(int grid, int chunks, bool allow) {
     return ks;
 }
 
+// smallest phase-grid width (W+1) that goes to the 8-wave double-buffered transposed-conv tiles (SHG_UP_MIN)
+static int conv_up_min() {
+    static const int v = getenv("SHG_UP_MIN") ? atoi(getenv("SHG_UP_MIN")) : 16;
+    return v;
+}
+
 static int conv_cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -695,7 +701,7 @@ static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, 
     if (up) {
         // all-phase transposed conv: large grids use 8-wave double-buffered tiles (128 ch x 128 px, or 64 ch x 256 px),
         // small ones the 4-wave 64 ch x 128 px tile (+ split-K)
-        const bool big = !(variant & 1) && p.OWp >= 32 && p.OHp >= 16 && p.wgroups == 1;
+        const bool big = !(variant & 1) && p.OWp >= conv_up_min() && p.OHp >= 16 && p.wgroups == 1;
         if (big && !narrow && (variant & 16)) return launch_conv<9, 8, 1, 1, 4, 4, 1, true, true, 4>(p, workspace, ws_bytes, s);
         if (big) return narrow ? launch_conv<9, 8, 2, 1, 1, 8, 1, true, true, 2>(p, workspace, ws_bytes, s)
                                : launch_conv<9, 8, 2, 1, 2, 4, 1, true, true, 2>(p, workspace, ws_bytes, s);
@@ -791,11 +797,14 @@ extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W,
     ConvParams p{};
     p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.wgroups = wgroups < 1 ? 1 : wgroups;
     if (mode == 2) {   // small transposed convs (the 4-wave 64 x 128 tile) may split; planar output of 4 phase planes
-        if (W + 1 >= 32 && H + 1 >= 16) return conv_tail_ws_bound(true);
         p.S = 1; p.span_y = 2; p.span_x = 2;
-        conv_tiles(p, 64, 128, true, 512);
+        const bool big = W + 1 >= conv_up_min() && H + 1 >= 16 && p.wgroups == 1;
+        if (big) conv_tiles(p, O <= 64 ? 64 : 128, O <= 64 ? 256 : 128, true, 512);
+        else conv_tiles(p, 64, 128, true, 512);
         const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, 8), true);
-        return ks > 1 ? (size_t)ks * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
+        const size_t split = ks > 1 ? (size_t)ks * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
+        const size_t tail = big ? conv_tail_ws_bound(true) : 0;
+        return split > tail ? split : tail;
     }
     const int S = mode == 0 ? 1 : 2;
     const int OH = (H + 2 * pad - kh) / S + 1, OW = (W + 2 * pad - kw) / S + 1;
