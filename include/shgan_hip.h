@@ -135,6 +135,10 @@ int shg_shu_split_irfft2_f32(const float* Y, const float* cw, const float* const
 /* ---- A24: eval composite (lib/experiments/shgan_default.py:257-262): x4 [N,4,H,W], img [N,3,H,W] -> u8 [N,3,H,W]. */
 int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int H, int W, void* stream);
 
+/* ---- input hand-off of the eval loop (lib/experiments/shgan_default.py:267-274): x = cat([mask-0.5, real*mask]).
+ * real [N,3,H,W] in [-1,1], mask [N,H,W] in {0,1} -> x [N,4,H,W]. */
+int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

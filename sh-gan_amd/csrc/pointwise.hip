@@ -259,3 +259,34 @@ extern "C" int shg_composite_u8(const float* x4, const float* img, uint8_t* out,
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input assembly of the eval loop (lib/experiments/shgan_default.py:267-274):
+//   x = cat([mask - 0.5, real * mask], dim=1)     real [N,3,H,W], mask [N,H,W] (0/1 floats) -> x [N,4,H,W]
+// one pass instead of the reference's sub + mul + cat.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_input_kernel(const float* real, const float* mask, float* x, int HW4, long total4) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;          // one float4 of one image plane
+    if (e >= total4) return;
+    const int n = (int)(e / HW4), q = (int)(e - (long)n * HW4);
+    const float4 m = reinterpret_cast<const float4*>(mask)[(long)n * HW4 + q];
+    float4* xo = reinterpret_cast<float4*>(x) + (long)n * 4 * HW4 + q;
+    xo[0] = make_float4(m.x - 0.5f, m.y - 0.5f, m.z - 0.5f, m.w - 0.5f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 r = reinterpret_cast<const float4*>(real)[((long)n * 3 + c) * HW4 + q];
+        xo[(long)(c + 1) * HW4] = make_float4(r.x * m.x, r.y * m.y, r.z * m.z, r.w * m.w);
+    }
+}
+
+extern "C" int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N, int H, int W, void* stream) {
+    SHG_CHECK_ARG(real && mask && x, "assemble_input: null pointer");
+    SHG_CHECK_ARG(N >= 0 && H >= 1 && W >= 1 && (H * W) % 4 == 0, "assemble_input: H*W must be a positive multiple of 4");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(real) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x)) & 15) == 0,
+                  "assemble_input: buffers must be 16-byte aligned");
+    if (N == 0) return SHG_OK;
+    const long total4 = (long)N * (H * W / 4);
+    hipLaunchKernelGGL(assemble_input_kernel, dim3(shg_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, real, mask, x, H * W / 4, total4);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

@@ -11,7 +11,9 @@ from .data import DistributedSampler, RandomMask, zipzap_arrange
 
 def assemble_input(real, mask):
     """real [N,3,R,R] in [-1,1], mask [N,1,R,R] in {0,1} -> x = cat([mask-0.5, real*mask]) (shgan_default.py:270-274)."""
-    return torch.cat([mask - 0.5, real * mask], dim=1)
+    if real.is_cuda:
+        return kernels.assemble_input(real.float(), mask.float())       # one HIP kernel instead of sub + mul + cat
+    return torch.cat([mask - 0.5, real * mask], dim=1)                  # host tensors (dataloader side): plain torch
 
 
 def run_generator(G, x, z, c=None, noise_mode='random'):

@@ -159,6 +159,18 @@ def composite_u8(x4, img):
     return out
 
 
+def assemble_input(real, mask):
+    """real [N,3,H,W] in [-1,1], mask [N,1,H,W] or [N,H,W] in {0,1} -> x [N,4,H,W] = cat([mask-0.5, real*mask])."""
+    real = _req(real, 'real')
+    mask = _req(mask, 'mask')
+    n, c, h, w = real.shape
+    if c != 3 or mask.numel() != n * h * w:
+        raise _lib.ShgError('assemble_input: real must be [N,3,H,W] and mask [N,(1,)H,W]')
+    x = torch.empty((n, 4, h, w), device=real.device, dtype=torch.float32)
+    check(_lib.get_lib().shg_assemble_input_f32(_ptr(real), _ptr(mask), _ptr(x), n, h, w, _stream()), 'assemble_input')
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------

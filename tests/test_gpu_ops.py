@@ -361,6 +361,20 @@ def test_composite_u8_bit_exact(mods):
     assert np.array_equal(np.where(m, c(out), 0), np.where(m, real_u8, 0))     # known pixels == the real image
 
 
+def test_assemble_input_bit_exact(mods):
+    """x = cat([mask-0.5, real*mask]) (shgan_default.py:267-274): same fp32 operations as torch -> bit-identical."""
+    kk = mods['kernels']
+    rs = np.random.RandomState(3)
+    for n, h, w in [(3, 16, 20), (2, 64, 64), (1, 2, 2)]:
+        real = torch.from_numpy(rs.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+        mask = torch.from_numpy((rs.rand(n, 1, h, w) < 0.6).astype(np.float32))
+        ref = torch.cat([mask - 0.5, real * mask], dim=1)
+        x = kk.assemble_input(real.to(DEV), mask.to(DEV))
+        assert np.array_equal(c(x), ref.numpy())
+    with pytest.raises(RuntimeError):
+        kk.assemble_input(torch.zeros(1, 3, 3, 3, device=DEV), torch.zeros(1, 1, 3, 3, device=DEV))     # H*W % 4 != 0
+
+
 def test_conv2d_gradfix_surface(mods):
     import torch.nn.functional as F
     rs = np.random.RandomState(11)
