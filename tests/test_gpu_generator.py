@@ -120,6 +120,30 @@ def test_winograd_and_direct_paths_agree_full_size(env):
     assert rel_err(c(a), c(b)) < 1e-5
 
 
+def test_mapping_truncation_and_batch_shapes(env):
+    """Mapping.forward (stylegan.py:394-430): truncation is the lerp towards w_avg of the untruncated ws (also with a
+    cutoff), and ragged batch sizes (1, 3, 17 > the 16-row slab of the dense kernel) give the rows of the full batch."""
+    orc = env['orc']
+    kw = dict(ch_base=1024, ch_max=32, w_dim=64, z_dim=48, w0_dim=96)
+    sd = orc.init_state_dict(256, seed=71, **kw)
+    sd['mapping.w_avg'] = torch.linspace(-1, 1, 64)
+    G = make_G(env, 256, sd, **kw)
+    z = torch.randn(17, 48, generator=torch.Generator().manual_seed(5)).to(DEV)
+    cnd = torch.zeros(17, 0, device=DEV)
+    ws = G.mapping(z, cnd)
+    assert tuple(ws.shape) == (17, G.num_ws, 64)
+    ref = orc.mapping(sd, z.cpu(), G.num_ws)
+    assert rel_err(c(ws), ref.numpy()) < 1e-5
+    w_avg = sd['mapping.w_avg'].to(DEV)
+    wt = G.mapping(z, cnd, truncation_psi=0.7)
+    assert rel_err(c(wt), c(w_avg.lerp(ws, 0.7))) < 1e-6
+    wc = G.mapping(z, cnd, truncation_psi=0.5, truncation_cutoff=3)
+    exp = ws.clone(); exp[:, :3] = w_avg.lerp(ws[:, :3], 0.5)
+    assert rel_err(c(wc), c(exp)) < 1e-6
+    for n in (1, 3):
+        assert rel_err(c(G.mapping(z[:n], cnd[:n])), c(ws[:n])) < 1e-6
+
+
 def test_sharded_eval_matches_unsharded(env):
     """Index path of the eval loop on one GPU: emulated 2-rank shards re-interleave to the 1-rank result."""
     orc, hz = env['orc'], env['harness']
