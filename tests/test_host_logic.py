@@ -42,6 +42,24 @@ def test_library_exports_every_header_symbol():
     assert _lib.get_lib().shg_abi_version() == _lib.ABI_VERSION
 
 
+def test_descriptor_structs_match_the_header_layout(tmp_path):
+    """The grouped entry points take arrays of plain C structs: the ctypes mirrors must have the layout a C compiler
+    gives include/shgan_hip.h (the header is plain C: compiled here with gcc)."""
+    import subprocess
+    src = tmp_path / 'layout.c'
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "shgan_hip.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(shg_dense_group), offsetof(shg_dense_group, y), '
+        'offsetof(shg_dense_group, ld1), offsetof(shg_dense_group, wgain), sizeof(shg_style_group), '
+        'offsetof(shg_style_group, dcoef), offsetof(shg_style_group, ld), offsetof(shg_style_group, pre_gain)); return 0; }\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    c_layout = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    D, S = _lib.DenseGroup, _lib.StyleGroup
+    assert c_layout == [ctypes.sizeof(D), D.y.offset, D.ld1.offset, D.wgain.offset,
+                        ctypes.sizeof(S), S.dcoef.offset, S.ld.offset, S.pre_gain.offset]
+
+
 def test_registry_names_match_reference():
     names = set(get_model().model.keys())
     for n in ('comodgan_mapping', 'shgan_encoder', 'comodgan_encoder', 'comodgan_synthesis', 'comodgan_generator',
