@@ -77,7 +77,9 @@ int shg_conv2d_f32(const float* x, const float* wt, float* y, int NB, int I, int
 size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W, int kh, int kw, int mode, int pad, int wgroups);
 /* Winograd F(2x2,3x3) form of the stride-1 3x3 'same' convolution (mode 0, pad 1 of shg_conv2d_f32; same fused operands and
  * result up to fp32 round-off, 2.25x fewer MFMA flops).  Weights: w [O,I,3,3] with the per-output-channel factor wscale [O]
- * (the `wscale` output of shg_conv_weight_prep_f32) -> wu [OP/64][ceil(I/8)][16][8][64] = G (w*wscale) G^T. */
+ * (the `wscale` output of shg_conv_weight_prep_f32) -> wu [OP/64][ceil(I/c)][16][64][c] = G (w*wscale) G^T in the
+ * register layout of the kernel, c = shg_conv_wino_chunk() input channels per K-chunk. */
+int shg_conv_wino_chunk(void);
 int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip, void* stream);
 int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
                         const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -45,6 +45,7 @@ _SIGS = {
     'shg_conv2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_i,
                        c_fp, ctypes.c_size_t, c_fp],
     'shg_conv2d_workspace_bytes': [c_i] * 10,
+    'shg_conv_wino_chunk': [],
     'shg_conv_weight_prep_wino_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_wino_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_upfir_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],

@@ -22,6 +22,7 @@
 // bias, lrelu_agc, skip) and stores two pixels at a time (128-byte row segments per 16 lanes).
 #include "shg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,7 +32,7 @@ __device__ __attribute__((aligned(16))) float shg_wino_zeros[64];   // zero sour
 
 struct WinoParams {
     const float* x;          // [NB, I, H, W]
-    const float* wu;         // transformed weights [OP/64][nchunk][16][8][64]
+    const float* wu;         // transformed weights [OP/64][nchunk][16][64 lanes][KC]
     float* y;                // [NB, O, H, W]
     const float* in_scale;   // [NB, I] or null
     const float* out_scale;  // [NB, O] or null
@@ -49,14 +50,22 @@ struct WinoParams {
 };
 
 namespace wino {
-constexpr int KC = 8, BO = 64, TY = 4, TX = 16, BT = TY * TX;
+// K chunk (input channels per barrier).  The weights never touch LDS (each wave keeps its own position's slice in
+// registers), so LDS holds only V and the raw windows: 12 channels = 137 KB of the 160 KB.
+#ifndef SHG_WINO_KC
+#define SHG_WINO_KC 8
+#endif
+constexpr int KC = SHG_WINO_KC, BO = 64, TY = 4, TX = 16, BT = TY * TX;
+static_assert(KC % 4 == 0 && (KC / 2) % 2 == 0 && KC <= 12, "KC: multiple of 4 with an even number of k-steps");
 // raw window per channel: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35 (16-byte aligned in global memory when W % 4 == 0,
 // and every float4 is either inside the image or entirely padding) = 10 x 10 float4, fetched by two 16-byte LDS-DMAs
 constexpr int PH = 2 * TY + 2, PW = 2 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
 constexpr int RP = PH * PW;                                        // 400 floats per channel
-constexpr int U_SZ = 16 * KC * BO, V_SZ = 16 * KC * BT, R_SZ = KC * RP;
+constexpr int V_SZ = 16 * KC * BT, R_SZ = KC * RP;
 constexpr int NT = 1024;                 // 16 waves: wave w multiplies position w
-constexpr size_t LDS_BYTES = sizeof(float) * 2 * (U_SZ + V_SZ + R_SZ);
+constexpr int NXF = KC;                  // waves 0..KC-1 transform one channel each; the others issue the window DMAs
+constexpr size_t LDS_BYTES = sizeof(float) * 2 * (V_SZ + R_SZ);
+static_assert(2 * V_SZ >= 16 * 32 * 32, "epilogue exchange buffer lives in the V region");
 }   // namespace wino
 
 __device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
@@ -69,9 +78,8 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
 __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     using namespace wino;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ul = smem;                         // [2][16][8][64]
-    float* Vl = smem + 2 * U_SZ;              // [2][16][8][64]
-    float* Rl = Vl + 2 * V_SZ;                // [2][8][RP]
+    float* Vl = smem;                         // [2][16][KC][64]
+    float* Rl = smem + 2 * V_SZ;              // [2][KC][RP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,86 +96,85 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
 
-    // ---- LDS-DMA roles
-    const int wk = wave & 7;                  // channel of the chunk this wave stages (waves 0-7 transform, waves 8-15 issue the DMAs)
-    // raw window: wave w fetches channel w of the chunk as float4 q = j*64 + lane (j = 0, 1; q < 100)
-    const float* rsrc[2];
-    unsigned rstep[2];
-    bool ract[2];
+    // ---- staging roles: waves 0..KC-1 transform channel `wave` of the chunk; waves KC..15 fetch the raw windows
+    const bool xformer = wave < NXF;
+    constexpr int NLD = 16 - NXF;             // loader waves
+    constexpr int CPL = (KC + NLD - 1) / NLD; // channels per loader wave
+    // raw window: float4 q = j*64 + lane (j = 0, 1; q < 100) of a channel
+    int roff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = j * 64 + lane;
         const int py = q / PW4, p4 = q - py * PW4;
         const int iy = oy0 - 1 + py, ix = ox0 - 4 + 4 * p4;
         const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
-        ract[j] = q < PATCH4;
-        rsrc[j] = ok ? p.x + ((long)n * p.I * HW + (long)iy * p.W + ix) : shg_wino_zeros;
-        rstep[j] = ok ? (unsigned)HW : 0u;
+        roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
     }
+    const bool ract1 = lane < PATCH4 - 64;
     auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 2) return;
-        const int ch = c * KC + wk;
-        const bool chok = ch < p.I;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float* src = chok ? rsrc[j] + (size_t)ch * rstep[j] : shg_wino_zeros;
-            if (ract[j])       // (inactive lanes write nothing: the window is 100 float4, the second piece 36 lanes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + wk * RP + j * 256), 16, 0, 0);
+        for (int q = 0; q < CPL; ++q) {
+            const int k = (wave - NXF) * CPL + q;
+            if (k >= KC) continue;
+            const int ch = c * KC + k;
+            const bool chok = ch < p.I;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino_zeros;
+                if (j == 0 || ract1)       // (inactive lanes write nothing: the window is 100 float4, the second piece 36 lanes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256), 16, 0, 0);
+            }
         }
     };
-    // weights: 32 wave-wide 1 KiB pieces per chunk, 4 per wave
-    const float* ubase = p.wu + (size_t)otile * p.nchunk * U_SZ + lane * 4;
-    auto dma_u = [&](int c, int buf) __attribute__((always_inline)) {
+
+    // ---- weights: wave w multiplies Winograd position w only, so its slice of U never needs to be shared -- each lane
+    // loads its own MFMA A-operands of a chunk (KC floats: [k-step][channel block]) straight into registers, one chunk ahead
+    constexpr int NU = KC / 4;
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(p.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
+    const size_t ustride = (size_t)16 * 64 * KC / 4;            // float4 per chunk
+    f32x4 ua[NU], ub[NU];                                       // even / odd chunks
+    auto load_u = [&](f32x4 (&dst)[NU], int c) __attribute__((always_inline)) {
         if (p.dbg & 1) return;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = j * 8 + wk;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + (size_t)c * U_SZ + piece * 256),
-                                             (__attribute__((address_space(3))) void*)(Ul + buf * U_SZ + piece * 256), 16, 0, 0);
-        }
+        for (int j = 0; j < NU; ++j) dst[j] = ubase[(size_t)c * ustride + j];
     };
 
     // ---- input transform role: channel `wave`, block `lane` (ty = lane/16, tx = lane%16)
     const int tty = lane >> 4, ttx = lane & 15;
-    const float* rbase = Rl + wk * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
-    float* vbase = Vl + wk * BT + lane;                     // + xi*KC*BT
-    // styles of channel `wave` of every chunk, one lane per chunk (up to 128 chunks = 1024 input channels)
+    const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
+    float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
+    // styles of channel `wave` of every chunk, one lane per chunk (up to 128 chunks)
     float scv[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-        const int ch = (v * 64 + lane) * KC + wk;
-        scv[v] = (p.in_scale && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
+        const int ch = (v * 64 + lane) * KC + wave;
+        scv[v] = (p.in_scale && xformer && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
     }
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 4) return;
         // style of this wave's channel in chunk c: lane c%64 of the preloaded vector c/64
         const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
         const float* rb = rbase + buf * R_SZ;
-        float d[4][4];
+        // d B per window row first (two rows of LDS reads in flight at a time: keeps the live set small), then B^T (.)
+        float f[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const f32x2 q0 = *reinterpret_cast<const f32x2*>(rb + r * PW);
             const f32x2 q1 = *reinterpret_cast<const f32x2*>(rb + r * PW + 2);
             const f32x2 q2 = *reinterpret_cast<const f32x2*>(rb + r * PW + 4);
-            d[r][0] = q0[1] * sc; d[r][1] = q1[0] * sc; d[r][2] = q1[1] * sc; d[r][3] = q2[0] * sc;
-        }
-        // B^T d : rows
-        float e[4][4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            e[0][cc] = d[0][cc] - d[2][cc];
-            e[1][cc] = d[1][cc] + d[2][cc];
-            e[2][cc] = d[2][cc] - d[1][cc];
-            e[3][cc] = d[1][cc] - d[3][cc];
+            const float d0 = q0[1] * sc, d1 = q1[0] * sc, d2 = q1[1] * sc, d3 = q2[0] * sc;
+            f[r][0] = d0 - d2; f[r][1] = d1 + d2; f[r][2] = d2 - d1; f[r][3] = d1 - d3;
+            if (r == 1) __builtin_amdgcn_sched_barrier(0);
         }
         float* vb = vbase + buf * V_SZ;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            vb[(r * 4 + 0) * KC * BT] = e[r][0] - e[r][2];
-            vb[(r * 4 + 1) * KC * BT] = e[r][1] + e[r][2];
-            vb[(r * 4 + 2) * KC * BT] = e[r][2] - e[r][1];
-            vb[(r * 4 + 3) * KC * BT] = e[r][1] - e[r][3];
+        for (int j = 0; j < 4; ++j) {
+            vb[(0 * 4 + j) * KC * BT] = f[0][j] - f[2][j];
+            vb[(1 * 4 + j) * KC * BT] = f[1][j] + f[2][j];
+            vb[(2 * 4 + j) * KC * BT] = f[2][j] - f[1][j];
+            vb[(3 * 4 + j) * KC * BT] = f[1][j] - f[3][j];
         }
     };
 
@@ -179,120 +186,123 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ob][tb][r] = 0.f;
-    const float* abase = Ul + (wave * KC + half) * BO + l31;    // + ks*2*BO + ob*32
-    const float* bbase = Vl + (wave * KC + half) * BT + l31;
+    const float* bbase = Vl + (wave * KC + half) * BT + l31;     // + ks*2*BT + tb*32
 
     // ---- prologue
-    const bool loader = wave >= 8;
-    if (loader) {
+    load_u(ua, 0);
+    if (!xformer) {
         dma_raw(0, 0);
-        dma_u(0, 0);
         if (p.nchunk > 1) dma_raw(1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!loader) transform(0, 0);
+    if (xformer) transform(0, 0);
     __syncthreads();
 
-    // The MFMA stream is skewed by one k-step against the barriers: the operands of a chunk's last k-step are read
-    // before the barrier and multiplied after it, while the first operands of the next chunk are on their way from
+    // The MFMA stream is skewed by one k-step against the barriers: the operands of a chunk's last k-step are kept in
+    // registers and multiplied after the barrier, while the first B operands of the next chunk are on their way from
     // LDS -- the matrix pipe has work the moment the barrier releases.
-    float a[2][2], b[2][2];
-    auto mma = [&](int buf) __attribute__((always_inline)) {
+    float b[2][2], apend[2];
+    auto mma = [&](float a0, float a1, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int tb = 0; tb < 2; ++tb) acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[buf][tb], acc[0][tb], 0, 0, 0);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-                acc[ob][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][ob], b[buf][tb], acc[ob][tb], 0, 0, 0);
+        for (int tb = 0; tb < 2; ++tb) acc[1][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[buf][tb], acc[1][tb], 0, 0, 0);
     };
-    for (int c = 0; c < p.nchunk; ++c) {
-        const int cur = c & 1;
+    // one chunk; PAR = c & 1 selects the register buffer holding its weights (the other receives chunk c+1)
+    auto chunk = [&](auto par, int c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        f32x4 (&ucur)[NU] = PAR ? ub : ua;
+        f32x4 (&unxt)[NU] = PAR ? ua : ub;
         const bool more = c + 1 < p.nchunk;
-        const float* ab = abase + cur * U_SZ;
-        const float* bb = bbase + cur * V_SZ;
+        const float* bb = bbase + PAR * V_SZ;
         auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob) a[buf][ob] = ab[(ks * 2) * BO + ob * 32];
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) b[buf][tb] = bb[(ks * 2) * BT + tb * 32];
         };
         fetch(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (c > 0) mma(1);                                      // last k-step of the previous chunk (operands in registers)
+        if (c > 0) mma(apend[0], apend[1], 1);                  // last k-step of the previous chunk
         __builtin_amdgcn_sched_barrier(0);
-        if (loader) {
-            if (more) dma_u(c + 1, cur ^ 1);
-            if (c + 2 < p.nchunk) dma_raw(c + 2, cur);          // raw(c) was consumed during chunk c-1
+        if (more) load_u(unxt, c + 1);                          // (the previous chunk no longer reads this buffer)
+        if (!xformer) {
+            if (c + 2 < p.nchunk) dma_raw(c + 2, PAR);          // raw(c) was consumed during chunk c-1
         } else if (more) {
-            transform(c + 1, cur ^ 1);                          // raw(c+1) landed before the previous barrier
+            transform(c + 1, PAR ^ 1);                          // raw(c+1) landed before the previous barrier
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KC / 2 - 1; ++ks) {
             fetch(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(ks & 1);
+            mma(ucur[(ks * 2) / 4][(ks * 2) % 4], ucur[(ks * 2 + 1) / 4][(ks * 2 + 1) % 4], ks & 1);
         }
-        // k-step 3 stays in a[1]/b[1]; its LDS reads must have completed before the buffers are handed back
+        apend[0] = ucur[(KC - 2) / 4][(KC - 2) % 4];
+        apend[1] = ucur[(KC - 1) / 4][(KC - 1) % 4];
+        // the last k-step's B operands stay in b[1]; their LDS reads must have completed before the buffers are handed back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(p.dbg & 8)) __syncthreads();
+    };
+    for (int c = 0; c < p.nchunk; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < p.nchunk) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
-    mma(1);
+    mma(apend[0], apend[1], 1);
     if (p.dbg & 16) return;
 
-    // ---- epilogue: exchange through LDS (reusing the weight + V buffers: 128 KiB), inverse transform, fused layer tail.
-    // Two passes of 32 channels x 64 blocks; per pass a thread owns pixel block t = tid%64 of channels tid/64 and tid/64+16.
-    float* Mx = Ul;                           // [16][32][64]  (Ul and Vl are adjacent)
+    // ---- epilogue: the 16 M_xi of an (o, t) pair live in 16 waves -> exchanged through LDS (the V buffers), four passes
+    // of 32 channels x 32 blocks; inverse transform and fused layer tail, one (channel, block) item per thread and pass.
+    float* Mx = Vl;                           // [16][32][32]
     const long plane = (long)p.H * p.W;
-    const int t_e = tid & 63;
-    const int oy = oy0 + 2 * (t_e >> 4), ox = ox0 + 2 * (t_e & 15);
-    // per-channel and per-pixel operands of both passes are requested up front (one latency, not four)
-    float osc[2][2], bsv[2][2];               // [ob][q]
-    f32x2 nzv[2];                             // [row]
+    const int o_l = tid >> 5, t_l = tid & 31;
+    // per-channel and per-pixel operands of all passes are requested up front (one latency, not four)
+    float osc[2], bsv[2];
+    f32x2 nzv[2][2];                          // [tb][row]
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
+    for (int ob = 0; ob < 2; ++ob) {
+        const int o = min(o0 + ob * 32 + o_l, p.O - 1);
+        osc[ob] = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
+        bsv[ob] = p.bias ? p.bias[o] : 0.f;
+    }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int o = min(o0 + ob * 32 + (tid >> 6) + 16 * q, p.O - 1);
-            osc[ob][q] = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
-            bsv[ob][q] = p.bias ? p.bias[o] : 0.f;
-        }
+    for (int tb = 0; tb < 2; ++tb) {
+        const int t = tb * 32 + t_l;
+        const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        nzv[i] = f32x2{0.f, 0.f};
-        if (p.noise_mode && oy + i < p.H && ox < p.W) {       // W % 4 == 0 and ox even: both pixels inside, 8-byte aligned
-            const float* np_ = p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + (long)(oy + i) * p.W + ox;
-            nzv[i] = *reinterpret_cast<const f32x2*>(np_);
+        for (int i = 0; i < 2; ++i) {
+            nzv[tb][i] = f32x2{0.f, 0.f};
+            if (p.noise_mode && oy + i < p.H && ox < p.W) {       // W % 4 == 0 and ox even: both pixels inside, 8-byte aligned
+                const float* np_ = p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + (long)(oy + i) * p.W + ox;
+                nzv[tb][i] = *reinterpret_cast<const f32x2*>(np_);
+            }
         }
     }
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
+    for (int pass = 0; pass < 4; ++pass) {
+        const int ob = pass >> 1, tb = pass & 1;
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                Mx[(wave * 32 + row) * 64 + tb * 32 + l31] = acc[ob][tb][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            Mx[(wave * 32 + row) * 32 + l31] = acc[ob][tb][r];
+        }
         __syncthreads();
+        float m[16];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int o_l = (tid >> 6) + 16 * q;
-            float m[16];
+        for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 32 + t_l];
+        // A^T m A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+        float t0[4], t1[4];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 64 + t_e];
-            // A^T m A, A^T = [[1,1,1,0],[0,1,-1,-1]]
-            float t0[4], t1[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                t0[cc] = m[0 * 4 + cc] + m[1 * 4 + cc] + m[2 * 4 + cc];
-                t1[cc] = m[1 * 4 + cc] - m[2 * 4 + cc] - m[3 * 4 + cc];
-            }
-            float yv[2][2];
-            yv[0][0] = t0[0] + t0[1] + t0[2]; yv[0][1] = t0[1] - t0[2] - t0[3];
-            yv[1][0] = t1[0] + t1[1] + t1[2]; yv[1][1] = t1[1] - t1[2] - t1[3];
-            const int o = o0 + ob * 32 + o_l;
-            if (o >= p.O || oy >= p.H || ox >= p.W) continue;
+        for (int cc = 0; cc < 4; ++cc) {
+            t0[cc] = m[0 * 4 + cc] + m[1 * 4 + cc] + m[2 * 4 + cc];
+            t1[cc] = m[1 * 4 + cc] - m[2 * 4 + cc] - m[3 * 4 + cc];
+        }
+        float yv[2][2];
+        yv[0][0] = t0[0] + t0[1] + t0[2]; yv[0][1] = t0[1] - t0[2] - t0[3];
+        yv[1][0] = t1[0] + t1[1] + t1[2]; yv[1][1] = t1[1] - t1[2] - t1[3];
+        const int t = tb * 32 + t_l;
+        const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
+        const int o = o0 + ob * 32 + o_l;
+        if (o < p.O && oy < p.H && ox < p.W) {
             const long base = ((long)n * p.O + o) * plane;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -303,23 +313,25 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
                 f32x2 out;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    float v = yv[i][jj] * osc[ob][q] + nzv[i][jj] * p.noise_strength + bsv[ob][q];
+                    float v = yv[i][jj] * osc[ob] + nzv[tb][i][jj] * p.noise_strength + bsv[ob];
                     v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
                     out[jj] = v + rs[jj];
                 }
                 *reinterpret_cast<f32x2*>(p.y + base + pix) = out;      // W % 4 == 0, ox even: aligned, both pixels inside
             }
         }
-        if (ob == 0) __syncthreads();
+        if (pass < 3) __syncthreads();
     }
 }
 
 // U = G g G^T per (o, i), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; g = w[o,i] * scale[o] (flip = true convolution).
-// Layout wu[otile][chunk][xi][k][64]: the [16][8][64] slice a workgroup needs per chunk is one contiguous 32 KiB run.
+// Layout wu[otile][chunk][xi][lane][KC]: lane = (i & 1) * 32 + o % 32 holds, for its position xi, the MFMA A-operands of the
+// chunk in the order [k-step = (i % KC) / 2][channel block = (o % 64) / 32] -- KC contiguous floats per lane, 64 lanes contiguous.
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* w, const float* scale, float* wu, int O, int I, int OP,
                                                           int nchunk, int flip) {
+    constexpr int KC = wino::KC;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)OP * nchunk * 8;
+    const long total = (long)OP * nchunk * KC;
     if (e >= total) return;
     const int o = (int)(e % OP);
     const int i = (int)(e / OP);
@@ -337,24 +349,29 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* w, const 
         gg[2][cc] = 0.5f * (g[0][cc] - g[1][cc] + g[2][cc]);
         gg[3][cc] = g[2][cc];
     }
-    float* dst = wu + (((long)(o >> 6) * nchunk + (i >> 3)) * 16 * 8 + (i & 7)) * 64 + (o & 63);
+    const int k = i % KC, chunk = i / KC;
+    const int ln = (k & 1) * 32 + (o & 31), slot = (k >> 1) * 2 + ((o & 63) >> 5);
+    float* dst = wu + ((((long)(o >> 6) * nchunk + chunk) * 16) * 64 + ln) * KC + slot;      // + xi * 64 * KC
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        dst[(long)(r * 4 + 0) * 8 * 64] = gg[r][0];
-        dst[(long)(r * 4 + 1) * 8 * 64] = 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]);
-        dst[(long)(r * 4 + 2) * 8 * 64] = 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]);
-        dst[(long)(r * 4 + 3) * 8 * 64] = gg[r][2];
+        dst[(long)(r * 4 + 0) * 64 * KC] = gg[r][0];
+        dst[(long)(r * 4 + 1) * 64 * KC] = 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]);
+        dst[(long)(r * 4 + 2) * 64 * KC] = 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]);
+        dst[(long)(r * 4 + 3) * 64 * KC] = gg[r][2];
     }
 }
 
+// input channels per weight chunk of the Winograd layout (sizes wu: [OP/64][ceil(I/chunk)][16][64][chunk] floats)
+extern "C" int shg_conv_wino_chunk(void) { return wino::KC; }
+
 // w [O,I,3,3], wscale [O] (per-output-channel factor: the demodulation pre-normalisation * gain of shg_conv_weight_prep_f32,
-// or all `gain`), wu [OP/64][ceil(I/8)][16][8][64] out (OP = O rounded up to 64; padding zero filled).
+// or all `gain`), wu out (OP = O rounded up to 64; padding zero filled).
 extern "C" int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip,
                                              void* stream) {
     SHG_CHECK_ARG(w && wscale && wu, "weight_prep_wino: null pointer");
     SHG_CHECK_ARG(O >= 1 && I >= 1 && OP % 64 == 0 && OP >= O, "weight_prep_wino: bad shape");
-    const int nchunk = shg_cdiv(I, 8);
-    const long total = (long)OP * nchunk * 8;
+    const int nchunk = shg_cdiv(I, wino::KC);
+    const long total = (long)OP * nchunk * wino::KC;
     hipLaunchKernelGGL(wino_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu, O, I, OP,
                        nchunk, flip);
     SHG_CHECK_LAUNCH();
@@ -370,7 +387,7 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d_wino: empty tensor");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino: OP must be a multiple of 64 and >= O");
     SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && (long)NB * O * H * W < 2147483647L, "conv2d_wino: tensor too large");
-    SHG_CHECK_ARG(I <= 1024, "conv2d_wino: at most 1024 input channels");
+    SHG_CHECK_ARG(I <= 128 * wino::KC, "conv2d_wino: too many input channels");
     SHG_CHECK_ARG(W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "conv2d_wino: needs W %% 4 == 0 and a 16-byte aligned x (use shg_conv2d_f32 otherwise)");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0,
                   "conv2d_wino: y / noise / residual must be 8-byte aligned");
@@ -379,7 +396,7 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
     p.tiles_x = shg_cdiv(W, 2 * wino::TX); p.tiles_y = shg_cdiv(H, 2 * wino::TY);
-    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, 8);
+    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino::KC);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }

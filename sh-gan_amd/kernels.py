@@ -188,8 +188,9 @@ class PreppedWeight:
         if self.wu is None:
             if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
                 raise _lib.ShgError('PreppedWeight.wino: needs an ungrouped 3x3 weight')
-            nchunk = (self.i + 7) // 8
-            self.wu = torch.empty((self.op // 64) * nchunk * 16 * 8 * 64, device=self.wt.device, dtype=torch.float32)
+            kc = int(_lib.get_lib().shg_conv_wino_chunk())
+            nchunk = (self.i + kc - 1) // kc
+            self.wu = torch.empty((self.op // 64) * nchunk * 16 * 64 * kc, device=self.wt.device, dtype=torch.float32)
             check(_lib.get_lib().shg_conv_weight_prep_wino_f32(_ptr(self._w), _ptr(self._wscale), _ptr(self.wu), self.o, self.i,
                                                                self.op, int(bool(self._flip)), _stream()), 'conv_weight_prep_wino')
             self._w = None          # the transformed copy is all that is needed from here on
