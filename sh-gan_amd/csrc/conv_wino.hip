@@ -9,16 +9,19 @@
 //
 // GEMM view: 16 independent products  M_xi[o, t] = sum_i U_xi[i, o] * V_xi[i, t]   (xi = position in the 4x4 block,
 // t = 2x2 output block).  One workgroup = 64 output channels x 64 blocks (4 x 16 blocks = 8 x 32 pixels of one image)
-// x all 16 positions: 64 accumulator tiles of 32x32 spread over 8 waves (wave w owns positions 2w, 2w+1).  K is
-// consumed in chunks of 8 input channels:
-//   * U chunk [16][8][64] (pre-transformed weights, prepared once per parameter version) arrives by LDS-DMA;
-//   * the raw 10 x 40 input window of the chunk's 8 channels arrives by 16-byte LDS-DMA (wave w: channel w), is transformed
-//     by the same wave (B^T d B, 32 add/sub per 4x4 block, per-sample style applied here) and written as V [16][8][64];
-//   * everything is double buffered: while chunk c is multiplied, U(c+1) / raw(c+2) are in flight and V(c+1) is built;
-//     one barrier per chunk.  The two wave groups build V at different points of the chunk so that one wave per SIMD
-//     always has MFMAs to issue.
-// Epilogue: the 16 M_xi of an (o, t) pair live in 16 different waves -> they are exchanged through LDS in two passes
-// of 32 channels x 64 blocks; each thread then applies A^T . A, the fused layer tail (demodulation coefficient, noise,
+// x all 16 positions = 64 accumulator tiles of 32x32, spread over 16 waves: wave w owns position w (4 tiles), so there
+// are four independent instruction streams per SIMD.  K is consumed in chunks of 8 input channels:
+//   * U (pre-transformed weights, prepared once per parameter version) never touches LDS: position w's slice is needed
+//     by wave w only, so every lane loads its own MFMA A-operands of the next chunk (8 floats, two 16-byte loads from a
+//     lane-major layout) into registers while the current chunk is multiplied;
+//   * the raw 10 x 40 input window of the chunk's 8 channels arrives by 16-byte LDS-DMA (waves 8-15, one channel each);
+//   * waves 0-7 transform one channel each (B^T d B, 32 add/sub per 4x4 block, per-sample style applied here) and write
+//     V [16][8][64] to LDS, from where every wave reads the B operands of its position;
+//   * V and the raw windows are double buffered: while chunk c is multiplied, raw(c+2) is in flight and V(c+1) is
+//     built; one barrier per chunk, and the MFMA stream is skewed one k-step across it so that the matrix pipe has work
+//     while the next operands arrive from LDS.
+// Epilogue: the 16 M_xi of an (o, t) pair live in 16 different waves -> they are exchanged through LDS in four passes
+// of 32 channels x 32 blocks; each thread then applies A^T . A, the fused layer tail (demodulation coefficient, noise,
 // bias, lrelu_agc, skip) and stores two pixels at a time (128-byte row segments per 16 lanes).
 #include "shg_common.h"
 #include <stdlib.h>
