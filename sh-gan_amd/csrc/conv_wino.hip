@@ -49,7 +49,7 @@ struct WinoParams {
     float noise_strength;
     int act;
     float alpha, gain, clamp;
-    int dbg;                 // timing studies (SHG_WINO_DBG): 1 skip weight DMA, 2 skip patch DMA, 4 skip transform, 8 skip barriers, 16 skip epilogue
+    int dbg;                 // timing studies (SHG_WINO_DBG): 1 skip weight DMA, 2 skip patch DMA, 4 skip transform, 16 skip epilogue
 };
 
 namespace wino {
@@ -80,9 +80,11 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
 
 __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     using namespace wino;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vl = smem;                         // [2][16][KC][64]
-    float* Rl = smem + 2 * V_SZ;              // [2][KC][RP]
+    // Two separate LDS objects: the compiler then knows that the LDS-DMA into the raw windows cannot alias the operand
+    // reads from V, and does not park an `s_waitcnt vmcnt(0)` (= the full latency of the DMA and weight loads it has just
+    // issued) in front of the chunk's MFMAs.
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
+    __shared__ __attribute__((aligned(16))) float Rl[2 * R_SZ];      // [2][KC][RP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         apend[1] = ucur[(KC - 1) / 4][(KC - 1) % 4];
         // the last k-step's B operands stay in b[1]; their LDS reads must have completed before the buffers are handed back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(p.dbg & 8)) __syncthreads();
+        __syncthreads();     // (unconditional: a path without it would leave the weight loads pending for the compiler's wait-count tracking)
     };
     for (int c = 0; c < p.nchunk; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);
@@ -403,14 +405,7 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)wino::LDS_BYTES);
-        if (e != hipSuccess) { shg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SHG_ERR_LAUNCH; }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), wino::LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_wino_kernel, dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
