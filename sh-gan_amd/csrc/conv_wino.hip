@@ -43,7 +43,7 @@ struct WinoParams {
     const float* noise;      // see noise_mode
     const float* residual;   // like y, added after the activation
     int NB, I, O, OP, H, W;
-    int tiles_x, tiles_y;    // 32-pixel x 8-pixel tiles per image
+    int tiles_x, tiles_y;    // tiles per image (8 x 32 or 16 x 16 pixels)
     int n_ttiles, n_otiles, nchunk;
     int noise_mode;          // 0 none, 1 [H,W], 2 [NB,H,W]
     float noise_strength;
@@ -58,16 +58,22 @@ namespace wino {
 #ifndef SHG_WINO_KC
 #define SHG_WINO_KC 8
 #endif
-constexpr int KC = SHG_WINO_KC, BO = 64, TY = 4, TX = 16, BT = TY * TX;
+constexpr int KC = SHG_WINO_KC, BO = 64, BT = 64;
 static_assert(KC % 4 == 0 && (KC / 2) % 2 == 0 && KC <= 12, "KC: multiple of 4 with an even number of k-steps");
-// raw window per channel: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35 (16-byte aligned in global memory when W % 4 == 0,
-// and every float4 is either inside the image or entirely padding) = 10 x 10 float4, fetched by two 16-byte LDS-DMAs
-constexpr int PH = 2 * TY + 2, PW = 2 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
-constexpr int RP = PH * PW;                                        // 400 floats per channel
-constexpr int V_SZ = 16 * KC * BT, R_SZ = KC * RP;
+// A tile is TY x TX blocks (TY * TX = 64) = 2TY x 2TX pixels: 4 x 16 (8 x 32 px) for images at least 32 wide, 8 x 8
+// (16 x 16 px) below.  Raw window per channel: rows oy0-1 .. oy0+2TY, columns ox0-4 .. ox0+2TX+3 (16-byte aligned in global
+// memory when W % 4 == 0, and every float4 is either inside the image or entirely padding), fetched by two 16-byte LDS-DMAs.
+template <int TY, int TX>
+struct Tile {
+    static_assert(TY * TX == BT, "64 blocks per tile");
+    static constexpr int PH = 2 * TY + 2, PW = 2 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
+    static constexpr int RP = PH * PW;                             // floats per channel (400 / 432)
+    static constexpr int R_SZ = KC * RP;
+    static_assert(PATCH4 <= 128, "window = two wave-wide DMA pieces");
+};
+constexpr int V_SZ = 16 * KC * BT;
 constexpr int NT = 1024;                 // 16 waves: wave w multiplies position w
 constexpr int NXF = KC;                  // waves 0..KC-1 transform one channel each; the others issue the window DMAs
-constexpr size_t LDS_BYTES = sizeof(float) * 2 * (V_SZ + R_SZ);
 static_assert(2 * V_SZ >= 16 * 32 * 32, "epilogue exchange buffer lives in the V region");
 }   // namespace wino
 
@@ -78,8 +84,11 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int total) {
     return base + idx;
 }
 
+template <int TY, int TX>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     using namespace wino;
+    using T = Tile<TY, TX>;
+    constexpr int PW = T::PW, PW4 = T::PW4, PATCH4 = T::PATCH4, RP = T::RP, R_SZ = T::R_SZ;
     // Two separate LDS objects: the compiler then knows that the LDS-DMA into the raw windows cannot alias the operand
     // reads from V, and does not park an `s_waitcnt vmcnt(0)` (= the full latency of the DMA and weight loads it has just
     // issued) in front of the chunk's MFMAs.
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     };
 
     // ---- input transform role: channel `wave`, block `lane` (ty = lane/16, tx = lane%16)
-    const int tty = lane >> 4, ttx = lane & 15;
+    const int tty = lane / TX, ttx = lane % TX;
     const float* rbase = Rl + wave * RP + (2 * tty) * PW + 2 * ttx + 2;     // window column 2*tx+3 = patch column 2*tx, read from the even column before it
     float* vbase = Vl + wave * BT + lane;                     // + xi*KC*BT
     // styles of channel `wave` of every chunk, one lane per chunk (up to 128 chunks)
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
         const int t = tb * 32 + t_l;
-        const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
+        const int oy = oy0 + 2 * (t / TX), ox = ox0 + 2 * (t % TX);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             nzv[tb][i] = f32x2{0.f, 0.f};
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         yv[0][0] = t0[0] + t0[1] + t0[2]; yv[0][1] = t0[1] - t0[2] - t0[3];
         yv[1][0] = t1[0] + t1[1] + t1[2]; yv[1][1] = t1[1] - t1[2] - t1[3];
         const int t = tb * 32 + t_l;
-        const int oy = oy0 + 2 * (t >> 4), ox = ox0 + 2 * (t & 15);
+        const int oy = oy0 + 2 * (t / TX), ox = ox0 + 2 * (t % TX);
         const int o = o0 + ob * 32 + o_l;
         if (o < p.O && oy < p.H && ox < p.W) {
             const long base = ((long)n * p.O + o) * plane;
@@ -400,12 +409,14 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
-    p.tiles_x = shg_cdiv(W, 2 * wino::TX); p.tiles_y = shg_cdiv(H, 2 * wino::TY);
+    const bool wide = W >= 32;               // 8 x 32 pixel tiles, else 16 x 16
+    p.tiles_x = shg_cdiv(W, wide ? 32 : 16); p.tiles_y = shg_cdiv(H, wide ? 8 : 16);
     p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino::KC);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
+    if (wide) hipLaunchKernelGGL((conv_wino_kernel<4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

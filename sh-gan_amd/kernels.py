@@ -217,10 +217,10 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
     return PreppedWeight(wt, wsq, o, i, op, kh, kw, groups, w=w if keep else None, wscale=wscale if keep else None, flip=flip)
 
 
-# Winograd F(2x2,3x3) path for stride-1 3x3 'same' convolutions on images of at least WINO_MIN pixels per side
+# Winograd F(2x2,3x3) path for stride-1 3x3 'same' convolutions on images of at least WINO_MIN pixels per side (8 x 32 pixel tiles from 32 columns up, 16 x 16 below)
 # (SHG_WINO=0 keeps everything on the direct implicit-GEMM kernel).
 WINO = os.environ.get('SHG_WINO', '1') != '0'
-WINO_MIN = int(os.environ.get('SHG_WINO_MIN', '32'))
+WINO_MIN = int(os.environ.get('SHG_WINO_MIN', '16'))
 
 
 MODE_SAME, MODE_DOWN2, MODE_UP2T = 0, 1, 2

@@ -147,6 +147,7 @@ def test_mfma_conv_vs_torch_cpu(mods, n, ci, co, h, w, k, mode, pad):
 WINO_CASES = [
     # n, ci, co, h, w : ragged channel counts (I % 8, O % 64), odd extents, several tiles per image, one-chunk K
     (2, 64, 64, 32, 32), (1, 13, 70, 33, 36), (3, 8, 3, 40, 64), (2, 72, 130, 35, 68), (1, 128, 64, 64, 96), (2, 5, 5, 32, 44),
+    (2, 64, 64, 16, 16), (1, 24, 70, 20, 24), (3, 16, 130, 17, 28),      # 16 x 16 pixel tiles (images narrower than 32)
     (1, 16, 16, 32, 33),      # W % 4 != 0: the wrapper must fall back to the direct kernel
 ]
 
