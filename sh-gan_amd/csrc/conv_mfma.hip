@@ -499,6 +499,16 @@ __global__ __launch_bounds__(WO * WP * 64, OCC) void conv_mfma_kernel(const Conv
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[ph][mo][np][r] += tw[(size_t)sl * NREG * NT + r * NT];
                 }
+                if constexpr (UP && OCC == 4) {
+                    // the 16-wave transposed variant is dispatched for the planar hand-over to the FIR kernel only
+                    // (no fused tail here: it lives in fir_up_planar): plain stores, no operand gather
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ob + (r & 3) + 8 * (r >> 2);
+                        if (o < p.O) p.y[base + (long)o * plane] = acc[ph][mo][np][r] * p.gain;
+                    }
+                    continue;
+                }
                 // gather the per-channel operands first (independent loads, one wait), then compute and store
                 float osc[16], bs[16], rs[16];
 #pragma unroll
@@ -695,14 +705,18 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
 static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, size_t ws_bytes, hipStream_t s) {
     const bool narrow = p.O <= 64;    // 64 x 256 tile instead of 128 x 128
     // SHG_CONV_VARIANT (tuning knob, bit flags): 1 = force the single-buffer 4-wave kernels; 2 / 4 / 8 = try the 8-wave
-    // double-buffered variants for 64-channel layers / stride-2 (128 px) / stride-2 (256 px); 16 = 16-wave transposed conv;
+    // double-buffered variants for 64-channel layers / stride-2 (128 px) / stride-2 (256 px); 16 = transposed conv back on 8 waves;
     // 32 = stride-2 back on 8 waves
     static const int variant = getenv("SHG_CONV_VARIANT") ? atoi(getenv("SHG_CONV_VARIANT")) : 0;
     if (up) {
         // all-phase transposed conv: large grids use 8-wave double-buffered tiles (128 ch x 128 px, or 64 ch x 256 px),
         // small ones the 4-wave 64 ch x 128 px tile (+ split-K)
         const bool big = !(variant & 1) && p.OWp >= conv_up_min() && p.OHp >= 16 && p.wgroups == 1;
-        if (big && !narrow && (variant & 16)) return launch_conv<9, 8, 1, 1, 4, 4, 1, true, true, 4>(p, workspace, ws_bytes, s);
+        const bool raw_out = p.out_mode == 1 && !p.out_scale && !p.bias && !p.noise && !p.residual && !p.act;
+        // planar hand-over to the FIR kernel: 16 waves (four instruction streams per SIMD), 128 ch x 128 px or 64 ch x 256 px
+        if (big && raw_out && !(variant & 16))
+            return narrow ? launch_conv<9, 8, 1, 1, 2, 8, 1, true, true, 4>(p, workspace, ws_bytes, s)
+                          : launch_conv<9, 8, 1, 1, 4, 4, 1, true, true, 4>(p, workspace, ws_bytes, s);
         if (big) return narrow ? launch_conv<9, 8, 2, 1, 1, 8, 1, true, true, 2>(p, workspace, ws_bytes, s)
                                : launch_conv<9, 8, 2, 1, 2, 4, 1, true, true, 2>(p, workspace, ws_bytes, s);
         return launch_conv<9, 8, 2, 1, 1, 4, 2, true, false, 2>(p, workspace, ws_bytes, s);
