@@ -117,9 +117,12 @@ extern "C" int shg_conv1x1_thin_in_f32(const float* x, const float* w, const flo
 
 template <int MAXO>
 __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const float* w, const float* styles, const float* bias,
-                                                    const float* base_up, const float* f, float* y, int I, int O, int H, int W) {
-    // ws[o][i] = w[o,i] * styles[n,i] staged in LDS; one thread = one output pixel x (coalesced rows)
-    extern __shared__ float ws[];   // [MAXO][I]
+                                                    const float* base_up, const float* f, float* y, int I, int O, int H, int W,
+                                                    int S) {
+    // ws[o][i] = w[o,i] * styles[n,i] staged in LDS.  A workgroup = 256/S pixels x S channel slices (S = 1 for large
+    // images: one thread per pixel, coalesced rows; small images split the channel loop S ways so that the serial
+    // chain per thread stays short) -- the slices are summed through LDS.
+    extern __shared__ float ws[];   // [MAXO][I] + [S-1][256/S][MAXO] partial sums
     const int n = blockIdx.z;
     for (int k = threadIdx.x; k < O * I; k += 256) {
         const int i = k % I;
@@ -127,25 +130,44 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const float*
     }
     __syncthreads();
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
+    const int PPB = 256 / S;                         // pixels per workgroup
+    const int pl = threadIdx.x % PPB, slice = threadIdx.x / PPB;
+    const int pix = blockIdx.x * PPB + pl;
+    const bool inside = pix < HW;
     float acc[MAXO];
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) acc[o] = 0.f;
-    const float* xp = x + (long)n * I * HW + pix;
-    int i = 0;
-    for (; i + 4 <= I; i += 4) {
-        const float x0 = xp[(long)i * HW], x1 = xp[(long)(i + 1) * HW], x2 = xp[(long)(i + 2) * HW], x3 = xp[(long)(i + 3) * HW];
+    const int per = (I + S - 1) / S;
+    const int i_lo = slice * per, i_hi = min(I, i_lo + per);
+    if (inside) {
+        const float* xp = x + (long)n * I * HW + pix;
+        int i = i_lo;
+        for (; i + 4 <= i_hi; i += 4) {
+            const float x0 = xp[(long)i * HW], x1 = xp[(long)(i + 1) * HW], x2 = xp[(long)(i + 2) * HW], x3 = xp[(long)(i + 3) * HW];
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-            if (o < O) acc[o] += ws[o * I + i] * x0 + ws[o * I + i + 1] * x1 + ws[o * I + i + 2] * x2 + ws[o * I + i + 3] * x3;
-    }
-    for (; i < I; ++i) {
-        const float x0 = xp[(long)i * HW];
+            for (int o = 0; o < MAXO; ++o)
+                if (o < O) acc[o] += ws[o * I + i] * x0 + ws[o * I + i + 1] * x1 + ws[o * I + i + 2] * x2 + ws[o * I + i + 3] * x3;
+        }
+        for (; i < i_hi; ++i) {
+            const float x0 = xp[(long)i * HW];
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-            if (o < O) acc[o] += ws[o * I + i] * x0;
+            for (int o = 0; o < MAXO; ++o)
+                if (o < O) acc[o] += ws[o * I + i] * x0;
+        }
     }
+    if (S > 1) {
+        float* red = ws + MAXO * I;                  // [S-1][PPB][MAXO]
+        if (slice > 0) {
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) red[((slice - 1) * PPB + pl) * MAXO + o] = acc[o];
+        }
+        __syncthreads();
+        if (slice > 0) return;
+        for (int sl = 0; sl < S - 1; ++sl)
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) acc[o] += red[(sl * PPB + pl) * MAXO + o];
+    }
+    if (!inside) return;
     const int oy = pix / W, ox = pix - oy * W;
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) {
@@ -184,10 +206,13 @@ extern "C" int shg_torgb_f32(const float* x, const float* w, const float* styles
     SHG_CHECK_ARG(O >= 1 && O <= 4, "torgb: O must be in 1..4 (got %d)", O);
     SHG_CHECK_ARG(!base_up || (f && H % 2 == 0 && W % 2 == 0), "torgb: base_up needs a 4x4 filter and even H, W");
     SHG_CHECK_ARG(N >= 1 && N <= 65535, "torgb: bad N");
-    SHG_CHECK_ARG((size_t)O * I * 4 <= 64 * 1024, "torgb: I too large");
-    dim3 grid(shg_cdiv(H * W, 256), 1, N);
-    hipLaunchKernelGGL((torgb_kernel<4>), grid, dim3(256), sizeof(float) * O * I, (hipStream_t)stream, x, w, styles, bias, base_up,
-                       f, y, I, O, H, W);
+    SHG_CHECK_ARG((size_t)4 * I * 4 + 4096 <= 64 * 1024, "torgb: I too large");
+    // channel slices per pixel: enough to put >= ~64k threads on the chip (small images are otherwise one long serial chain)
+    int S = 1;
+    while (S < 16 && (long)N * H * W * S < 65536 && I / (S * 2) >= 8) S *= 2;
+    dim3 grid(shg_cdiv(H * W, 256 / S), 1, N);
+    hipLaunchKernelGGL((torgb_kernel<4>), grid, dim3(256), sizeof(float) * (4 * I + (S - 1) * (256 / S) * 4), (hipStream_t)stream, x, w,
+                       styles, bias, base_up, f, y, I, O, H, W, S);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
