@@ -22,10 +22,19 @@
 // 32x32 (x4 phases for UP).  K is consumed in chunks of KC input channels: weights [KC*NTAPS][BO] and
 // the input patch [PATCH][KC+1] live in LDS; every MFMA covers two channels of one tap (lanes 0-31:
 // channel c, lanes 32-63: channel c+1).  Operand reads are conflict-free ds_read_b32 with immediate
-// offsets.  The next chunk is prefetched into registers (global loads in flight) while the current
-// one is multiplied, so one workgroup alone keeps its MFMA pipes fed; 2 workgroups per CU cover the
-// barrier gaps.  Small grids are split along K (partial sums to a workspace + a fused reduce/epilogue
-// kernel) so that 4x4..16x16 layers still fill 256 CUs.
+// offsets, prefetched one step ahead of the MFMAs that consume them.
+// Two families of instantiations:
+//   * DB (large images): 8 or 16 waves, one workgroup per CU, double-buffered LDS and one barrier per
+//     chunk.  Weights go global -> LDS by LDS-DMA (1 KiB per wave instruction, no registers); the patch
+//     is register-staged (styles applied on the way) and handed over to LDS by the wave groups of a
+//     SIMD at evenly spread points of the chunk, so some wave always has MFMAs to issue.  Workgroups
+//     beyond the last full round over the CUs are cut into K-slices (tail split) and finished by a tiny
+//     second launch of the same kernel.
+//   * single buffer (small images / 64-channel tiles): 4 waves, 2-3 workgroups per CU cover each
+//     other's barrier gaps; small grids are split along K (partial sums to a workspace + a fused
+//     reduce/epilogue kernel) so that 4x4..16x16 layers still fill 256 CUs.
+// The stride-1 3x3 layers of images >= 16x16 normally run on the Winograd kernel (conv_wino.hip); this
+// file serves them when W % 4 != 0 and for everything else (stride 2, transposed, 1x1, tiny images).
 #include "shg_common.h"
 #include <stdlib.h>
 #include <utility>
