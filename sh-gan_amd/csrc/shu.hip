@@ -21,46 +21,87 @@ __device__ __forceinline__ void shu_build_twiddles(float2* tw) {
     }
 }
 
+typedef float shu_f32x16 __attribute__((ext_vector_type(16)));
+
 // x: channel planes [C][64][64] per sample at x + n*xbs.  T: [N, 2C, 64, 33]; ch c = Re, ch C+c = Im,
 // rows shifted so DC sits on row 31 (shgan.py:313-319), scaled by 1/4096 (norm='forward').
+//
+// Both passes are small dense matrix products with the DFT matrices and run on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32, exact fp32 products / fp32 accumulation -- same arithmetic as a scalar DFT loop):
+//   pass 1 (along w, real input):   P[m][h] = sum_w A1[m][w] x[h][w],  m = 0..32 -> cos rows (Re R[h][m]),
+//                                   m = 33..63 -> -sin rows of k = m-32 = 1..31 (Im R[h][k]; Im is 0 at k = 0, 32)
+//   pass 2 (along h, complex):      D[m][k] = sum_kk A2[m][kk] B[kk][k],  B = [Re R ; Im R] (128 x 33),
+//                                   m < 64: Re T[u=m] = [cos | sin],  m >= 64: Im T[u=m-64] = [-sin | cos]
+// One workgroup = one plane, 4 waves = 4 output tiles of 32x32 per pass; column k = 32 of pass 2 (the 33rd) is
+// done by 128 threads on the VALU.
 __global__ __launch_bounds__(256) void shu_rfft2_shift_kernel(const float* x, long xbs, float* T, int C) {
     __shared__ float xs[SHU_N][SHU_N + 1];
-    __shared__ float2 R[SHU_N][SHU_NH];
+    __shared__ float Rr[SHU_N][SHU_NH], Ri[SHU_N][SHU_NH];
     __shared__ float2 tw[SHU_N];
     const int c = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     shu_build_twiddles(tw);
     const float* xp = x + (long)n * xbs + (long)c * SHU_N * SHU_N;
-    for (int e = threadIdx.x; e < SHU_N * SHU_N; e += 256) xs[e >> 6][e & 63] = xp[e];
+    for (int e = tid; e < SHU_N * SHU_N; e += 256) xs[e >> 6][e & 63] = xp[e];
+    if (tid < SHU_N) { Ri[tid][0] = 0.f; Ri[tid][32] = 0.f; }
     __syncthreads();
-    // real -> half-complex along w
-    for (int e = threadIdx.x; e < SHU_N * SHU_NH; e += 256) {
-        const int h = e / SHU_NH, k = e - h * SHU_NH;
-        float re = 0.f, im = 0.f;
+    {   // ---- pass 1: tile (mt, nt) = (wave / 2, wave % 2); K = w
+        const int m = (wave >> 1) * 32 + l31, h = (wave & 1) * 32 + l31;
+        const int km = m < SHU_NH ? m : m - 32;             // frequency of this A row
+        shu_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int idx = (km * half) & 63;                          // (km * w) mod 64 for w = 2*ks + half
 #pragma unroll 8
-        for (int w = 0; w < SHU_N; ++w) {
-            const float2 t = tw[(k * w) & 63];
-            const float v = xs[h][w];
-            re += v * t.x;
-            im -= v * t.y;
+        for (int ks = 0; ks < SHU_N / 2; ++ks) {
+            const float2 t = tw[idx];
+            const float av = m < SHU_NH ? t.x : -t.y;
+            const float bv = xs[h][2 * ks + half];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            idx = (idx + 2 * km) & 63;
         }
-        R[h][k] = make_float2(re, im);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (mr < SHU_NH) Rr[h][mr] = acc[r]; else Ri[h][mr - 32] = acc[r];
+        }
     }
     __syncthreads();
-    // complex DFT along h, scale, shift rows, split re/im into channels
     const float sc = 1.0f / (SHU_N * SHU_N);
-    for (int e = threadIdx.x; e < SHU_N * SHU_NH; e += 256) {
-        const int u = e / SHU_NH, k = e - u * SHU_NH;
-        float re = 0.f, im = 0.f;
+    {   // ---- pass 2, columns k = 0..31: m-tile = wave (rows m = wave*32 ..), K = 128 (Re R rows, then Im R rows)
+        const int m = wave * 32 + l31, u = m & 63;
+        const bool imrow = m >= 64;
+        shu_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int idx = (u * half) & 63;                           // (u * h) mod 64, h = (2*ks + half) mod 64
 #pragma unroll 8
+        for (int ks = 0; ks < SHU_N; ++ks) {
+            const int kk = 2 * ks + half, h = kk & 63;
+            const bool second = kk >= 64;                     // B row from Im R
+            const float2 t = tw[idx];
+            // Re T = cos*Rr + sin*Ri ;  Im T = -sin*Rr + cos*Ri      (e^{-i theta})
+            const float av = imrow ? (second ? t.x : -t.y) : (second ? t.y : t.x);
+            const float bv = second ? Ri[h][l31] : Rr[h][l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            idx = (idx + 2 * u) & 63;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int ur = mr & 63, row = (ur + 31) & 63;
+            T[(((long)n * 2 * C + (mr >= 64 ? C : 0) + c) * SHU_N + row) * SHU_NH + l31] = acc[r] * sc;
+        }
+    }
+    if (tid < 2 * SHU_N) {   // ---- pass 2, column k = 32 (Im R = 0 there)
+        const int u = tid & 63;
+        const bool imrow = tid >= 64;
+        float v = 0.f;
         for (int h = 0; h < SHU_N; ++h) {
             const float2 t = tw[(u * h) & 63];
-            const float2 v = R[h][k];
-            re += v.x * t.x + v.y * t.y;     // (a+bi)(c - si)
-            im += v.y * t.x - v.x * t.y;
+            v += (imrow ? -t.y : t.x) * Rr[h][32];
         }
-        const int r = (u + 31) & 63;
-        T[(((long)n * 2 * C + c) * SHU_N + r) * SHU_NH + k] = re * sc;
-        T[(((long)n * 2 * C + C + c) * SHU_N + r) * SHU_NH + k] = im * sc;
+        T[(((long)n * 2 * C + (imrow ? C : 0) + c) * SHU_N + ((u + 31) & 63)) * SHU_NH + 32] = v * sc;
     }
 }
 
@@ -102,7 +143,7 @@ __global__ __launch_bounds__(256) void shu_split_irfft2_kernel(const ShuSplitPar
         S[e / SHU_NH][e % SHU_NH] = make_float2(re, im);
     }
     __syncthreads();
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < 4; ++l) {          // r = 4 .. 32: scalar DFTs (together 1/7 of the work of the 64 x 64 level)
         const int r = 4 << l, rh = r / 2 + 1, tstep = SHU_N / r;
         if (!p.out[l]) continue;
         const float* g = p.gauss[l];
@@ -133,6 +174,90 @@ __global__ __launch_bounds__(256) void shu_split_irfft2_kernel(const ShuSplitPar
             op[e] = p.accumulate ? op[e] + v : v;
         }
         __syncthreads();
+    }
+    if (!p.out[4]) return;
+    // ---- r = 64 level on the matrix cores (same scheme as shu_rfft2_shift_kernel, inverse signs):
+    //   V[j][w] = g[a][w] * S[a][w], a = (j + 31) & 63                     (weight + row un-shift, shgan.py:328-334)
+    //   pass A: [Re Z ; Im Z][m][w] = sum_kk A[m][kk] [Re V ; Im V][kk][w]   A = [[cos, -sin], [sin, cos]](theta j y)
+    //   pass B: out[y][x] = sum_kk Zc[y][kk] Bm[kk][x],  kk < 33: Re Z[y][w=kk] * c_w cos(theta w x) (c_0 = c_32 = 1, else 2),
+    //           kk >= 33: Im Z[y][w=kk-32] * (-2 sin(theta w x))            (c2r ignores Im of the DC / Nyquist bins)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    float* Vr = reinterpret_cast<float*>(&Z[0][0]);          // [64][33]
+    float* Vi = Vr + SHU_N * SHU_NH;
+    {
+        const float* g = p.gauss[4];
+        for (int e = tid; e < SHU_N * SHU_NH; e += 256) {
+            const int j = e / SHU_NH, w = e - j * SHU_NH;
+            const int a = (j + 31) & 63;
+            const float2 v = S[a][w];
+            const float gw = g[a * SHU_NH + w];
+            Vr[e] = gw * v.x; Vi[e] = gw * v.y;
+        }
+    }
+    __syncthreads();
+    float* Zr = reinterpret_cast<float*>(&S[0][0]);          // [64][33]  (S is no longer needed)
+    float* Zi = Zr + SHU_N * SHU_NH;
+    {   // pass A, columns w = 0..31: m-tile = wave, K = 128 (Re V rows, then Im V rows)
+        const int m = wave * 32 + l31, y = m & 63;
+        const bool imrow = m >= 64;
+        shu_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int idx = (y * half) & 63;
+#pragma unroll 8
+        for (int ks = 0; ks < SHU_N; ++ks) {
+            const int kk = 2 * ks + half, j = kk & 63;
+            const bool second = kk >= 64;
+            const float2 t = tw[idx];
+            // Re Z = cos*Vr - sin*Vi ;  Im Z = sin*Vr + cos*Vi      (e^{+i theta})
+            const float av = imrow ? (second ? t.x : t.y) : (second ? -t.y : t.x);
+            const float bv = (second ? Vi : Vr)[j * SHU_NH + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            idx = (idx + 2 * y) & 63;
+        }
+        // column w = 32 on the VALU (threads 0..127: row m = tid)
+        float v32 = 0.f;
+        if (tid < 2 * SHU_N) {
+            const int yy = tid & 63;
+            const bool im2 = tid >= 64;
+            for (int j = 0; j < SHU_N; ++j) {
+                const float2 t = tw[(yy * j) & 63];
+                const float vr = Vr[j * SHU_NH + 32], vi = Vi[j * SHU_NH + 32];
+                v32 += im2 ? (t.y * vr + t.x * vi) : (t.x * vr - t.y * vi);
+            }
+        }
+        __syncthreads();                 // everyone is done reading S-derived data? (S itself was last read above) -> Zr/Zi may be written
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            (mr >= 64 ? Zi : Zr)[(mr & 63) * SHU_NH + l31] = acc[r];
+        }
+        if (tid < 2 * SHU_N) (tid >= 64 ? Zi : Zr)[(tid & 63) * SHU_NH + 32] = v32;
+    }
+    __syncthreads();
+    {   // pass B: tile (mt, nt) = (wave / 2, wave % 2), rows m = y, columns n = x, K = 64
+        const int y = (wave >> 1) * 32 + l31, x = (wave & 1) * 32 + l31;
+        shu_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int ks = 0; ks < SHU_N / 2; ++ks) {
+            const int kk = 2 * ks + half;
+            const bool second = kk >= SHU_NH;
+            const int w = second ? kk - 32 : kk;
+            const float2 t = tw[(w * x) & 63];
+            const float coef = (w == 0 || w == 32) ? 1.f : 2.f;
+            const float av = (second ? Zi : Zr)[y * SHU_NH + w];
+            const float bv = second ? -2.f * t.y : coef * t.x;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        float* op = p.out[4] + (long)n * p.obs[4] + (long)c * SHU_N * SHU_N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int yr = (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = op + yr * SHU_N + x;
+            *dst = p.accumulate ? *dst + acc[r] : acc[r];
+        }
     }
 }
 
