@@ -73,13 +73,19 @@ __device__ __forceinline__ float ufd_finish(const UfdParams& p, const UfdPlane& 
     return v;
 }
 
-template <int FH, int FW>
+// VEC4: the input rows are 16-byte aligned (W % 4 == 0, aligned base) and 0 <= px0 <= 4: the window is fetched as aligned
+// float4 (columns ox0-4 .. ox0+67, each float4 entirely inside the image or entirely padding) -- 630 loads per tile
+// instead of 2345 dword loads.
+template <int FH, int FW, bool VEC4>
 __global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
-    constexpr int TH = 32, TW = 64, IH = TH + FH - 1, IW = TW + FW - 1, PITCH = IW + 1;
+    constexpr int TH = 32, TW = 64, IH = TH + FH - 1, IW = TW + FW - 1;
+    constexpr int PITCH = VEC4 ? 72 : IW + 1;  // VEC4: 18 float4 per row, LDS column = ix - (ox0 - 4)
     constexpr int RPT = (IH + 3) / 4;          // window rows staged per thread (4 row groups x 64 columns)
     constexpr int NX = IH * (FW - 1);          // elements of the FW-1 extra window columns
+    constexpr int NV4 = IH * 18, V4PT = (NV4 + 255) / 256;
     static_assert(NX <= 256, "extra window columns must fit one pass");
-    __shared__ float tile[IH * PITCH];
+    static_assert(!VEC4 || (FW == 4 && FH == 4), "the float4 window assumes a 4x4 filter");
+    __shared__ __attribute__((aligned(16))) float tile[IH * PITCH];
     // taps: uniform addresses -> scalar loads; fr[ky][kx] multiplies x[oy + ky - py0][ox + kx - px0]
     float fr[FH * FW];
 #pragma unroll
@@ -97,34 +103,62 @@ __global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
     const int ixe = ox0 - p.px0 + xc, iye = iy0 + xr;
     const bool xok = xact && iye >= 0 && iye < p.H && ixe >= 0 && ixe < p.W;
     const long plane = (long)p.H * p.W;
-    float tvr[RPT + 1];
+    const int coff = VEC4 ? 4 - p.px0 : 0;           // LDS column of window column 0
+    float tvr[VEC4 ? 1 : RPT + 1];
+    float4 tv4[VEC4 ? V4PT : 1];
     // unconditional loads from clamped 32-bit byte offsets off the uniform plane base, masked afterwards
     auto load_tile = [&](int nc) __attribute__((always_inline)) {
-        int ix_i = ix0, rg_i = rg;
-        asm volatile("" : "+v"(ix_i), "+v"(rg_i));     // keep the per-load offsets / masks out of the loop-invariant set
         const char* pb = reinterpret_cast<const char*>(p.x + nc * plane);
-        const bool okx = ix_i >= 0 && ix_i < p.W;
+        if constexpr (VEC4) {
+            int t_i = tid;
+            asm volatile("" : "+v"(t_i));                  // keep the per-load offsets / masks out of the loop-invariant set
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = rg_i + 4 * k;
-            const int iy = iy0 + r;
-            const bool ok = okx && r < IH && iy >= 0 && iy < p.H;
-            const unsigned boff = ok ? (unsigned)(iy * p.W + ix_i) * 4u : 0u;
-            const float val = *reinterpret_cast<const float*>(pb + boff);
-            tvr[k] = ok ? val : 0.f;
+            for (int k = 0; k < V4PT; ++k) {
+                const int e = t_i + 256 * k;
+                const int r = e / 18, q = e - r * 18;
+                const int iy = iy0 + r, ix = ox0 - 4 + 4 * q;
+                const bool ok = e < NV4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
+                const unsigned boff = ok ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+                const float4 val = *reinterpret_cast<const float4*>(pb + boff);
+                tv4[k] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            int ix_i = ix0, rg_i = rg;
+            asm volatile("" : "+v"(ix_i), "+v"(rg_i));
+            const bool okx = ix_i >= 0 && ix_i < p.W;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = rg_i + 4 * k;
+                const int iy = iy0 + r;
+                const bool ok = okx && r < IH && iy >= 0 && iy < p.H;
+                const unsigned boff = ok ? (unsigned)(iy * p.W + ix_i) * 4u : 0u;
+                const float val = *reinterpret_cast<const float*>(pb + boff);
+                tvr[k] = ok ? val : 0.f;
+            }
+            const unsigned eoff = xok ? (unsigned)(iye * p.W + ixe) * 4u : 0u;
+            const float val = *reinterpret_cast<const float*>(pb + eoff);
+            tvr[RPT] = xok ? val : 0.f;
         }
-        const unsigned eoff = xok ? (unsigned)(iye * p.W + ixe) * 4u : 0u;
-        const float val = *reinterpret_cast<const float*>(pb + eoff);
-        tvr[RPT] = xok ? val : 0.f;
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (VEC4) {
+#pragma unroll
+            for (int k = 0; k < V4PT; ++k) {
+                const int e = tid + 256 * k;
+                if (e < NV4) reinterpret_cast<float4*>(tile)[e] = tv4[k];     // row r = e/18 at r*72 floats: contiguous in e
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                if (rg + 4 * k < IH) tile[(rg + 4 * k) * PITCH + tx] = tvr[k];
+            if (xact) tile[xr * PITCH + xc] = tvr[RPT];
+        }
     };
     int nc = blockIdx.z;
     if (nc < p.NC) load_tile(nc);
     for (; nc < p.NC; nc += gridDim.z) {
         const UfdPlane pl = ufd_plane(p, nc);
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-            if (rg + 4 * k < IH) tile[(rg + 4 * k) * PITCH + tx] = tvr[k];
-        if (xact) tile[xr * PITCH + xc] = tvr[RPT];
+        store_tile();
         __syncthreads();
         if (nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);      // next plane's window, in flight during the FIR
         const int ox = ox0 + tx;
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
 #pragma unroll
             for (int r = 0; r < 4 + FH - 1; ++r)
 #pragma unroll
-                for (int k = 0; k < FW; ++k) win[r][k] = tile[(ty + r) * PITCH + tx + k];
+                for (int k = 0; k < FW; ++k) win[r][k] = tile[(ty + r) * PITCH + tx + k + coff];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int oy = oy0 + ty + t;
@@ -343,7 +377,9 @@ static int ufd_launch(UfdParams& p, hipStream_t s) {
         const int tiles = shg_cdiv(p.OW, 64) * shg_cdiv(p.OH, 32);
         int gzs = 8192 / tiles; if (gzs < 1) gzs = 1; if (gzs > p.NC) gzs = p.NC;
         dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 32), gzs);
-        hipLaunchKernelGGL((fir_same_kernel<4, 4>), grid, dim3(256), 0, s, p);
+        const bool vec4 = p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && p.px0 >= 0 && p.px0 <= 4;
+        if (vec4) hipLaunchKernelGGL((fir_same_kernel<4, 4, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fir_same_kernel<4, 4, false>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 4), gz);
         hipLaunchKernelGGL(upfirdn_generic_kernel, grid, dim3(256), sizeof(float) * p.fh * p.fw, s, p);
