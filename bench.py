@@ -1,73 +1,97 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): SH-GAN generator forward, images/s at 512x512 batch 16 per GPU.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic masked inputs already resident in
-HBM: Generator.forward (mapping -> SHU encoder -> co-modulated synthesis, noise_mode='random' as in the
-reference eval loop) + the uint8 composite.  Weights: the reference's random initialisers (seeded);
-data: synthetic.  Multi-GPU = batch sharding, one process per GPU, no collective on the data path
-(weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+N > 1 without a launcher: this script spawns its own N ranks (torch.multiprocessing.spawn, one per GPU, as the
+reference's main.py:83-89 does); under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` it
+joins the ranks the launcher started (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
 
-Rank 0 prints ONE JSON line with `roofline` (the dominant kernel class, conv_mfma: algorithmic flops /
-HIP-event time measured live over the timed steps, vs the dense fp32-MFMA peak of
-/opt/skills/guides/MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle timed on this host on a
-bounded sample -- a reported baseline, not the target)."""
+One "step" = one pass of the hot path over one batch of synthetic masked inputs already resident in HBM:
+Generator.forward (mapping -> SHU encoder -> co-modulated synthesis, noise_mode='random' as in the reference eval
+loop) + the uint8 composite.  Weights: the reference's random initialisers, seeded identically on every rank
+(shgan_amd.configs.seeded_init_); data: synthetic.  Multi-GPU = batch sharding, one process per GPU, no collective on
+the data path (weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+The headline loop runs WITHOUT instrumentation.  A second, untimed pass then brackets every kernel launch with HIP
+events on the launch stream (kernels.KernelTimer) and rank 0 prints ONE JSON line with
+  roofline      the dominant kernel (conv_wino_kernel): flops the matrix cores EXECUTE (16/36 of the direct form for
+                Winograd F(2x2,3x3)) / HIP-event time / dense fp32-MFMA peak; the direct-form ("algorithmic") rate is
+                reported beside it under its own key, per convolution class;
+  hbm           the HBM-bound kernel classes: algorithmic bytes / HIP-event time / 8 TB/s;
+  cpu_baseline  the CPU oracle timed on this host on a bounded sample (a reported baseline, not the target)."""
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # dense fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_HBM_GBS = 8000.0
-GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MAC), whole forward
-CONV_GFLOP_PER_IMAGE = {256: 180.3, 512: 238.3}   # the 3x3 convolutions alone
+PEAK_HBM_GBS = 8000.0              # HBM3E spec; 6.3 TB/s is what a float4 copy reaches (same guide)
+GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MAC), whole forward, direct form
+WINO_EXECUTED = 16.0 / 36.0                        # F(2x2,3x3): multiplies per 2x2 outputs vs the direct form
 
 
-def pmc_traffic(resolution, batch):
-    """HBM bytes per convolution launch (conv_wino_kernel + conv_mfma_kernel, launch-weighted) from the committed PMC
-    summary (tools/gpu_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the process, so the number is
-    attached from profiles/ when it matches the workload."""
+def pmc_traffic(resolution, batch, kernel='conv_wino_kernel'):
+    """HBM bytes per launch of ``kernel`` from the committed PMC summary (tools/gpu_traffic.sh: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside the process: the number is a constant of the committed profile, attached when the profile
+    matches the workload -- ``traffic_source`` in the JSON line says so."""
     path = os.path.join(ROOT, 'profiles', f'traffic_{resolution}x{batch}.json')
     if not os.path.exists(path):
-        return None
-    js = json.load(open(path))
-    tot = n = 0.0
-    for k in ('conv_wino_kernel', 'conv_mfma_kernel'):
-        d = js.get(k)
-        if d:
-            tot += (d['read_bytes_per_launch'] + d['write_bytes_per_launch']) * d['launches']
-            n += d['launches']
-    return round(tot / n / 1e9, 4) if n else None
+        return None, None
+    d = json.load(open(path)).get(kernel)
+    if not d:
+        return None, None
+    return round((d['read_bytes_per_launch'] + d['write_bytes_per_launch']) / 1e9, 4), os.path.relpath(path, ROOT)
 
 
-def cpu_baseline(resolution, n_images, seed):
-    """Time the CPU oracle (torch fp32 CPU ops, all host threads) on a bounded sample."""
+def cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(resolution, bench_batch, n_images, forwards, noise_mode, seed):
+    """the CPU restatement (oracle, torch CPU fp32) on this host: 1 warm-up + ``forwards`` timed forwards
+    + composite with the bench's noise mode.  The batch is truncated from the bench batch to ``n_images`` so that the
+    default run stays within ~30 s of CPU work (a 512x16 forward alone takes ~18 s on 32 threads); stated in ``sample``."""
     import torch
     from oracle import shgan_oracle as orc
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs
     # more threads than ~32 make torch's CPU grouped convolutions *slower* on a 256-core host
     # (measured: 16 thr 0.94, 32 thr 0.97, 64 thr 0.59, 256 thr 0.04 img/s at 512x512), so cap at 32
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
-    sd = orc.init_state_dict(resolution, seed=seed)
+    G = configs.seeded_init_(configs.build_generator(resolution), seed=seed)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    del G
     x, z, _, _ = orc.synthetic_batch(n_images, resolution, 512, seed=seed + 1)
+    times = []
     with torch.no_grad():
-        orc.generator_forward(sd, x[:1], z[:1], resolution, noise_mode='none')      # page-in / warm-up
-        t0 = time.perf_counter()
-        orc.run_generator(sd, x, z, resolution, noise_mode='const')
-        dt = time.perf_counter() - t0
-    return dict(value=round(n_images / dt, 4), unit='images/s', cores=threads, kind='port',
-                sample=f'{n_images} images {resolution}x{resolution}, 1 forward + composite after 1-image warm-up, '
-                       f'oracle/shgan_oracle.py (torch CPU fp32), {dt:.1f} s')
+        orc.run_generator(sd, x[:1], z[:1], resolution, noise_mode=noise_mode)      # page-in / warm-up
+        for _ in range(forwards):
+            t0 = time.perf_counter()
+            orc.run_generator(sd, x, z, resolution, noise_mode=noise_mode)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return dict(value=round(n_images / best, 4), unit='images/s', cores=threads, kind='port', cpu=cpu_model(),
+                host_cores=os.cpu_count(),
+                sample=f'{forwards} timed forwards + composite (best of; all: {[round(t, 2) for t in times]} s) after a 1-image '
+                       f'warm-up, batch truncated {bench_batch} -> {n_images} images {resolution}x{resolution}, noise_mode='
+                       f'{noise_mode!r}, oracle/shgan_oracle.py (torch CPU fp32, {threads} threads)')
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -77,101 +101,169 @@ def main():
     ap.add_argument('--noise-mode', default='random')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
-    a = ap.parse_args()
-    res = a.resolution
-    batch = a.batch or {256: 32, 512: 16}.get(res, 8)
+    ap.add_argument('--cpu-forwards', type=int, default=3)
+    ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
+    return ap.parse_args()
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def worker(local_rank, a, spawned_world=None, port=None):
+    """One rank.  ``spawned_world`` is set when this process was started by bench.py's own spawn."""
     import torch
     import torch.distributed as dist
     import shgan_amd  # noqa: F401
-    from shgan_amd import eval_harness, kernels
-    from test_host_logic import build_generator
-    from oracle import shgan_oracle as orc      # weights only (the reference's initialisers, seeded)
+    from shgan_amd import configs, eval_harness, kernels
 
+    if spawned_world is not None:
+        os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(spawned_world),
+                          MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if world != a.gpus:
-        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    res = a.resolution
+    batch = a.batch or {256: 32, 512: 16}.get(res, 8)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py needs a HIP device: the product has no CPU path')
+    oversub = ndev < world               # fewer GPUs than ranks (launch-path smoke on a 1-GPU box): ranks share devices
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device('cuda', local % ndev)
     use_dist = world > 1 or 'RANK' in os.environ          # under torch.distributed.run even a 1-rank job joins RCCL
+    backend = None
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = 'gloo' if oversub else 'nccl'            # RCCL needs one device per rank
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
-    G = build_generator(res)
-    G.load_state_dict(orc.init_state_dict(res, seed=0), strict=True)   # every rank initialises identically: no broadcast needed
+    def barrier():
+        if use_dist:
+            if backend == 'nccl':
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
+
+    G = configs.build_generator(res)
+    configs.seeded_init_(G, seed=0)        # every rank initialises identically: no weight broadcast needed
     G = G.eval().requires_grad_(False).to(dev)
     # rank r holds its own shard of the global batch (rank-strided ids, ds_sampler.py:67)
-    x, z, _, _ = eval_harness.synthetic_batch(batch, res, G.z_dim, seed=1000 + rank, device=dev, masks='bernoulli')
+    ids = [rank + world * k for k in range(batch)]
+    x, z, _, _ = eval_harness.synthetic_items(ids, res, G.z_dim, seed=1000, device=dev)
+    torch.manual_seed(world + rank)        # per-rank noise stream (shgan_default.py:165-167)
 
     def step():
         return eval_harness.run_generator(G, x, z, noise_mode=a.noise_mode)
 
     for _ in range(a.warmup):
         step()
-    timer = kernels.KernelTimer()
-    kernels.set_timer(timer)
-    if use_dist:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
-    kernels.set_timer(None)
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
 
+    # ---- second pass (not part of the headline): per-kernel-class HIP-event times
+    tsum = {}
+    psteps = max(0, a.profile_steps)
+    if rank == 0 and psteps:
+        timer = kernels.KernelTimer()
+        kernels.set_timer(timer)
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        kernels.set_timer(None)
+        tsum = timer.summary()
+    barrier()
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         ips = world * batch * a.steps / dt
-        tsum = timer.summary()
-        zero = dict(calls=0, ms=0.0, work=0.0)
-        sd, sw = tsum.get('conv_mfma', zero), tsum.get('conv_wino', zero)     # direct implicit-GEMM / Winograd F(2x2,3x3)
-        conv_ms = sd['ms'] + sw['ms']
-        conv_work = sd['work'] + sw['work']                 # algorithmic (direct-form) flops: 2*N*O*I*taps*pixels
-        issued = sd['work'] + sw['work'] * 16.0 / 36.0      # flops the MFMA units actually execute
-        ach = conv_work / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        iss = issued / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
-        def cls(d):
-            return {'launches_per_step': d['calls'] // max(a.steps, 1), 'ms_per_step': round(d['ms'] / max(a.steps, 1), 3),
-                    'algorithmic_tflops': round(d['work'] / (d['ms'] * 1e-3) / 1e12, 2) if d['ms'] > 0 else None}
+        def cls_conv(name, executed_factor):
+            d = tsum.get(name)
+            if not d or d['ms'] <= 0:
+                return None
+            sec = d['ms'] * 1e-3
+            return {'launches_per_step': d['calls'] // psteps, 'ms_per_step': round(d['ms'] / psteps, 3),
+                    'avg_launch_us': round(d['ms'] / d['calls'] * 1e3, 1),
+                    'executed_tflops': round(d['work'] * executed_factor / sec / 1e12, 2),
+                    'frac_of_fp32_mfma_peak': round(d['work'] * executed_factor / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'direct_form_tflops': round(d['work'] / sec / 1e12, 2)}
+
+        def cls_hbm(name):
+            d = tsum.get(name)
+            if not d or d['ms'] <= 0:
+                return None
+            gbs = d['work'] / (d['ms'] * 1e-3) / 1e9
+            return {'launches_per_step': d['calls'] // psteps, 'ms_per_step': round(d['ms'] / psteps, 3),
+                    'algorithmic_GB_per_step': round(d['work'] / psteps / 1e9, 3), 'achieved_GBps': round(gbs, 1),
+                    'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)}
+
+        conv = {k: v for k, v in (('conv_wino', cls_conv('conv_wino', WINO_EXECUTED)),
+                                  ('conv_mfma_s2', cls_conv('conv_mfma_s2', 1.0)),
+                                  ('conv_mfma_up', cls_conv('conv_mfma_up', 1.0)),
+                                  ('conv_mfma_s1', cls_conv('conv_mfma_s1', 1.0)),
+                                  ('conv_mfma_1x1', cls_conv('conv_mfma_1x1', 1.0))) if v}
+        hbm = {k: v for k, v in ((n, cls_hbm(n)) for n in ('upfirdn2d', 'fir_up_planar', 'torgb', 'fromrgb', 'shu', 'composite_u8'))
+               if v}
+        conv_ms = sum(tsum[k]['ms'] for k in tsum if k.startswith('conv_'))
+        conv_exec = sum(tsum[k]['work'] * (WINO_EXECUTED if k == 'conv_wino' else 1.0) for k in tsum if k.startswith('conv_'))
+        conv_alg = sum(tsum[k]['work'] for k in tsum if k.startswith('conv_'))
+        dom = conv.get('conv_wino')
+        traffic, traffic_src = pmc_traffic(res, batch)
+        roof = {'bound': 'mfma', 'kernel': 'conv_wino_kernel (Winograd F(2x2,3x3) 3x3 stride-1 layers, the largest share of a step)',
+                'achieved': dom['executed_tflops'] if dom else None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': dom['frac_of_fp32_mfma_peak'] if dom else None,
+                'definition': 'flops executed on the matrix cores (16/36 of the direct-form flops) / HIP-event time of the '
+                              'launches in the instrumented pass / dense fp32 MFMA peak',
+                'avg_launch_us': dom['avg_launch_us'] if dom else None,
+                'direct_form_tflops': dom['direct_form_tflops'] if dom else None,
+                'traffic': traffic, 'traffic_unit': 'GB per launch (HBM read+write, PMC FETCH_SIZE*2 + WRITE_SIZE)',
+                'traffic_source': f'constant of the committed profile {traffic_src}, not measured in this run' if traffic_src else None,
+                'classes': conv,
+                'all_conv': {'ms_per_step': round(conv_ms / psteps, 3) if psteps else None,
+                             'executed_tflops': round(conv_exec / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                             'frac_of_fp32_mfma_peak': round(conv_exec / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if conv_ms else None,
+                             'direct_form_tflops': round(conv_alg / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None},
+                'whole_step': {'executed_gflop_per_step': round(conv_exec / psteps / 1e9, 1) if psteps else None,
+                               'executed_tflops_over_wall': round(conv_exec / psteps / (ms * 1e-3) / 1e12, 2) if psteps else None,
+                               'frac_of_fp32_mfma_peak': round(conv_exec / psteps / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if psteps else None,
+                               'direct_form_gflop_per_image': GFLOP_PER_IMAGE.get(res)}}
         line = {
             'metric': 'generator images/sec', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU',
                        'resolution': res, 'batch_per_gpu': batch, 'global_batch': batch * world, 'noise_mode': a.noise_mode,
-                       'parallelism': f'batch-shard x{world}'},
-            # achieved = ALGORITHMIC (direct-form) convolution flops / HIP-event time of every convolution launch.  The
-            # stride-1 3x3 layers run as Winograd F(2x2,3x3) (16 instead of 36 multiplies per 2x2 outputs, exact fp32
-            # MFMA), so `achieved` can exceed what the matrix cores execute: `mfma_issued` is the executed rate.
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_wino_kernel + conv_mfma_kernel (every 3x3/1x1 convolution launch)',
-                         'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'mfma_issued': round(iss, 3), 'frac_mfma_issued': round(iss / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'traffic': pmc_traffic(res, batch),
-                         'traffic_unit': 'GB per launch (HBM read+write, PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/traffic_*.json)',
-                         'launches_per_step': (sd['calls'] + sw['calls']) // max(a.steps, 1),
-                         'kernel_ms_per_step': round(conv_ms / max(a.steps, 1), 3),
-                         'gflop_per_step': round(conv_work / max(a.steps, 1) / 1e9, 1),
-                         'classes': {'conv_wino': cls(sw), 'conv_mfma': cls(sd)},
-                         'whole_forward_frac_of_fp32_mfma_peak': round(
-                             ips / world * GFLOP_PER_IMAGE.get(res, 0) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                       'parallelism': f'batch-shard x{world}', 'launcher': 'self-spawn' if spawned_world else
+                       ('torch.distributed.run' if 'RANK' in os.environ and spawned_world is None and use_dist else 'single process'),
+                       'collective_backend': backend, 'ranks_share_devices': oversub},
+            'timing': 'headline loop uninstrumented; roofline/hbm from a separate instrumented pass of '
+                      f'{psteps} steps (HIP events on the launch stream)',
+            'roofline': roof,
+            'hbm': {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'classes': hbm},
         }
         if not a.no_cpu_baseline and world == 1:
             try:
-                line['cpu_baseline'] = cpu_baseline(res, a.cpu_images, seed=0)
+                line['cpu_baseline'] = cpu_baseline(res, batch, a.cpu_images, a.cpu_forwards, a.noise_mode, seed=0)
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 line['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
                                         'sample': f'failed: {e!r}'}
@@ -180,6 +272,21 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if 'RANK' in os.environ:                         # started by torch.distributed.run (or any external launcher)
+        world = int(os.environ.get('WORLD_SIZE', 1))
+        if world != a.gpus:
+            raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+        worker(int(os.environ.get('LOCAL_RANK', 0)), a)
+    elif a.gpus == 1:
+        worker(0, a)
+    else:                                            # own launcher: one process per GPU
+        import torch.multiprocessing as mp
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        mp.spawn(worker, args=(a, a.gpus, free_port()), nprocs=a.gpus, join=True)
 
 
 if __name__ == '__main__':

@@ -141,6 +141,10 @@ int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int
  * real [N,3,H,W] in [-1,1], mask [N,H,W] in {0,1} -> x [N,4,H,W]. */
 int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N, int H, int W, void* stream);
 
+/* ---- next row N3 (training-side critic, forward only): minibatch_std_layer (stylegan.py:686-704).
+ * x [N,C,H,W] -> y [N,C+F,H,W]; N % G == 0, C % F == 0; stat [N/G * F] is caller-owned scratch. */
+int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, int H, int W, int G, int F, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

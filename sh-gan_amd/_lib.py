@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -60,9 +60,16 @@ _SIGS = {
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_assemble_input_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'shg_minibatch_std_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }
 
 _lib = None
+
+
+def use_library(path):
+    """Point the loader at another build of the same ABI (tools/ use the -DSHG_ABLATE timing-study library)."""
+    global _lib, LIB_PATH
+    _lib, LIB_PATH = None, path
 
 
 class ShgError(RuntimeError):

@@ -23,35 +23,43 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def _digest():
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+
+
+def _digest(extra=()):
+    """sha256 over every kernel source, the public C header (an ABI struct edit must trigger a rebuild) and the flags."""
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        with open(os.path.join(CSRC, name), 'rb') as fh:
-            h.update(name.encode())
-            h.update(fh.read())
-    h.update(' '.join(FLAGS).encode())
+    for d in (CSRC, INCLUDE):
+        for name in sorted(os.listdir(d)):
+            with open(os.path.join(d, name), 'rb') as fh:
+                h.update(name.encode())
+                h.update(fh.read())
+    h.update(' '.join(list(FLAGS) + list(extra)).encode())
     return h.hexdigest()
 
 
-def lib_path():
-    return os.path.join(LIBDIR, LIBNAME)
+def lib_path(ablate=False):
+    return os.path.join(LIBDIR, 'libshgan_hip_ablate.so' if ablate else LIBNAME)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablate=False):
+    """``ablate=True`` builds the timing-study variant (-DSHG_ABLATE: the SHG_*_DBG / SHG_CONV_VARIANT environment switches
+    that make kernels skip work) as a SEPARATE library for tools/; the product library has no such switches."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, '.build_digest')
-    dig = _digest()
-    if not force and os.path.exists(lib_path()) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    extra = ['-DSHG_ABLATE'] if ablate else []
+    stamp = os.path.join(LIBDIR, '.build_digest_ablate' if ablate else '.build_digest')
+    dig = _digest(extra)
+    if not force and os.path.exists(lib_path(ablate)) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         if verbose:
-            print(f'[build] {LIBNAME} up to date')
-        return lib_path()
+            print(f'[build] {os.path.basename(lib_path(ablate))} up to date')
+        return lib_path(ablate)
     hipcc = _hipcc()
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        obj = os.path.join(LIBDIR, src.replace('.hip', '.abl.o' if ablate else '.o'))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print('[build]', ' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -62,7 +70,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed on {src}')
         if verbose and out.strip():
             print(out.decode(errors='replace'))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path()] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path(ablate)] + objs
     if verbose:
         print('[build]', ' '.join(cmd))
     subprocess.check_call(cmd)
@@ -70,8 +78,8 @@ def build(force=False, verbose=True):
         os.remove(obj)
     with open(stamp, 'w') as fh:
         fh.write(dig)
-    return lib_path()
+    return lib_path(ablate)
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, ablate='--ablate' in sys.argv)

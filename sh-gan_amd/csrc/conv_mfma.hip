@@ -88,8 +88,14 @@ struct ConvParams {
     int tail_first, tail_ks, tail_ips, fix;
     float* tail_ws;
     int raw_reduce;          // split-K tail only sums the slices (transposed conv: its epilogue lives in the FIR kernel)
-    int dbg;                 // ablation bits for kernel timing studies (SHG_CONV_DBG, default 0): 1 skip W loads, 2 skip X loads,
-                             // 4 skip LDS stores, 8 skip barriers, 16 skip epilogue, 32 no tail split
+    // Ablation bits for kernel timing studies -- only in the -DSHG_ABLATE build used by tools/ (env SHG_CONV_DBG: 1 skip W
+    // loads, 2 skip X loads, 4 skip LDS stores, 8 skip barriers, 16 skip epilogue, 32 no tail split).  The product build
+    // has no such switch: `dbg` is the constant 0 there and every `p.dbg & ...` branch folds away.
+#ifdef SHG_ABLATE
+    int dbg;
+#else
+    static constexpr int dbg = 0;
+#endif
 };
 
 // Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}).  Used for the MFMA
@@ -630,8 +636,12 @@ static int conv_ksplit(int grid, int chunks, bool allow) {
 
 // smallest phase-grid width (W+1) that goes to the 8-wave double-buffered transposed-conv tiles (SHG_UP_MIN)
 static int conv_up_min() {
+#ifdef SHG_ABLATE
     static const int v = getenv("SHG_UP_MIN") ? atoi(getenv("SHG_UP_MIN")) : 16;
     return v;
+#else
+    return 16;
+#endif
 }
 
 static int conv_cu_count() {
@@ -716,7 +726,11 @@ static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, 
     // SHG_CONV_VARIANT (tuning knob, bit flags): 1 = force the single-buffer 4-wave kernels; 2 / 4 / 8 = try the 8-wave
     // double-buffered variants for 64-channel layers / stride-2 (128 px) / stride-2 (256 px); 16 = transposed conv back on 8 waves;
     // 32 = stride-2 back on 8 waves
+#ifdef SHG_ABLATE
     static const int variant = getenv("SHG_CONV_VARIANT") ? atoi(getenv("SHG_CONV_VARIANT")) : 0;
+#else
+    constexpr int variant = 0;
+#endif
     if (up) {
         // all-phase transposed conv: large grids use 8-wave double-buffered tiles (128 ch x 128 px, or 64 ch x 256 px),
         // small ones the 4-wave 64 ch x 128 px tile (+ split-K)
@@ -778,7 +792,9 @@ static int conv_fill(ConvParams& p, const float* x, const float* wt, float* y, i
     p.wgroups = wgroups < 1 ? 1 : wgroups; p.wstride = wstride;
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.out_mode = out_mode; p.ksplit = 1;
+#ifdef SHG_ABLATE
     { const char* d = getenv("SHG_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
+#endif
     if (mode == 2) {
         // transposed stride 2 (conv2d_resample.py:130-137): Y = 2u+a, X = 2v+b over u in [0,H], v in [0,W]
         p.OHt = 2 * H + 1; p.OWt = 2 * W + 1; p.OHp = H + 1; p.OWp = W + 1; p.S = 1;

@@ -49,7 +49,13 @@ struct WinoParams {
     float noise_strength;
     int act;
     float alpha, gain, clamp;
-    int dbg;                 // timing studies (SHG_WINO_DBG): 1 skip weight DMA, 2 skip patch DMA, 4 skip transform, 16 skip epilogue
+    // timing studies, -DSHG_ABLATE build only (env SHG_WINO_DBG: 1 skip weight loads, 2 skip window DMA, 4 skip transform,
+    // 16 skip epilogue); the product build folds every `p.dbg & ...` branch away
+#ifdef SHG_ABLATE
+    int dbg;
+#else
+    static constexpr int dbg = 0;
+#endif
 };
 
 namespace wino {
@@ -414,7 +420,9 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino::KC);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+#ifdef SHG_ABLATE
     { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }
+#endif
     if (wide) hipLaunchKernelGGL((conv_wino_kernel<4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wino_kernel<8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();

@@ -315,3 +315,61 @@ extern "C" int shg_assemble_input_f32(const float* real, const float* mask, floa
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// minibatch_std_layer (stylegan.py:686-704): x [N,C,H,W] -> y [N,C+F,H,W].  The batch is split into N/G groups of G
+// samples (sample of group-slot g and group n = g*(N/G) + n), the channels into F sets of c = C/F; the statistic of
+// (n, f) is the mean over (c, H, W) of the standard deviation over the G samples; it is appended as channel C+f of
+// every sample of group n.  Launch 1: one workgroup per (n, f) reduces; launch 2 copies x and broadcasts the statistic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mbstd_stat_kernel(const float* x, float* stat, int NG, int G, int F, int c, int HW, int C) {
+    const int n = blockIdx.x / F, f = blockIdx.x % F;
+    const int per = c * HW;
+    const long sample = (long)C * HW;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const float* px = x + (long)n * sample + (long)f * per + e;     // + g*NG*sample
+        float mean = 0.f;
+        for (int g = 0; g < G; ++g) mean += px[(long)g * NG * sample];
+        mean /= (float)G;
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) { const float d = px[(long)g * NG * sample] - mean; var += d * d; }
+        acc += sqrtf(var / (float)G + 1e-8f);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stat[n * F + f] = red[0] / (float)per;
+}
+
+__global__ __launch_bounds__(256) void mbstd_write_kernel(const float* x, const float* stat, float* y, int NG, int F, int C, int HW, long total) {
+    const long stride = (long)gridDim.x * 256;
+    const int CF = C + F;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const long nc = e / HW;
+        const int pix = (int)(e - nc * HW);
+        const int s = (int)(nc / CF), ch = (int)(nc - (long)s * CF);
+        y[e] = ch < C ? x[((long)s * C + ch) * HW + pix] : stat[(s % NG) * F + (ch - C)];
+    }
+}
+
+extern "C" int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, int H, int W, int G, int F, void* stream) {
+    SHG_CHECK_ARG(x && y && stat, "minibatch_std: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1 && H >= 1 && W >= 1 && G >= 1 && F >= 1, "minibatch_std: bad shape");
+    SHG_CHECK_ARG(N % G == 0, "minibatch_std: batch %d is not a multiple of the group size %d", N, G);
+    SHG_CHECK_ARG(C % F == 0, "minibatch_std: %d channels do not split into %d sets", C, F);
+    const int NG = N / G, HW = H * W;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mbstd_stat_kernel, dim3(NG * F), dim3(256), 0, s, x, stat, NG, G, F, C / F, HW, C);
+    SHG_CHECK_LAUNCH();
+    const long total = (long)N * (C + F) * HW;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(mbstd_write_kernel, dim3(grid), dim3(256), 0, s, x, stat, y, NG, F, C, HW, total);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

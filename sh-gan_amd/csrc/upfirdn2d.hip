@@ -34,7 +34,12 @@ struct UfdParams {
     int act;                 // 0 none, 1 lrelu_agc
     float alpha, act_gain, clamp;
     int has_epilogue;
-    int dbg;                 // timing studies (SHG_FIR_DBG): 1 skip window loads, 2 skip FIR math, 4 skip stores
+    // timing studies, -DSHG_ABLATE build only (env SHG_FIR_DBG: 1 skip window loads, 2 skip FIR math, 4 skip stores)
+#ifdef SHG_ABLATE
+    int dbg;
+#else
+    static constexpr int dbg = 0;
+#endif
 };
 
 __device__ __forceinline__ float ufd_epilogue(const UfdParams& p, float v, int nc, int oy, int ox) {
@@ -460,7 +465,9 @@ extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, 
     p.scale = scale; p.bias = bias; p.noise = noise; p.residual = residual;
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
+#ifdef SHG_ABLATE
     { const char* d = getenv("SHG_FIR_DBG"); p.dbg = d ? atoi(d) : 0; }
+#endif
     // each workgroup walks several (n,c) planes with the next window prefetched; ~8k workgroups keep 256 CUs busy
     const int TV = W >= 96 ? 128 : (W >= 48 ? 64 : 32), TU = 1024 / TV;
     const int tiles = shg_cdiv(W, TV) * shg_cdiv(H, TU);

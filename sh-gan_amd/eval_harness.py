@@ -1,7 +1,8 @@
 """Eval-loop caller of the generator: the body of
 lib/experiments/shgan_default.py:257-289 -- input assembly, generator call, uint8 composite -- and the
 batch-sharded multi-GPU loop (one process per GPU, rank-strided samples, no collective on the data
-path; an optional RCCL all-gather returns the uint8 results in dataset order)."""
+path; an optional all-gather returns the uint8 results in dataset order: RCCL over xGMI on GPUs,
+gloo on the CPU for the world-size-2 tests)."""
 import numpy as np
 import torch
 
@@ -42,30 +43,61 @@ def synthetic_batch(n, resolution, z_dim=512, seed=0, device='cuda', masks='free
     return assemble_input(real, m).to(device), z.to(device), real_u8, mask
 
 
+def synthetic_items(ids, resolution, z_dim=512, seed=0, device='cuda'):
+    """Inputs of the dataset items ``ids`` of a synthetic eval set, built ON ``device`` in one batch (no per-image host
+    work or H2D copy): item i is drawn from its own generator seeded with (seed, i), so it is the same image whichever
+    rank / batch position processes it.  -> x [B,4,R,R], z [B,z_dim], real_u8 [B,3,R,R], mask [B,1,R,R] (all on device)."""
+    dev = torch.device(device)
+    b = len(ids)
+    real_u8 = torch.empty((b, 3, resolution, resolution), dtype=torch.uint8, device=dev)
+    mask = torch.empty((b, 1, resolution, resolution), dtype=torch.float32, device=dev)
+    z = torch.empty((b, z_dim), dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev)
+    for k, i in enumerate(ids):
+        g.manual_seed(int(seed) * 1000003 + int(i))
+        real_u8[k].random_(0, 256, generator=g)
+        mask[k].bernoulli_(0.7, generator=g)
+        z[k].normal_(generator=g)
+    real = real_u8.to(torch.float32).div_(127.5).sub_(1.0)
+    return assemble_input(real, mask), z, real_u8, mask
+
+
+def shard_ids(n_items, rank, world):
+    """Sample ids of rank ``rank``: ``DistributedSampler(shuffle=False, extend=True)`` = indices[rank::world] after the
+    extend-pad with leading indices (ds_sampler.py:58-68)."""
+    return list(iter(DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)))
+
+
 def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, gather=True, device='cuda',
-                 noise_mode='const', masks='bernoulli'):
-    """Batch-sharded evaluation over a synthetic dataset of ``n_items`` images: rank r processes the
-    sample ids ``DistributedSampler(extend=True)`` gives it, in batches of ``batch_size``; with
-    ``gather`` the uint8 outputs are all-gathered (RCCL) and re-interleaved to dataset order.
-    Item i's inputs depend only on (seed, i), so any world size produces the same per-item results."""
+                 noise_mode='const', step_fn=None, z_dim=None):
+    """Batch-sharded evaluation over a synthetic dataset of ``n_items`` images (BASELINE config 4): rank r processes
+    the sample ids ``shard_ids`` gives it, in batches of ``batch_size`` built on the device; with ``gather`` the uint8
+    outputs are all-gathered (one ``all_gather_into_tensor`` per run: RCCL on GPUs, gloo on CPU tensors) and
+    re-interleaved to dataset order (eva_base.py:196-230).  ``step_fn(x, z) -> uint8 [B,3,R,R]`` replaces the generator
+    step (the CPU world-size-2 test injects a stand-in; the product path is ``run_generator(G, ...)``).
+    With ``noise_mode='random'`` the torch generator is seeded per rank as the reference does (seed*world + rank,
+    shgan_default.py:165-167)."""
     import torch.distributed as dist
-    ids = list(iter(DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)))
+    if step_fn is None:
+        def step_fn(x, z):
+            return run_generator(G, x, z, noise_mode=noise_mode)
+    if z_dim is None:
+        z_dim = G.z_dim
+    if noise_mode == 'random':
+        torch.manual_seed(seed * world + rank)
+    ids = shard_ids(n_items, rank, world)
     outs = []
     for b0 in range(0, len(ids), batch_size):
-        chunk = ids[b0:b0 + batch_size]
-        xs, zs = [], []
-        for i in chunk:
-            x, z, _, _ = synthetic_batch(1, resolution, G.z_dim, seed=seed * 1000003 + i, device=device, masks=masks)
-            xs.append(x)
-            zs.append(z)
-        outs.append(run_generator(G, torch.cat(xs), torch.cat(zs), noise_mode=noise_mode))
+        x, z, _, _ = synthetic_items(ids[b0:b0 + batch_size], resolution, z_dim, seed=seed, device=device)
+        outs.append(step_fn(x, z))
     local = torch.cat(outs)
     if not gather or world == 1:
         return ids, local
-    full = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, local)
-    per_rank_ids = [list(iter(DistributedSampler(list(range(n_items)), num_replicas=world, rank=r, shuffle=False, extend=True)))
-                    for r in range(world)]
+    # concatenated-along-dim-0 form: the one layout both RCCL and gloo accept for all_gather_into_tensor
+    full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous())
+    full = full.view((world,) + tuple(local.shape))
+    per_rank_ids = [shard_ids(n_items, r, world) for r in range(world)]
     order = zipzap_arrange(per_rank_ids)[:n_items]
     merged = zipzap_arrange([full[r].cpu().numpy() for r in range(world)])[:n_items]
     return order, merged

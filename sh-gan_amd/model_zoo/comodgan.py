@@ -57,6 +57,8 @@ class encoder_epilogue(discrim_epilogue):
     def forward(self, x, img=None, cmap=None):
         if self.fromrgb is not None:
             x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+        if self.mbstd is not None:
+            x = self.mbstd(x)
         feat = self.conv(x)
         x = self.fc(feat.flatten(1))
         if self.out is not None:

@@ -103,8 +103,26 @@ class heterogeneous_filter(nn.Module):
         y = kernels.conv2d(x.reshape(n, c, (h * w) // 32, 32), self.prepped(), mode=kernels.MODE_SAME, pad=0)
         return y.reshape(n, -1, h, w)
 
+    def cweight(self, h, w, device):
+        """Band-weight table for an [h, w] half spectrum, built once per geometry (shgan.py:145-155)."""
+        key = (h, w, str(device))
+        if getattr(self, '_cw_key', None) != key:
+            self.__dict__['_cw_val'] = make_cweight(self.freedom, (h, w), self.type, device=device)
+            self.__dict__['_cw_key'] = key
+        return self.__dict__['_cw_val']
+
     def forward(self, x):
-        raise NotImplementedError('use SHU.forward: the band sum is fused with the Gaussian split / irFFT2 kernel')
+        """Standalone form (shgan.py:143-160): y = sum_k conv1x1(x, W)[:, :, k] * cw[k].  SHU.forward does not come through
+        here -- it fuses this band sum with the Gaussian split and the inverse FFTs in one kernel."""
+        n, c, h, w = x.shape
+        y = self.band_conv(x).view(n, self.out_channels, -1, h, w)
+        cw = self.cweight(h, w, x.device)
+        out = None
+        for k in range(cw.shape[0]):     # plain fma launches: a cold path kept for drop-in completeness
+            term = y[:, :, k].contiguous()
+            wk = cw[k].expand_as(term).contiguous()
+            out = kernels.fma(term, wk, out if out is not None else torch.zeros_like(term))
+        return out
 
 
 class gaussian_heatmap_2d(object):

@@ -115,6 +115,7 @@ class dense(nn.Module):
         self.bias = nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
         self.weight_gain = lr_multi / np.sqrt(in_features)
         self.bias_gain = lr_multi
+        self.lr_multi, self.bias_init = lr_multi, bias_init
         self.repr = 'dense({}, {}, bias={}, act={}, lr_multi={})'.format(in_features, out_features, bias, activation, lr_multi)
 
     def forward(self, x, out=None):
@@ -122,7 +123,7 @@ class dense(nn.Module):
         b = self.bias.detach() if self.bias is not None else None
         if ak is None:   # non-fusable activation object
             return self.activation(kernels.dense(x, self.weight.detach(), b, wgain=self.weight_gain, bgain=self.bias_gain))
-        return kernels.dense(x, self.weight.detach(), b, wgain=self.weight_gain, bgain=self.bias_gain, act=ak['act'], out=out)
+        return kernels.dense(x, self.weight.detach(), b, wgain=self.weight_gain, bgain=self.bias_gain, out=out, **ak)
 
     def __repr__(self):
         return self.repr
@@ -214,7 +215,7 @@ class conv2d_layer(nn.Module):
             if self.down == 1:
                 if k == 1 and self.weight.shape[1] <= 8 and (x.shape[2] * x.shape[3]) % 4 == 0:
                     return kernels.conv1x1_thin_in(x, self.weight.detach().reshape(self.weight.shape[0], -1), b,
-                                                   wgain=self.weight_gain, act=ak['act'], gain=gain)
+                                                   wgain=self.weight_gain, **ak)
                 return kernels.conv2d(x, self.prepped(), mode=kernels.MODE_SAME, pad=self.padding, bias=b, **ak)
             # low-pass with the resample filter, then the stride-2 convolution (conv2d_resample.py:116-120)
             f = self.resample_filter
@@ -509,20 +510,29 @@ class discrim_block(nn.Module):
         return x, img
 
 
+class minibatch_std_layer(nn.Module):
+    """Appends the per-group standard-deviation statistic as ``num_channels`` extra channels (stylegan.py:686-704)."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size = group_size
+        self.num_channels = num_channels
+
+    def forward(self, x):
+        return kernels.minibatch_std(x, self.group_size, self.num_channels)
+
+
 class discrim_epilogue(nn.Module):
-    """4x4 tail: conv 3x3 -> fc -> out (stylegan.py:707-755); minibatch-std is not on the generator
-    path (mbstd_c_n = 0 for the encoder) and is rejected here."""
+    """4x4 tail: [minibatch-std] -> conv 3x3 -> fc -> out (stylegan.py:707-755)."""
 
     def __init__(self, ic_n, resolution, cmap_dim, rgb_n=None, mbstd_group_size=4, mbstd_c_n=1,
                  activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', reslink=True):
         super().__init__()
-        if mbstd_c_n > 0:
-            raise NotImplementedError('minibatch_std_layer is discriminator-only and out of the generator hot path')
         self.ic_n, self.cmap_dim, self.resolution, self.rgb_n, self.reslink = ic_n, cmap_dim, resolution, rgb_n, reslink
         self.fromrgb = None
         if rgb_n is not None:
             self.fromrgb = conv2d_layer(rgb_n, ic_n, 1, bias=True, activation=activation, up=1, down=1, resample_filter=None)
-        self.mbstd = None
+        self.mbstd = minibatch_std_layer(group_size=mbstd_group_size, num_channels=mbstd_c_n) if mbstd_c_n > 0 else None
         self.conv = conv2d_layer(ic_n + mbstd_c_n, ic_n, 3, bias=True, activation=activation, up=1, down=1,
                                  resample_filter=None)
         self.fc = dense(ic_n * (resolution ** 2), ic_n, activation=activation)
@@ -531,8 +541,47 @@ class discrim_epilogue(nn.Module):
     def forward(self, x, img=None, cmap=None):
         if self.fromrgb is not None:
             x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+        if self.mbstd is not None:
+            x = self.mbstd(x)
         x = self.conv(x)
         x = self.out(self.fc(x.flatten(1)))
         if self.cmap_dim is not None:
-            raise NotImplementedError('conditional projection is not on the generator path')
+            raise NotImplementedError('conditional projection (c_dim > 0) is not used by any shipped SH-GAN config')
         return x
+
+
+@register('stylegan2_discriminator', version)
+class Discriminator(nn.Module):
+    """The training-time critic, forward only (stylegan.py:757-838): residual down blocks (3x3 -> 3x3 stride 2, plus the
+    FIR-decimated 1x1 skip of conv2d_resample.py:104-108, both scaled by sqrt(.5)) and the minibatch-std epilogue.
+    SH-GAN feeds it cat([mask-0.5, image]) (ic_n = 4, comodgan.yaml:51-58)."""
+
+    def __init__(self, resolution=256, ic_n=3, ch_base=16384, ch_max=512, use_fp16_before_res=16, resample_filter=[1, 3, 3, 1],
+                 activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', mbstd_group_size=4, mbstd_c_n=1, c_dim=None,
+                 cmap_dim=None):
+        super().__init__()
+        log2res = int(np.log2(resolution))
+        if 2 ** log2res != resolution:
+            raise ValueError
+        if use_fp16_before_res is not None and resolution > use_fp16_before_res:
+            raise NotImplementedError('the HIP path is fp32: pass use_fp16_before_res=None (as all shipped configs do)')
+        if c_dim is not None and c_dim > 0:
+            raise NotImplementedError('label-conditioned critics are not used by any shipped SH-GAN config')
+        self.encode_res = [2 ** i for i in range(log2res, 1, -1)]
+        self.ic_n, self.ch_base, self.ch_max = ic_n, ch_base, ch_max
+        self.resample_filter, self.activation = resample_filter, activation
+        for idx, (ri, rj) in enumerate(zip(self.encode_res[:-1], self.encode_res[1:])):
+            ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
+            setattr(self, 'b{}'.format(ri), discrim_block(ci, ci, cj, rgb_n=(ic_n if idx == 0 else None),
+                                                          resample_filter=resample_filter, activation=activation,
+                                                          reslink=True, use_fp16=False))
+        self.mapping = None
+        c4 = min(ch_base // self.encode_res[-1], ch_max)
+        self.b4 = discrim_epilogue(c4, resolution=4, cmap_dim=None, activation=activation,
+                                   mbstd_group_size=mbstd_group_size, mbstd_c_n=mbstd_c_n)
+
+    def forward(self, img, c, **kwargs):
+        x = None
+        for res in self.encode_res[0:-1]:
+            x, img = getattr(self, 'b{}'.format(res))(x, img)
+        return self.b4(x, img, None)

@@ -74,3 +74,42 @@ print("rank", r, "ok")
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_gloo_world2_sharded_eval_gather_and_zipzap():
+    """BASELINE config 4's loop on CPU: two gloo ranks run ``eval_harness.sharded_eval`` end to end -- rank-strided ids,
+    batched per-item input synthesis, the all_gather_into_tensor + zipzap re-interleave branch -- with a stand-in for the
+    generator step (the product step needs a GPU); the gathered result must equal the 1-rank run item for item, and the
+    padded tail (11 items over 2 ranks -> 12 slots) must be dropped (ds_sampler.py:60-62, eva_base.py:196-230)."""
+    script = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd import eval_harness as hz
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+def step(x, z):      # stand-in generator: per-item function of (x, z) -> uint8 [B,3,R,R]
+    img = torch.tanh(x[:, 1:4] * 0.5 + z[:, :3, None, None] * 0.1)
+    m = x[:, 0:1] + 0.5
+    return ((x[:, 1:4] * m + img * (1 - m)) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8)
+kw = dict(n_items=11, batch_size=4, resolution=32, seed=7, device="cpu", step_fn=step, z_dim=8)
+order, merged = hz.sharded_eval(None, rank=r, world=2, gather=True, **kw)
+ids1, out1 = hz.sharded_eval(None, rank=0, world=1, gather=False, **kw)
+assert order == ids1 == list(range(11)), order
+assert merged.shape == (11, 3, 32, 32) and merged.dtype == np.uint8
+assert np.array_equal(merged, out1.numpy())
+ids_r, local = hz.sharded_eval(None, rank=r, world=2, gather=False, **kw)
+assert ids_r == ([0, 2, 4, 6, 8, 10] if r == 0 else [1, 3, 5, 7, 9, 0]), ids_r      # extend-pad re-uses item 0
+assert np.array_equal(local.numpy()[:5], merged[r:10:2])
+dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+    port = str(31500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

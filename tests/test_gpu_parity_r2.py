@@ -1,0 +1,262 @@
+"""GPU parity, round 2 additions: direct oracle tests of the kernels that round 1 covered only end to end (torgb with
+and without the fused RGB up-sampling, the thin 1x1 convolution, bias_act in every operand combination, scale_channels,
+the generic upfirdn2d epilogue), reference-generated fixtures for the 512 model, the plain StyleGAN2 modules and the
+discriminator, full-batch 512x16 against the oracle, an element-wise relative check, and the launch-side guards."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def mods():
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs, eval_harness, kernels
+    from shgan_amd.model_zoo import shgan, stylegan
+    from shgan_amd.model_zoo.stylegan_utils import upfirdn2d
+    from oracle import shgan_oracle as orc
+    return dict(kernels=kernels, stylegan=stylegan, shgan=shgan, orc=orc, configs=configs, harness=eval_harness, ufd=upfirdn2d)
+
+
+def c(a):
+    return a.detach().cpu().numpy()
+
+
+def rnd(rs, *shape):
+    return torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+
+
+def elementwise_rel(a, b, floor):
+    """max over elements of |a-b| / max(|b|, floor): the element-wise counterpart of conftest.rel_err."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+@pytest.mark.parametrize('n,ci,h,w', [(2, 64, 64, 64), (3, 37, 8, 8), (1, 512, 4, 4), (2, 128, 32, 64)])
+@pytest.mark.parametrize('with_base', [False, True])
+def test_torgb_kernel_vs_oracle(mods, n, ci, h, w, with_base):
+    """torgb_layer (stylegan.py:325-337) + `upsample2d(img) + y` (comodgan.py:331-338) in one kernel."""
+    orc, k = mods['orc'], mods['kernels']
+    rs = np.random.RandomState(11)
+    x, wt, styles, bias = rnd(rs, n, ci, h, w), rnd(rs, 3, ci), rnd(rs, n, ci), rnd(rs, 3)
+    f = orc.setup_filter([1, 3, 3, 1])
+    ref = orc.modulated_conv2d(x, wt.view(3, ci, 1, 1), styles, demodulate=False) + bias.view(1, -1, 1, 1)
+    base = None
+    if with_base:
+        base = rnd(rs, n, 3, h // 2, w // 2)
+        ref = ref + orc.upsample2d(base, f)
+    y = k.torgb(x.to(DEV), wt.to(DEV), styles.to(DEV), bias.to(DEV), base_up=None if base is None else base.to(DEV),
+                f=f.to(DEV) if with_base else None)
+    assert rel_err(c(y), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('act,alpha,act_gain,clamp,gain', [(True, 0.2, 2 ** 0.5, 256.0, 1.0), (True, 0.1, 1.0, None, 0.5),
+                                                          (True, 0.3, 1.7, 0.4, 1.0), (False, 0.2, 1.0, None, 0.25)])
+def test_thin_conv1x1_and_dense_activation_arguments(mods, act, alpha, act_gain, clamp, gain):
+    """fromrgb (stylegan.py:640-642) and dense (stylegan.py:87-98) with non-default lrelu_agc arguments."""
+    orc, k = mods['orc'], mods['kernels']
+    rs = np.random.RandomState(12)
+    x, wt, b = rnd(rs, 3, 4, 16, 24), rnd(rs, 20, 4), rnd(rs, 20)
+    ref = torch.einsum('oi,nihw->nohw', wt * 0.5, x) + b.view(1, -1, 1, 1)
+    ref = orc.lrelu_agc(ref, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp) if act else ref * gain
+    y = k.conv1x1_thin_in(x.to(DEV), wt.to(DEV), b.to(DEV), wgain=0.5, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+    assert rel_err(c(y), ref.numpy()) < 1e-5
+    xd, wd, bd = rnd(rs, 5, 96), rnd(rs, 33, 96), rnd(rs, 33)
+    refd = xd @ (wd * 0.1).t() + bd * 2.0
+    refd = orc.lrelu_agc(refd, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp) if act else refd * gain
+    yd = k.dense(xd.to(DEV), wd.to(DEV), bd.to(DEV), wgain=0.1, bgain=2.0, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+    assert rel_err(c(yd), refd.numpy()) < 1e-5
+
+
+def test_bias_act_all_operand_combinations(mods):
+    """y = act((x*scale) + noise*strength + bias) + residual with every subset of the optional operands
+    (stylegan.py:175-180,232-238; common/utils.py:135-143)."""
+    import itertools
+    orc, k = mods['orc'], mods['kernels']
+    rs = np.random.RandomState(13)
+    n, ch, h, w = 3, 5, 6, 10
+    x, scale, bias, res = rnd(rs, n, ch, h, w), rnd(rs, n * ch), rnd(rs, ch), rnd(rs, n, ch, h, w)
+    noises = {'none': None, 'shared': rnd(rs, h, w), 'per_sample': rnd(rs, n, 1, h, w)}
+    for use_scale, use_bias, use_res, nk, act in itertools.product((0, 1), (0, 1), (0, 1), noises, (True, False)):
+        ref = x * scale.view(n, ch, 1, 1) if use_scale else x.clone()
+        if noises[nk] is not None:
+            ref = ref + noises[nk] * 0.7
+        if use_bias:
+            ref = ref + bias.view(1, -1, 1, 1)
+        ref = orc.lrelu_agc(ref, gain=0.6, alpha=0.15, act_gain=1.3, clamp=1.5) if act else ref * 0.6
+        if use_res:
+            ref = ref + res
+        y = k.bias_act(x.to(DEV), bias=bias.to(DEV) if use_bias else None, scale=scale.to(DEV) if use_scale else None,
+                       noise=None if noises[nk] is None else noises[nk].to(DEV), noise_strength=0.7,
+                       residual=res.to(DEV) if use_res else None, act=act, gain=0.6, alpha=0.15, act_gain=1.3, clamp=1.5)
+        assert rel_err(c(y), ref.numpy()) < 1e-6, (use_scale, use_bias, use_res, nk, act)
+
+
+def test_scale_channels_and_fma(mods):
+    k = mods['kernels']
+    rs = np.random.RandomState(14)
+    x, s = rnd(rs, 4, 7, 9, 11), rnd(rs, 4 * 7)
+    assert torch.equal(k.scale_channels(x.to(DEV), s.to(DEV)).cpu(), x * s.view(4, 7, 1, 1))          # one rounding: exact
+    a, b, cc = rnd(rs, 2, 3, 5, 5), rnd(rs, 2, 3, 1, 1), rnd(rs, 1, 3, 5, 5)
+    assert rel_err(c(k.fma(a.to(DEV), b.to(DEV), cc.to(DEV))), torch.addcmul(cc, a, b).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('up,down,pad,fshape', [(2, 1, [2, 1, 2, 1], (4, 4)), (1, 2, [1, 1, 1, 1], (4, 4)), (1, 1, [2, 1, 0, 3], (3, 5)),
+                                                ([2, 3], [3, 2], [3, 2, 4, 1], (3, 5))])
+def test_generic_upfirdn2d_epilogue_vs_oracle(mods, up, down, pad, fshape):
+    """The generic gather (upfirdn2d.cu:29-92 semantics) with the fused layer tail, on geometries the fast paths do not take."""
+    orc, k = mods['orc'], mods['kernels']
+    rs = np.random.RandomState(15)
+    n, ch = 2, 3
+    x, f = rnd(rs, n, ch, 13, 11), rnd(rs, *fshape)
+    ref0 = orc.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=1.5)
+    scale, bias, res = rnd(rs, n * ch), rnd(rs, ch), rnd(rs, *ref0.shape)
+    noise = rnd(rs, *ref0.shape[2:])
+    ref = orc.lrelu_agc(ref0 * scale.view(n, ch, 1, 1) + noise * 0.2 + bias.view(1, -1, 1, 1), gain=0.8) + res
+    upx, upy = (up, up) if isinstance(up, int) else up
+    dnx, dny = (down, down) if isinstance(down, int) else down
+    y = k.upfirdn2d(x.to(DEV), f.to(DEV), upx, upy, dnx, dny, pad[0], pad[1], pad[2], pad[3], gain=1.5,
+                    epilogue=dict(scale=scale.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV), noise_strength=0.2,
+                                  residual=res.to(DEV), act=True, gain=0.8))
+    assert rel_err(c(y), ref.numpy()) < 1e-5
+
+
+def test_heterogeneous_filter_standalone_forward(mods):
+    """shgan.py:143-160 called on its own, on the SHU geometry and on another one."""
+    orc, shgan = mods['orc'], mods['shgan']
+    rs = np.random.RandomState(16)
+    for h, w in ((64, 33), (16, 32)):
+        hf = shgan.heterogeneous_filter(8, 8, freedom=[2, 3], type='piecewise_linear').to(DEV)
+        wt = (1.0 / 8 + rnd(rs, 8, 48) * 0.1)
+        with torch.no_grad():
+            hf.weight.copy_(wt.to(DEV))
+        x = rnd(rs, 2, 8, h, w)
+        cw = shgan.make_cweight([2, 3], (h, w))
+        ref = orc.heterogeneous_filter(x, wt, cw)
+        assert rel_err(c(hf(x.to(DEV))), ref.numpy()) < 1e-5
+
+
+def test_operands_on_cpu_or_mixed_devices_are_rejected(mods):
+    from shgan_amd._lib import ShgError
+    k = mods['kernels']
+    x = torch.zeros(1, 2, 4, 4, device=DEV)
+    with pytest.raises(ShgError):
+        k.bias_act(x, bias=torch.zeros(2))                     # CPU operand
+    with pytest.raises(ShgError):
+        k.scale_channels(torch.zeros(1, 2, 4, 4), torch.zeros(2))
+    # non-contiguous operands are copied and kept alive until the launch (two temporaries must not alias)
+    rs = np.random.RandomState(17)
+    sc, bs = rnd(rs, 6, 2).to(DEV), rnd(rs, 2, 2).to(DEV)
+    xx = rnd(rs, 3, 2, 4, 4).to(DEV)
+    y = k.bias_act(xx, scale=sc[:, 0], bias=bs[:, 1], act=False)
+    ref = xx * sc[:, 0].reshape(3, 2, 1, 1) + bs[:, 1].reshape(1, 2, 1, 1)
+    assert rel_err(c(y), c(ref)) < 1e-6
+
+
+def test_generator_full_width_512_golden(mods):
+    """Reference-generated fixture of the full-width 512 model (BASELINE config 3's network, batch 1)."""
+    g = load_golden('generator_full512_stats')
+    orc, hz, cfgs = mods['orc'], mods['harness'], mods['configs']
+    sd = orc.init_state_dict(512, seed=int(g['seed']), noise_strength=0.05)
+    G = cfgs.build_generator(512)
+    G.load_state_dict(sd, strict=True)
+    assert len(G.state_dict()) == int(g['num_keys']) and sum(p.numel() for p in G.parameters()) == int(g['nparam'])
+    G = G.eval().requires_grad_(False).to(DEV)
+    x, z, _, mask = orc.synthetic_batch(1, 512, 512, seed=int(g['input_seed']))
+    xg, feats = G.encoder(x.to(DEV))
+    assert rel_err(c(xg), g['xg']) < 1e-4
+    assert rel_err(c(feats[512])[:, ::8, ::32, ::32], g['feat512_ds']) < 1e-4
+    assert rel_err(c(feats[256])[:, ::16, ::16, ::16], g['feat256_ds']) < 1e-4
+    img = G(x=x.to(DEV), z=z.to(DEV), c=torch.zeros(1, 0, device=DEV), noise_mode='const')
+    assert rel_err(c(img)[:, :, ::16, ::16], g['img_ds']) < 1e-3
+    assert rel_err(c(img).flatten()[g['sample_idx']], g['sample_val']) < 1e-3
+    assert elementwise_rel(c(img).flatten()[g['sample_idx']], g['sample_val'], floor=1e-2 * float(np.abs(g['sample_val']).max())) < 1e-3
+    st = np.array([img.mean().item(), img.std().item(), img.min().item(), img.max().item()])
+    assert np.allclose(st, g['stats'], rtol=1e-3, atol=1e-3)
+    u8 = c(hz.run_generator(G, x.to(DEV), z.to(DEV), noise_mode='const'))
+    d = np.abs(u8[:, :, ::16, ::16].astype(np.int32) - g['comb_u8_ds'].astype(np.int32))
+    assert d.max() <= 1
+    import hashlib
+    assert hashlib.sha256((u8 * mask).tobytes()).hexdigest() == str(g['known_sha256'])     # known region: bit-exact
+
+
+def test_full_batch_512x16_vs_oracle_four_images(mods):
+    """BASELINE config 3 at full size: the 16-image batch on the GPU against the CPU oracle on four of its images
+    (the oracle runs them as 1-image batches: the batch-global style norm cancels under demodulation),
+    with the global-max AND an element-wise relative criterion."""
+    orc, hz, cfgs = mods['orc'], mods['harness'], mods['configs']
+    G = cfgs.seeded_init_(cfgs.build_generator(512), seed=81, noise_strength=0.05)
+    sd = {k_: v.detach().clone() for k_, v in G.state_dict().items()}
+    G = G.eval().requires_grad_(False).to(DEV)
+    x, z, _, _ = hz.synthetic_items(list(range(16)), 512, 512, seed=82, device=DEV)
+    img = G(x=x, z=z, c=torch.zeros(16, 0, device=DEV), noise_mode='const')
+    for i in (0, 5, 10, 15):
+        ref = orc.generator_forward(sd, x[i:i + 1].cpu(), z[i:i + 1].cpu(), 512, noise_mode='const').numpy()
+        got = c(img[i:i + 1])
+        assert rel_err(got, ref) < 1e-4, i
+        assert elementwise_rel(got, ref, floor=1e-2 * float(np.abs(ref).max())) < 1e-3, i
+
+
+def test_sharded_eval_full_width_512_batch16(mods):
+    """One rank's share of BASELINE config 4 (full-width 512, batch 16 per GPU): 2 emulated ranks x 16 images against the
+    unsharded run of the same 32-item dataset; the known pixels are bit-identical, the holes differ by <= 1 LSB."""
+    hz, cfgs = mods['harness'], mods['configs']
+    from shgan_amd.data import zipzap_arrange
+    G = cfgs.seeded_init_(cfgs.build_generator(512), seed=83).eval().requires_grad_(False).to(DEV)
+    ids1, out1 = hz.sharded_eval(G, 32, 16, 512, rank=0, world=1, seed=5, gather=False, device=DEV)
+    parts = [hz.sharded_eval(G, 32, 16, 512, rank=r, world=2, seed=5, gather=False, device=DEV) for r in range(2)]
+    order = zipzap_arrange([p[0] for p in parts])[:32]
+    merged = zipzap_arrange([c(p[1]) for p in parts])[:32]
+    assert order == ids1 == list(range(32)) and merged.shape == (32, 3, 512, 512)
+    d = np.abs(merged.astype(np.int32) - c(out1).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-2
+    _, _, real_u8, mask = hz.synthetic_items(list(range(32)), 512, 512, seed=5, device=DEV)
+    m = c(mask).astype(bool)
+    assert np.array_equal(np.where(m, merged, 0), np.where(m, c(real_u8), 0))
+
+
+def _load_sd(module, g, prefix):
+    sd = {k_[len(prefix):]: torch.from_numpy(g[k_]) for k_ in g.files if k_.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+    return module.eval().requires_grad_(False).to(DEV)
+
+
+def test_plain_stylegan2_generator_golden(mods):
+    """stylegan.py:436-606: const-input synthesis, the plain Generator and the res_link block, against the reference's
+    own outputs with the reference's own weights (strict state-dict load)."""
+    g = load_golden('stylegan2_plain')
+    sg = mods['stylegan']
+    mp = sg.Mapping(z_dim=32, c_dim=0, w_dim=32, num_ws=8, num_layers=3, lr_multiplier=0.01, w_avg_beta=0.995)
+    syn = sg.Synthesis(w_dim=32, resolution=32, rgb_n=3, ch_base=256, ch_max=16, use_fp16_after_res=32)
+    G = _load_sd(sg.Generator(mp, syn), g, 'sd__')
+    assert G.num_ws == int(g['num_ws'])
+    z = torch.from_numpy(g['z']).to(DEV)
+    cnd = torch.zeros(3, 0, device=DEV)
+    assert rel_err(c(G(z, cnd, noise_mode='const')), g['img_const']) < 1e-4
+    assert rel_err(c(G(z, cnd, noise_mode='none')), g['img_none']) < 1e-4
+    assert rel_err(c(G(z, cnd, truncation_psi=0.6, truncation_cutoff=4, noise_mode='const')), g['img_trunc']) < 1e-4
+    blk = _load_sd(sg.synthesis_block(8, 12, w_dim=16, resolution=16, rgb_n=3, res_link=True), g, 'rlsd__')
+    xo, io = blk(torch.from_numpy(g['rl__x']).to(DEV), torch.from_numpy(g['rl__img']).to(DEV),
+                 torch.from_numpy(g['rl__ws']).to(DEV), noise_mode='const')
+    assert rel_err(c(xo), g['rl__x_out']) < 1e-4 and rel_err(c(io), g['rl__img_out']) < 1e-4
+
+
+def test_discriminator_forward_golden(mods):
+    """Next row N3, forward only: `stylegan2_discriminator` (stylegan.py:757-838) incl. `minibatch_std_layer`."""
+    g = load_golden('discriminator')
+    sg, k = mods['stylegan'], mods['kernels']
+    x = torch.from_numpy(g['mb__x']).to(DEV)
+    assert rel_err(c(k.minibatch_std(x, 4, 1)), g['mb__y_g4_f1']) < 1e-5
+    assert rel_err(c(k.minibatch_std(x, 2, 3)), g['mb__y_g2_f3']) < 1e-5
+    assert rel_err(c(k.minibatch_std(x, None, 2)), g['mb__y_gN_f2']) < 1e-5
+    D = _load_sd(sg.Discriminator(resolution=32, ic_n=4, ch_base=256, ch_max=16, use_fp16_before_res=None,
+                                  mbstd_group_size=4, mbstd_c_n=1), g, 'sd__')
+    for n in (8, 2):
+        logits = D(torch.from_numpy(g[f'img{n}']).to(DEV), None)
+        assert tuple(logits.shape) == (n, 1)
+        assert rel_err(c(logits), g[f'logits{n}']) < 1e-4, n

@@ -18,17 +18,8 @@ ACT = 'lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)'
 
 
 def build_generator(resolution=256, ch_base=32768, ch_max=512, w_dim=512, z_dim=512, w0_dim=1024):
-    num_ws = {256: 14, 512: 16, 1024: 18}[resolution]
-    mp = comodgan.Mapping(z_dim=z_dim, c_dim=0, w_dim=w_dim, num_ws=num_ws, num_layers=8, activation=ACT,
-                          lr_multiplier=0.01, w_avg_beta=0.995)
-    enc = shgan.Encoder(resolution=resolution, ic_n=4, oc_n=w0_dim, ch_base=ch_base, ch_max=ch_max, use_fp16_before_res=None,
-                        resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=0, mbstd_c_n=0, c_dim=None,
-                        cmap_dim=None, use_dropout=True, has_extra_final_layer=False, shu_channels=32,
-                        shu_df_freedom=[2, 3], shu_df_type='piecewise_linear', shu_input_res=64, shu_lowest_res=4,
-                        shu_tail_sigma_mult=3, shu_gaussian_at_input_res=False)
-    syn = comodgan.Synthesis(w_dim=w_dim, w0_dim=w0_dim, resolution=resolution, rgb_n=3, ch_base=ch_base, ch_max=ch_max,
-                             use_fp16_after_res=None, resample_filter=[1, 3, 3, 1], activation=ACT)
-    return comodgan.Generator(mp, enc, syn)
+    from shgan_amd import configs
+    return configs.build_generator(resolution, ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim)
 
 
 def test_library_exports_every_header_symbol():
@@ -131,3 +122,53 @@ def test_bad_arguments_are_reported_by_the_c_abi():
     assert small > 0 and small % (16 * 512 * 4 * 4 * 4) == 0
     assert lib.shg_conv2d_workspace_bytes(16, 512, 512, 64, 64, 3, 3, 0, 1, 1) == 256 * 128 * 256 * 4
     assert lib.shg_conv2d_workspace_bytes(16, 64, 64, 512, 512, 3, 3, 0, 1, 1) == 0
+
+
+def test_configs_build_and_seeded_init_are_deterministic():
+    """The product constructs the shipped generators by itself (registry configs = the flattened YAML of SURVEY A.1) and
+    initialises them identically in every process: same seed -> bit-identical state dict, reference initialiser statistics."""
+    from shgan_amd import configs
+    kw = dict(ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    cfg = configs.model_cfg('shgan_g256', **kw)
+    assert cfg['type'] == 'comodgan_generator' and cfg['args']['encoder']['type'] == 'shgan_encoder'
+    assert cfg['args']['encoder']['args']['shu_df_freedom'] == [2, 3] and cfg['args']['mapping']['args']['num_ws'] == 14
+    assert configs.model_cfg('shgan_g512')['args']['synthesis']['args']['resolution'] == 512
+    with pytest.raises(KeyError):
+        configs.model_cfg('shgan_g1024')
+    a = configs.seeded_init_(configs.build_generator(256, **kw), seed=3, noise_strength=0.1, bias_std=0.1).state_dict()
+    b = configs.seeded_init_(configs.build_generator(256, **kw), seed=3, noise_strength=0.1, bias_std=0.1).state_dict()
+    c = configs.seeded_init_(configs.build_generator(256, **kw), seed=4).state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a['synthesis.b8.conv0.weight'], c['synthesis.b8.conv0.weight'])
+    assert float(c['synthesis.b8.conv0.noise_strength']) == 0.0 and float(a['synthesis.b8.conv0.noise_strength']) == pytest.approx(0.1)
+    assert torch.all(c['synthesis.b8.conv0.affine.bias'] == 1) and torch.all(c['synthesis.b8.conv0.bias'] == 0)
+    assert abs(float(c['mapping.fc3.weight'].std()) - 100.0) < 5.0                     # randn / lr_multiplier
+    assert abs(float(c['encoder.shu.df1.weight'].mean()) - 1 / 64) < 1e-3            # N(1/C, 0.1/C)
+    assert abs(float(c['encoder.shu.conv0.weight'].std()) - 1 / 8) < 0.01            # He-normal, fan-in 64
+
+
+def test_activation_arguments_reach_the_kernels():
+    """``dense`` and the thin 1x1 convolution pass the lrelu_agc instance's alpha / gain / clamp on, they do
+    not fall back to the defaults of the wrapper."""
+    from shgan_amd.model_zoo import stylegan
+    seen = {}
+
+    def fake_dense(x, w, b=None, **kw):
+        seen['dense'] = kw
+        return x
+
+    def fake_thin(x, w, b=None, **kw):
+        seen['thin'] = kw
+        return x
+    old = kernels.dense, kernels.conv1x1_thin_in
+    kernels.dense, kernels.conv1x1_thin_in = fake_dense, fake_thin
+    try:
+        d = stylegan.dense(8, 8, activation='lrelu_agc(alpha=0.1, gain=1)')
+        d(torch.zeros(2, 8))
+        assert seen['dense']['act'] is True and seen['dense']['alpha'] == 0.1 and seen['dense']['act_gain'] == 1
+        assert seen['dense']['clamp'] is None
+        layer = stylegan.conv2d_layer(4, 16, 1, activation='lrelu_agc(alpha=0.3, gain=sqrt_2, clamp=7)')
+        layer(torch.zeros(1, 4, 8, 8), gain=0.5)
+        assert seen['thin']['alpha'] == 0.3 and seen['thin']['clamp'] == 7 and seen['thin']['gain'] == 0.5
+    finally:
+        kernels.dense, kernels.conv1x1_thin_in = old

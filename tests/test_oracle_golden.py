@@ -168,3 +168,20 @@ def test_integer_paths_bit_exact():
         assert orc.sampler_indices(n_items, world, rank, extend=True) == [int(v) for v in row[3:]]
     assert orc.zipzap_arrange([[0, 2, 4, 6], [1, 3, 5, 7]]) == list(g['zipzap_out'])
     assert orc.zipzap_arrange([[0, 3, 6], [1, 4, 7], [2, 5]]) == list(g['zipzap_out_ragged'])
+
+
+def test_oracle_full_width_512_matches_reference():
+    """The 512 blocks of the oracle against the reference-generated fixture (round 1 pinned them only through their symmetry
+    with the 256 blocks): full-width 512x512, batch 1."""
+    g = load_golden('generator_full512_stats')
+    sd = orc.init_state_dict(512, seed=int(g['seed']), noise_strength=0.05)
+    x, z, _, mask = orc.synthetic_batch(1, 512, 512, seed=int(g['input_seed']))
+    with torch.no_grad():
+        img, inter = orc.generator_forward(sd, x, z, 512, noise_mode='const', return_intermediates=True)
+    assert rel_err(inter['xg'].numpy(), g['xg']) < 2e-6
+    assert rel_err(inter['feats'][512].numpy()[:, ::8, ::32, ::32], g['feat512_ds']) < 2e-6
+    assert rel_err(img.numpy()[:, :, ::16, ::16], g['img_ds']) < 1e-5
+    assert rel_err(img.numpy().flatten()[g['sample_idx']], g['sample_val']) < 1e-5
+    u8 = orc.composite_u8(x, img).numpy()
+    import hashlib
+    assert hashlib.sha256((u8 * mask).tobytes()).hexdigest() == str(g['known_sha256'])

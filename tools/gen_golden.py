@@ -378,9 +378,101 @@ def gen_masks():
     print('  wrote', path)
 
 
+def gen_generator_full512_stats():
+    """Full-width G (79.8 M params) at 512x512, N=1 (BASELINE config 3's model): statistics, sampled pixels, a strided
+    slice and the b512 intermediate statistics -- pins the 512 blocks against the reference itself."""
+    G = build_reference_generator(512, 32768, 512, 512, 512, 1024)
+    sd = orc.init_state_dict(512, seed=35, noise_strength=0.05)
+    G.load_state_dict(sd, strict=True)
+    nparam = sum(p.numel() for p in G.parameters())
+    real_u8, mask, z = synth_inputs(1, 512, 512, seed=36)
+    x = assemble_x(real_u8, mask)
+    with torch.no_grad():
+        xg, feats = G.encoder(x)
+        img = G(x=x, z=torch.from_numpy(z), c=torch.zeros(1, 0), noise_mode='const')
+    g = rs(37)
+    idx = g.randint(0, img.numel(), size=512)
+    m = x[:, 0:1] + 0.5
+    comb_u8 = ((x[:, 1:4] * m + img * (1 - m)) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8)
+    save('generator_full512_stats', seed=np.int64(35), input_seed=np.int64(36), nparam=np.int64(nparam),
+         stats=np.array([img.mean().item(), img.std().item(), img.min().item(), img.max().item()]),
+         sample_idx=idx, sample_val=img.flatten()[idx].numpy(), img_ds=img[:, :, ::16, ::16].numpy(),
+         feat512_ds=feats[512][:, ::8, ::32, ::32].numpy(), feat256_ds=feats[256][:, ::16, ::16, ::16].numpy(),
+         xg=xg.numpy(),
+         known_sha256=np.array(hashlib.sha256((comb_u8 * torch.from_numpy(mask)).numpy().tobytes()).hexdigest()),
+         comb_u8_ds=comb_u8[:, :, ::16, ::16].numpy(),
+         num_keys=np.int64(len(G.state_dict())))
+
+
+def _sd_arrays(module, prefix='sd__'):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def gen_stylegan2_plain():
+    """stylegan.py:436-606 (`stylegan2_mapping` / `stylegan2_synthesis` / `stylegan2_generator`, const-input blocks) and
+    the `res_link` branch of `synthesis_block` -- the plain StyleGAN2 modules the co-modulated ones derive from.  Small
+    widths; the reference's own initial weights (torch.manual_seed) travel inside the fixture."""
+    torch.manual_seed(2024)
+    mp = stylegan.Mapping(z_dim=32, c_dim=0, w_dim=32, num_ws=8, num_layers=3, activation=ACT, lr_multiplier=0.01,
+                          w_avg_beta=0.995)
+    syn = stylegan.Synthesis(w_dim=32, resolution=32, rgb_n=3, ch_base=256, ch_max=16, use_fp16_after_res=32,
+                             resample_filter=[1, 3, 3, 1], activation=ACT)
+    G = stylegan.Generator(mp, syn).eval().requires_grad_(False)
+    for n_, p_ in G.named_parameters():
+        if n_.endswith('noise_strength'):
+            p_.fill_(0.1)
+        if n_.endswith('.bias') and 'affine' not in n_:
+            p_.copy_(torch.randn_like(p_) * 0.1)
+    z = torch.randn(3, 32)
+    out = dict(z=z.numpy(), num_ws=np.int64(G.num_ws))
+    out.update(_sd_arrays(G))
+    out['img_const'] = G(z, torch.zeros(3, 0), noise_mode='const').numpy()
+    out['img_none'] = G(z, torch.zeros(3, 0), noise_mode='none').numpy()
+    out['img_trunc'] = G(z, torch.zeros(3, 0), truncation_psi=0.6, truncation_cutoff=4, noise_mode='const').numpy()
+    # res_link block (stylegan.py:481-483,500-507): 1x1 up-skip added to the conv branch
+    torch.manual_seed(2025)
+    blk = stylegan.synthesis_block(8, 12, w_dim=16, resolution=16, rgb_n=3, activation=ACT, res_link=True).eval().requires_grad_(False)
+    blk.conv0.noise_strength.fill_(0.2)
+    blk.conv1.noise_strength.fill_(0.3)
+    x = torch.randn(2, 8, 8, 8)
+    img = torch.randn(2, 3, 8, 8)
+    ws = torch.randn(2, 3, 16)
+    xo, io = blk(x, img, ws, noise_mode='const')
+    out.update({'rl__x': x.numpy(), 'rl__img': img.numpy(), 'rl__ws': ws.numpy(), 'rl__x_out': xo.numpy(), 'rl__img_out': io.numpy()})
+    out.update(_sd_arrays(blk, 'rlsd__'))
+    save('stylegan2_plain', **out)
+
+
+def gen_discriminator():
+    """stylegan.py:624-838: `stylegan2_discriminator` forward (reslink blocks with the down-2 1x1 skip of
+    conv2d_resample.py:104-108, `minibatch_std_layer` :686-704, epilogue) at reduced width, N=6 (one full group of 4 + a
+    ragged rest is rejected by the reference's reshape, so N is a multiple of the group size... N=8) and N=2 (< group)."""
+    torch.manual_seed(2026)
+    D = stylegan.Discriminator(resolution=32, ic_n=4, ch_base=256, ch_max=16, use_fp16_before_res=None,
+                               resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=4, mbstd_c_n=1,
+                               c_dim=None, cmap_dim=None).eval().requires_grad_(False)
+    for n_, p_ in D.named_parameters():
+        if n_.endswith('.bias'):
+            p_.copy_(torch.randn_like(p_) * 0.1)
+    out = _sd_arrays(D)
+    for n in (8, 2):
+        img = torch.randn(n, 4, 32, 32)
+        out[f'img{n}'] = img.numpy()
+        out[f'logits{n}'] = D(img, None).numpy()
+    # the std layer on its own, incl. several feature groups
+    x = torch.randn(8, 6, 4, 4)
+    out['mb__x'] = x.numpy()
+    out['mb__y_g4_f1'] = stylegan.minibatch_std_layer(4, 1)(x).numpy()
+    out['mb__y_g2_f3'] = stylegan.minibatch_std_layer(2, 3)(x).numpy()
+    out['mb__y_gN_f2'] = stylegan.minibatch_std_layer(None, 2)(x).numpy()
+    save('discriminator', **out)
+
+
 GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modconv=gen_modconv,
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
-            generator_full_stats=gen_generator_full_stats, masks=gen_masks)
+            generator_full_stats=gen_generator_full_stats, masks=gen_masks,
+            generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
+            discriminator=gen_discriminator)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
