@@ -90,6 +90,17 @@ int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I
 int shg_upfir_planar_f32(const float* mid, const float* f, float* y, int N, int C, int H, int W, int flip, float gain,
                          const float* scale, const float* bias, const float* noise, int noise_mode, float noise_strength,
                          int act, float alpha, float act_gain, float clamp, const float* residual, void* stream);
+/* Polyphase-Winograd form of mode 2 / out_mode 1 (conv_wino_poly.hip): the `ee` phase as F(3x3,2x2), `eo`/`oe`/`oo` of
+ * every 2x2 block of low-resolution pixels with 16 multiplies, one-pixel strips by single-tap contractions -- 5.8 instead of
+ * 9 multiplies per low-resolution pixel, same result up to fp32 round-off.  y [4][NB,O,H+1,W+1] raw phase planes (no
+ * epilogue operands: the consumer is shg_upfir_planar_f32).  wt / wscale from shg_conv_weight_prep_f32; wu_a, wu_b:
+ * [OP/64][ceil(I/8)][16][64][8] floats each.  shg_conv2d_up_poly_supported tells whether the geometry is served
+ * (H >= 32, H even, W % 4 == 0); otherwise call shg_conv2d_f32. */
+int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP, int flip,
+                                     void* stream);
+int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W);
+int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O,
+                           int OP, int H, int W, const float* in_scale, void* stream);
 /* 1x1 convolution with I <= 8 input channels (encoder fromrgb, stylegan.py:640-642): y = act(W*wgain @ x + bias). */
 int shg_conv1x1_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int N, int I, int O, int HW, float wgain,
                             int act, float alpha, float gain, float clamp, void* stream);

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -60,6 +60,9 @@ _SIGS = {
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_assemble_input_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'shg_conv_weight_prep_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'shg_conv2d_up_poly_supported': [c_i, c_i, c_i, c_i, c_i],
+    'shg_conv2d_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp],
     'shg_minibatch_std_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }
 

@@ -1,0 +1,489 @@
+// Polyphase Winograd forms of the stride-2 transposed 3x3 convolution (the "up" layers) on the fp32 matrix cores of
+// gfx950 -- same 16-position / 16-wave skeleton as conv_wino.hip, different transforms.
+//
+// Reference semantics: conv2d_resample.py:122-137 -> F.conv_transpose2d(stride=2) as called from modulated_conv2d
+// (stylegan.py:103-193) for every `conv0` of comodgan.synthesis_block (comodgan.py:304-340):
+//      out[2u+ky, 2v+kx] += w[ky][kx] * x[u, v]          u in [0,H), v in [0,W), out is (2H+1) x (2W+1).
+// The four sub-pixel phases (a, b) = (Y & 1, X & 1) of `out` are four INDEPENDENT small convolutions of the same
+// low-resolution input (u, v index the phase plane; x = 0 outside the image):
+//      ee[u,v] = sum_{ky,kx in {0,2}} w[ky][kx] x[u-ky/2, v-kx/2]        2x2 taps, (H+1) x (W+1)
+//      eo[u,v] = sum_{ky in {0,2}}     w[ky][1]  x[u-ky/2, v]            2x1 taps, (H+1) x  W
+//      oe[u,v] = sum_{kx in {0,2}}     w[1][kx]  x[u, v-kx/2]            1x2 taps,  H    x (W+1)
+//      oo[u,v] =                       w[1][1]   x[u, v]                 1 tap,     H    x  W
+// = 36 multiplies per 2x2 block of low-resolution pixels in the direct form.  Here:
+//   scheme UA: `ee` as Winograd F(3x3, 2x2): 16 multiplies per 3x3 outputs (input transform B^T d B is the one of
+//              F(2x2,3x3); G = [[1,0],[.5,.5],[.5,-.5],[0,1]], A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]);
+//   scheme UB: `eo`, `oe`, `oo` of a 2x2 block from its 3x3 input patch with 6 + 6 + 4 = 16 multiplies
+//              (F(2,2) along the 2-tap axis: m1 = (d0-d1) g1, m2 = d1 (g0+g1), m3 = (d2-d1) g0; y0 = m1+m2, y1 = m2+m3);
+//   the row u = H of `eo` and the column v = W of `oe` (one pixel thick) come from strip_kernel below.
+// Together (16/9 + 4) = 5.8 multiplies per low-resolution pixel instead of 9: 1.56x fewer MFMA flops, still exact fp32
+// MFMA arithmetic with transform constants 0, +-1, +-1/2.
+//
+// Both schemes are "16 independent GEMMs M_xi[o,t] = sum_i U_xi[i,o] V_xi[i,t]" over 64 output channels x 64 blocks,
+// so the kernel body is the one of conv_wino.hip: wave w owns position w (4 accumulator tiles of 32x32), U from
+// registers (lane-major layout, one chunk ahead), raw input window by 16-byte LDS-DMA, V built in LDS by waves 0-7,
+// double buffering with one barrier per 8-channel chunk, MFMA stream skewed one k-step across the barrier, exchange
+// epilogue through LDS.  Output: raw phase planes [4][NB,O,H+1,W+1] for shg_upfir_planar_f32 (which applies the 4x4
+// FIR of conv2d_resample.py:138, the demodulation coefficient and the layer tail).
+#include "shg_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((aligned(16))) float shg_poly_zeros[64];   // zero source for LDS-DMA lanes that fall into padding
+
+struct PolyParams {
+    const float* x;          // [NB, I, H, W]
+    const float* wu;         // transformed weights [OP/64][nchunk][16][64 lanes][KC]
+    float* y;                // phase planes [4][NB, O, H+1, W+1]
+    const float* in_scale;   // [NB, I] or null
+    int NB, I, O, OP, H, W;
+    int nby, nbx;            // blocks per image
+    int tiles_x, tiles_y;    // tiles per image
+    int n_ttiles, n_otiles, nchunk;
+};
+
+namespace poly {
+constexpr int KC = 8, BO = 64, BT = 64;
+constexpr int V_SZ = 16 * KC * BT;
+constexpr int NT = 1024;
+constexpr int NXF = KC;
+
+// Scheme UA: 3x3 output blocks of the `ee` plane from 4x4 input patches.  Scheme UB: 2x2 blocks of eo / oe / oo from 3x3 patches.
+enum { UA = 0, UB = 1 };
+
+template <int SCHEME, int TY, int TX>
+struct Geo {
+    static_assert(TY * TX == BT, "64 blocks per tile");
+    static constexpr int BS = SCHEME == UA ? 3 : 2;                    // block edge in phase-plane pixels
+    static constexpr int PH = SCHEME == UA ? 3 * TY + 1 : 2 * TY + 1;  // window rows
+    // window columns: 16-byte aligned start at or before the first needed column, rounded up to whole float4
+    static constexpr int PW = SCHEME == UA ? ((3 * TX + 1 + 3 + 3) / 4) * 4 : 2 * TX + 4;
+    static constexpr int PW4 = PW / 4, PATCH4 = PH * PW4, RP = PH * PW, R_SZ = KC * RP;
+    static constexpr int NPIECE = (PATCH4 + 63) / 64;
+};
+}   // namespace poly
+
+__device__ __forceinline__ int poly_xcd_remap(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <int SCHEME, int TY, int TX>
+__global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
+    using namespace poly;
+    using G = Geo<SCHEME, TY, TX>;
+    constexpr int PW = G::PW, PW4 = G::PW4, PATCH4 = G::PATCH4, RP = G::RP, R_SZ = G::R_SZ, BS = G::BS, NPIECE = G::NPIECE;
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
+    __shared__ __attribute__((aligned(16))) float Rl[2 * R_SZ];      // [2][KC][RP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int nwork = p.n_ttiles * p.n_otiles;
+    const int work = poly_xcd_remap(blockIdx.x, nwork);
+    const int otile = work / p.n_ttiles;
+    const int ttile = work - otile * p.n_ttiles;
+    const int txb = ttile % p.tiles_x;
+    const int tyb = (ttile / p.tiles_x) % p.tiles_y;
+    const int n = ttile / (p.tiles_x * p.tiles_y);
+    const int by0 = tyb * TY, bx0 = txb * TX;            // first block of the tile
+    const int o0 = otile * BO;
+    const int HW = p.H * p.W;
+    // window origin in the low-resolution image: both schemes read rows / columns BS*b - 1 ... ; the column start is
+    // rounded down to a multiple of 4 floats (UB: 2*bx0 - 4, i.e. three columns of slack; UA: 0..3 columns)
+    const int wy0 = BS * by0 - 1;
+    const int wx0 = SCHEME == UA ? ((3 * bx0 - 1) & ~3) : 2 * bx0 - 4;
+    const int coff = (BS * bx0 - 1) - wx0;               // window column of the first needed input column
+
+    const bool xformer = wave < NXF;
+    constexpr int NLD = 16 - NXF;
+    constexpr int CPL = (KC + NLD - 1) / NLD;
+    int roff[NPIECE];
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+        const int q = j * 64 + lane;
+        const int py = q / PW4, p4 = q - py * PW4;
+        const int iy = wy0 + py, ix = wx0 + 4 * p4;
+        const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
+        roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
+    }
+    const bool ract_last = lane < PATCH4 - 64 * (NPIECE - 1);
+    auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int k = (wave - NXF) * CPL + q;
+            if (k >= KC) continue;
+            const int ch = c * KC + k;
+            const bool chok = ch < p.I;
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) {
+                const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_poly_zeros;
+                if (j < NPIECE - 1 || ract_last)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    constexpr int NU = KC / 4;
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(p.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
+    const size_t ustride = (size_t)16 * 64 * KC / 4;
+    f32x4 ua[NU], ub[NU];
+    auto load_u = [&](f32x4 (&dst)[NU], int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) dst[j] = ubase[(size_t)c * ustride + j];
+    };
+
+    // ---- input transform role: channel `wave`, block `lane`
+    const int tty = lane / TX, ttx = lane % TX;
+    const float* rbase = Rl + wave * RP + (BS * tty) * PW + BS * ttx + coff;
+    float* vbase = Vl + wave * BT + lane;
+    float scv[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int ch = (v * 64 + lane) * KC + wave;
+        scv[v] = (p.in_scale && xformer && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
+    }
+    auto transform = [&](int c, int buf) __attribute__((always_inline)) {
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
+        const float* rb = rbase + buf * R_SZ;
+        float* vb = vbase + buf * V_SZ;
+        if constexpr (SCHEME == UA) {
+            // B^T d B on the 4x4 patch (rows first, two rows of LDS reads in flight at a time)
+            float f[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d0 = rb[r * PW] * sc, d1 = rb[r * PW + 1] * sc, d2 = rb[r * PW + 2] * sc, d3 = rb[r * PW + 3] * sc;
+                f[r][0] = d0 - d2; f[r][1] = d1 + d2; f[r][2] = d2 - d1; f[r][3] = d1 - d3;
+                if (r == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vb[(0 * 4 + j) * KC * BT] = f[0][j] - f[2][j];
+                vb[(1 * 4 + j) * KC * BT] = f[1][j] + f[2][j];
+                vb[(2 * 4 + j) * KC * BT] = f[2][j] - f[1][j];
+                vb[(3 * 4 + j) * KC * BT] = f[1][j] - f[3][j];
+            }
+        } else {
+            float d[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) d[r][cc] = rb[r * PW + cc] * sc;
+            // eo: positions j*2 + (c-1), F(2,2) down the rows of columns 1, 2
+#pragma unroll
+            for (int cc = 1; cc < 3; ++cc) {
+                vb[(0 * 2 + cc - 1) * KC * BT] = d[0][cc] - d[1][cc];
+                vb[(1 * 2 + cc - 1) * KC * BT] = d[1][cc];
+                vb[(2 * 2 + cc - 1) * KC * BT] = d[2][cc] - d[1][cc];
+            }
+            // oe: positions 6 + (r-1)*3 + j, F(2,2) along the columns of rows 1, 2
+#pragma unroll
+            for (int r = 1; r < 3; ++r) {
+                vb[(6 + (r - 1) * 3 + 0) * KC * BT] = d[r][0] - d[r][1];
+                vb[(6 + (r - 1) * 3 + 1) * KC * BT] = d[r][1];
+                vb[(6 + (r - 1) * 3 + 2) * KC * BT] = d[r][2] - d[r][1];
+            }
+            // oo: positions 12 + (r-1)*2 + (c-1)
+#pragma unroll
+            for (int r = 1; r < 3; ++r)
+#pragma unroll
+                for (int cc = 1; cc < 3; ++cc) vb[(12 + (r - 1) * 2 + cc - 1) * KC * BT] = d[r][cc];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ob][tb][r] = 0.f;
+    const float* bbase = Vl + (wave * KC + half) * BT + l31;
+
+    load_u(ua, 0);
+    if (!xformer) {
+        dma_raw(0, 0);
+        if (p.nchunk > 1) dma_raw(1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (xformer) transform(0, 0);
+    __syncthreads();
+
+    float b[2][2], apend[2];
+    auto mma = [&](float a0, float a1, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[buf][tb], acc[0][tb], 0, 0, 0);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[1][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[buf][tb], acc[1][tb], 0, 0, 0);
+    };
+    auto chunk = [&](auto par, int c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        f32x4 (&ucur)[NU] = PAR ? ub : ua;
+        f32x4 (&unxt)[NU] = PAR ? ua : ub;
+        const bool more = c + 1 < p.nchunk;
+        const float* bb = bbase + PAR * V_SZ;
+        auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) b[buf][tb] = bb[(ks * 2) * BT + tb * 32];
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c > 0) mma(apend[0], apend[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_u(unxt, c + 1);
+        if (!xformer) {
+            if (c + 2 < p.nchunk) dma_raw(c + 2, PAR);
+        } else if (more) {
+            transform(c + 1, PAR ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KC / 2 - 1; ++ks) {
+            fetch(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ucur[(ks * 2) / 4][(ks * 2) % 4], ucur[(ks * 2 + 1) / 4][(ks * 2 + 1) % 4], ks & 1);
+        }
+        apend[0] = ucur[(KC - 2) / 4][(KC - 2) % 4];
+        apend[1] = ucur[(KC - 1) / 4][(KC - 1) % 4];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int c = 0; c < p.nchunk; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < p.nchunk) chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+    mma(apend[0], apend[1], 1);
+
+    // ---- epilogue: exchange the 16 M_xi of every (channel, block) through LDS, inverse transform, raw plane stores
+    float* Mx = Vl;                           // [16][32][32]
+    const int PWg = p.W + 1;
+    const long plane = (long)(p.H + 1) * PWg;
+    const int o_l = tid >> 5, t_l = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int ob = pass >> 1, tb = pass & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            Mx[(wave * 32 + row) * 32 + l31] = acc[ob][tb][r];
+        }
+        __syncthreads();
+        float m[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 32 + t_l];
+        const int t = tb * 32 + t_l;
+        const int by = by0 + t / TX, bx = bx0 + t % TX;
+        const int o = o0 + ob * 32 + o_l;
+        if (o < p.O && by < p.nby && bx < p.nbx) {
+            float* yb = p.y + ((long)n * p.O + o) * plane;             // + phase * NB*O*plane
+            const long pstride = (long)p.NB * p.O * plane;
+            if constexpr (SCHEME == UA) {
+                // A^T m A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
+                float t3[3][4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    t3[0][cc] = m[0 * 4 + cc] + m[1 * 4 + cc] + m[2 * 4 + cc];
+                    t3[1][cc] = m[1 * 4 + cc] - m[2 * 4 + cc];
+                    t3[2][cc] = m[1 * 4 + cc] + m[2 * 4 + cc] - m[3 * 4 + cc];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int u = 3 * by + i;
+                    if (u > p.H) continue;
+                    const float y0 = t3[i][0] + t3[i][1] + t3[i][2], y1 = t3[i][1] - t3[i][2], y2 = t3[i][1] + t3[i][2] - t3[i][3];
+                    float* yr = yb + (long)u * PWg + 3 * bx;
+                    yr[0] = y0;
+                    if (3 * bx + 1 <= p.W) yr[1] = y1;
+                    if (3 * bx + 2 <= p.W) yr[2] = y2;
+                }
+            } else {
+                const int u0 = 2 * by, v0 = 2 * bx;                    // all four pixels of a body block are inside the image
+                float* yeo = yb + pstride + (long)u0 * PWg + v0;
+                float* yoe = yb + 2 * pstride + (long)u0 * PWg + v0;
+                float* yoo = yb + 3 * pstride + (long)u0 * PWg + v0;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    yeo[cc] = m[0 * 2 + cc] + m[1 * 2 + cc];
+                    yeo[PWg + cc] = m[1 * 2 + cc] + m[2 * 2 + cc];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    yoe[r * PWg] = m[6 + r * 3] + m[6 + r * 3 + 1];
+                    yoe[r * PWg + 1] = m[6 + r * 3 + 1] + m[6 + r * 3 + 2];
+                    yoo[r * PWg] = m[12 + r * 2];
+                    yoo[r * PWg + 1] = m[12 + r * 2 + 1];
+                }
+            }
+        }
+        if (pass < 3) __syncthreads();
+    }
+}
+
+// The one-pixel strips the 2x2 body blocks of scheme UB do not reach: eo[H, v] = w[2][1] . x[H-1, v] (v < W) and
+// oe[u, W] = w[1][2] . x[u, W-1] (u < H): two single-tap contractions over the input channels along one image row /
+// column.  One workgroup (4 waves) = 64 output channels x 64 strip positions of one image; operands straight from
+// global memory (wt is the GEMM layout of shg_conv_weight_prep_f32: [OP/64][IP*9][64], row = i*9 + tap).
+__global__ __launch_bounds__(256) void conv_poly_strip_kernel(const PolyParams p, const float* wt, int IPK) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wo = wave >> 1, wp = wave & 1;
+    const int nseg_r = (p.W + 63) / 64, nseg_c = (p.H + 63) / 64;
+    int seg = blockIdx.x % (nseg_r + nseg_c);
+    const int otile = (blockIdx.x / (nseg_r + nseg_c)) % p.n_otiles;
+    const int n = blockIdx.x / ((nseg_r + nseg_c) * p.n_otiles);
+    const bool col = seg >= nseg_r;
+    if (col) seg -= nseg_r;
+    const int len = col ? p.H : p.W;
+    const int pos = seg * 64 + wp * 32 + l31;                 // strip position of this lane's B column
+    const int tap = col ? 1 * 3 + 2 : 2 * 3 + 1;
+    const int HW = p.H * p.W;
+    const bool pok = pos < len;
+    const float* xb = p.x + (long)n * p.I * HW + (pok ? (col ? pos * p.W + p.W - 1 : (p.H - 1) * p.W + pos) : 0);
+    const float* wb = wt + ((long)otile * IPK + tap) * 64 + wo * 32 + l31;     // + i*9*64
+    const float* sb = p.in_scale ? p.in_scale + (long)n * p.I : nullptr;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int i0 = 0; i0 < p.I; i0 += 2) {
+        const int i = min(i0 + half, p.I - 1);
+        const float a = (i0 + half < p.I) ? wb[(long)i * 9 * 64] : 0.f;
+        float bv = pok ? xb[(long)i * HW] : 0.f;
+        if (sb) bv *= sb[i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    if (!pok) return;
+    const int PWg = p.W + 1;
+    const long plane = (long)(p.H + 1) * PWg;
+    const long pix = col ? (long)pos * PWg + p.W : (long)p.H * PWg + pos;
+    float* yb = p.y + (long)(col ? 2 : 1) * p.NB * p.O * plane + (long)n * p.O * plane + pix;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = otile * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.O) yb[(long)o * plane] = acc[r];
+    }
+}
+
+// U for both schemes from w [O,I,3,3] * scale[o]; tap (ky,kx) = w[ky*3+kx] (flip: 8 - index), as the transposed kernel of
+// conv_mfma.hip indexes them.  Layout as conv_wino.hip: wu[otile][chunk][xi][lane][KC].
+__global__ __launch_bounds__(256) void poly_weight_kernel(const float* w, const float* scale, float* wu, int O, int I, int OP,
+                                                          int nchunk, int flip, int scheme) {
+    constexpr int KC = poly::KC;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)OP * nchunk * KC;
+    if (e >= total) return;
+    const int o = (int)(e % OP);
+    const int i = (int)(e / OP);
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        g[t / 3][t % 3] = (o < O && i < I) ? w[((long)o * I + i) * 9 + tt] * scale[o] : 0.f;
+    }
+    float u[16];
+    if (scheme == poly::UA) {
+        // correlation taps of the 2x2 problem: q[k][l] = w[2-2k][2-2l]; U = G q G^T, G = [[1,0],[.5,.5],[.5,-.5],[0,1]]
+        const float q00 = g[2][2], q01 = g[2][0], q10 = g[0][2], q11 = g[0][0];
+        float gq[4][2];
+        gq[0][0] = q00; gq[0][1] = q01;
+        gq[1][0] = 0.5f * (q00 + q10); gq[1][1] = 0.5f * (q01 + q11);
+        gq[2][0] = 0.5f * (q00 - q10); gq[2][1] = 0.5f * (q01 - q11);
+        gq[3][0] = q10; gq[3][1] = q11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u[r * 4 + 0] = gq[r][0];
+            u[r * 4 + 1] = 0.5f * (gq[r][0] + gq[r][1]);
+            u[r * 4 + 2] = 0.5f * (gq[r][0] - gq[r][1]);
+            u[r * 4 + 3] = gq[r][1];
+        }
+    } else {
+        const float g0 = g[0][1], g1 = g[2][1];        // eo: tap on x[u], tap on x[u-1]
+        const float h0 = g[1][0], h1 = g[1][2];        // oe: tap on x[v], tap on x[v-1]
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) { u[0 * 2 + cc] = g1; u[1 * 2 + cc] = g0 + g1; u[2 * 2 + cc] = g0; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { u[6 + r * 3 + 0] = h1; u[6 + r * 3 + 1] = h0 + h1; u[6 + r * 3 + 2] = h0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[12 + k] = g[1][1];
+    }
+    const int k = i % KC, chunk = i / KC;
+    const int ln = (k & 1) * 32 + (o & 31), slot = (k >> 1) * 2 + ((o & 63) >> 5);
+    float* dst = wu + ((((long)(o >> 6) * nchunk + chunk) * 16) * 64 + ln) * KC + slot;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) dst[(long)xi * 64 * KC] = u[xi];
+}
+
+// w [O,I,3,3], wscale [O] -> wu_a, wu_b (each [OP/64][ceil(I/8)][16][64][8] floats).
+extern "C" int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP,
+                                                int flip, void* stream) {
+    SHG_CHECK_ARG(w && wscale && wu_a && wu_b, "weight_prep_up_poly: null pointer");
+    SHG_CHECK_ARG(O >= 1 && I >= 1 && OP % 64 == 0 && OP >= O, "weight_prep_up_poly: bad shape");
+    const int nchunk = shg_cdiv(I, poly::KC);
+    const long total = (long)OP * nchunk * poly::KC;
+    hipLaunchKernelGGL(poly_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu_a, O, I, OP,
+                       nchunk, flip, (int)poly::UA);
+    SHG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(poly_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu_b, O, I, OP,
+                       nchunk, flip, (int)poly::UB);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// 1 when shg_conv2d_up_poly_f32 handles this geometry (otherwise use shg_conv2d_f32 mode 2, out_mode 1)
+extern "C" int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W) {
+    return (H >= 32 && W >= 32 && H % 2 == 0 && W % 4 == 0 && I <= 128 * poly::KC && NB >= 1 && O >= 1) ? 1 : 0;
+}
+
+// Phase planes of the stride-2 transposed 3x3 convolution of x * in_scale[n,i]: y [4][NB,O,H+1,W+1] (same contract as
+// shg_conv2d_f32 mode 2 / out_mode 1 without epilogue operands).  wt = GEMM-layout weights of shg_conv_weight_prep_f32
+// (for the strips), wu_a / wu_b from shg_conv_weight_prep_up_poly_f32.
+extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I,
+                                      int O, int OP, int H, int W, const float* in_scale, void* stream) {
+    SHG_CHECK_ARG(x && wt && wu_a && wu_b && y, "conv2d_up_poly: null pointer");
+    SHG_CHECK_ARG(shg_conv2d_up_poly_supported(NB, I, O, H, W), "conv2d_up_poly: unsupported geometry (use shg_conv2d_f32 mode 2)");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_up_poly: OP must be a multiple of 64 and >= O");
+    SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && 4L * NB * O * (H + 1) * (W + 1) < 2147483647L, "conv2d_up_poly: tensor too large");
+    SHG_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "conv2d_up_poly: x must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    PolyParams p{};
+    p.x = x; p.y = y; p.in_scale = in_scale;
+    p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
+    p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
+    // scheme UB: 2x2 body blocks
+    {
+        p.wu = wu_b; p.nby = H / 2; p.nbx = W / 2;
+        const bool wide = p.nbx >= 16;
+        p.tiles_x = shg_cdiv(p.nbx, wide ? 16 : 8); p.tiles_y = shg_cdiv(p.nby, wide ? 4 : 8);
+        p.n_ttiles = p.tiles_x * p.tiles_y * NB;
+        if (wide) hipLaunchKernelGGL((conv_poly_kernel<poly::UB, 4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
+        else hipLaunchKernelGGL((conv_poly_kernel<poly::UB, 8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
+        SHG_CHECK_LAUNCH();
+    }
+    // scheme UA: 3x3 blocks of the ee plane; tile shape by padding waste
+    {
+        p.wu = wu_a; p.nby = shg_cdiv(H + 1, 3); p.nbx = shg_cdiv(W + 1, 3);
+        const long w88 = (long)shg_cdiv(p.nbx, 8) * shg_cdiv(p.nby, 8), w416 = (long)shg_cdiv(p.nbx, 16) * shg_cdiv(p.nby, 4);
+        const bool wide = w416 < w88;
+        p.tiles_x = shg_cdiv(p.nbx, wide ? 16 : 8); p.tiles_y = shg_cdiv(p.nby, wide ? 4 : 8);
+        p.n_ttiles = p.tiles_x * p.tiles_y * NB;
+        if (wide) hipLaunchKernelGGL((conv_poly_kernel<poly::UA, 4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
+        else hipLaunchKernelGGL((conv_poly_kernel<poly::UA, 8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
+        SHG_CHECK_LAUNCH();
+    }
+    // strips
+    {
+        const int nseg = shg_cdiv(W, 64) + shg_cdiv(H, 64);
+        hipLaunchKernelGGL(conv_poly_strip_kernel, dim3(nseg * p.n_otiles * NB), dim3(256), 0, s, p, wt, (I + 31) / 32 * 32 * 9);
+        SHG_CHECK_LAUNCH();
+    }
+    return SHG_OK;
+}

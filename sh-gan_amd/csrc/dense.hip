@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* x, const float*
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0 && n < nb) {
             v = v * wgain + bias;
-            if (act) v = shg_lrelu_agc(v, alpha, gain, clamp);
+            v = act ? shg_lrelu_agc(v, alpha, gain, clamp) : v * gain;
             y[(long)(n0 + n) * ldy + o] = v;
         }
     }

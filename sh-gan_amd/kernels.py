@@ -118,16 +118,18 @@ class KernelTimer:
         ev.record(stream)
         return ev
 
-    def end(self, cls, start, work, stream):
+    def end(self, cls, start, work, stream, executed=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(stream)
-        self.records.setdefault(cls, []).append((start, ev, work))
+        self.records.setdefault(cls, []).append((start, ev, work, work if executed is None else executed))
 
     def summary(self):
-        """-> {class: dict(calls, ms, work)} ; call after torch.cuda.synchronize()."""
+        """-> {class: dict(calls, ms, work, executed)} ; call after torch.cuda.synchronize().  ``work`` = algorithmic
+        (direct-form) flops or bytes, ``executed`` = flops the matrix cores actually run (Winograd forms run fewer)."""
         out = {}
         for cls, recs in self.records.items():
-            out[cls] = dict(calls=len(recs), ms=sum(a.elapsed_time(b) for a, b, _ in recs), work=sum(w for _, _, w in recs))
+            out[cls] = dict(calls=len(recs), ms=sum(r[0].elapsed_time(r[1]) for r in recs), work=sum(r[2] for r in recs),
+                            executed=sum(r[3] for r in recs))
         return out
 
 
@@ -140,7 +142,7 @@ def set_timer(t):
 
 
 @contextlib.contextmanager
-def _timed(L, cls, work):
+def _timed(L, cls, work, executed=None):
     """``with _timed(L, 'class', work):`` -- device guard of the launch + (when a KernelTimer is installed) HIP events
     around it on the launch stream."""
     with L:
@@ -150,7 +152,7 @@ def _timed(L, cls, work):
             st = torch.cuda.current_stream(L.dev)
             t0 = _timer.begin(st)
             yield
-            _timer.end(cls, t0, work, st)
+            _timer.end(cls, t0, work, st, executed)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -295,11 +297,27 @@ def assemble_input(real, mask):
 class PreppedWeight:
     """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq).  ``wu`` (Winograd
     F(2x2,3x3) layout, shg_conv_weight_prep_wino_f32) is built on first use by a stride-1 3x3 convolution."""
-    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', '_w', '_wscale', '_flip')
+    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', 'wu_up', '_w', '_wscale', '_flip')
 
     def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1, w=None, wscale=None, flip=False):
         self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.groups = wt, wsq, o, i, op, kh, kw, groups
-        self.wu, self._w, self._wscale, self._flip = None, w, wscale, flip
+        self.wu, self.wu_up, self._w, self._wscale, self._flip = None, None, w, wscale, flip
+
+    def up_poly(self):
+        """(wu_a, wu_b): polyphase-Winograd weights of the stride-2 transposed convolution (shg_conv_weight_prep_up_poly_f32)."""
+        if self.wu_up is None:
+            if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
+                raise _lib.ShgError('PreppedWeight.up_poly: needs an ungrouped 3x3 weight')
+            L = _Launch()
+            w, ws = L.req(self._w, 'w'), L.req(self._wscale, 'wscale')
+            nchunk = (self.i + 7) // 8
+            size = (self.op // 64) * nchunk * 16 * 64 * 8
+            wa, wb = L.new((size,)), L.new((size,))
+            with L:
+                check(_lib.get_lib().shg_conv_weight_prep_up_poly_f32(_ptr(w), _ptr(ws), _ptr(wa), _ptr(wb), self.o, self.i, self.op,
+                                                                      int(bool(self._flip)), L.stream()), 'conv_weight_prep_up_poly')
+            self.wu_up = (wa, wb)
+        return self.wu_up
 
     def wino(self):
         if self.wu is None:
@@ -313,7 +331,6 @@ class PreppedWeight:
             with L:
                 check(_lib.get_lib().shg_conv_weight_prep_wino_f32(_ptr(w), _ptr(ws), _ptr(self.wu), self.o, self.i, self.op,
                                                                    int(bool(self._flip)), L.stream()), 'conv_weight_prep_wino')
-            self._w = None          # the transformed copy is all that is needed from here on
         return self.wu
 
 
@@ -344,6 +361,7 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
 # test set ``kernels.WINO = False`` to keep everything on the direct implicit-GEMM kernel.
 WINO = True
 WINO_MIN = 16
+UP_POLY = True          # stride-2 transposed 3x3 convolutions in the polyphase-Winograd form (conv_wino_poly.hip)
 
 MODE_SAME, MODE_DOWN2, MODE_UP2T = 0, 1, 2
 _CONV_CLASS = {MODE_SAME: 'conv_mfma_s1', MODE_DOWN2: 'conv_mfma_s2', MODE_UP2T: 'conv_mfma_up'}
@@ -379,10 +397,21 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
     if (WINO and mode == MODE_SAME and pad == 1 and pw.kh == 3 and pw.kw == 3 and pw.groups == 1 and h >= WINO_MIN and w >= WINO_MIN
             and w % 4 == 0 and x.data_ptr() % 16 == 0 and i <= 1024 and (pw.wu is not None or pw._w is not None)):
         wu = pw.wino()
-        with _timed(L, 'conv_wino', 2.0 * nb * pw.o * i * 9 * oh * ow):        # direct-form (algorithmic) flops
+        direct = 2.0 * nb * pw.o * i * 9 * oh * ow                                # direct-form (algorithmic) flops
+        with _timed(L, 'conv_wino', direct, direct * 16.0 / 36.0):
             check(lib.shg_conv2d_wino_f32(
                 _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise), nmode,
                 float(noise_strength), a, al, g, cl, _ptr(residual), L.stream()), 'conv2d_wino')
+        return y
+    if (UP_POLY and mode == MODE_UP2T and planar and pw.groups == 1 and pw._w is not None and out_scale is None and bias is None
+            and noise is None and residual is None and not act and gain == 1.0 and x.data_ptr() % 16 == 0
+            and lib.shg_conv2d_up_poly_supported(nb, i, pw.o, h, w)):
+        wa, wb = pw.up_poly()
+        nba, nbb = ((h + 1 + 2) // 3) * ((w + 1 + 2) // 3), (h // 2) * (w // 2)
+        executed = 2.0 * nb * pw.o * i * (16.0 * (nba + nbb) + h + w)
+        with _timed(L, 'conv_poly_up', 2.0 * nb * pw.o * i * 9 * h * w, executed):
+            check(lib.shg_conv2d_up_poly_f32(_ptr(x), _ptr(pw.wt), _ptr(wa), _ptr(wb), _ptr(y), nb, i, pw.o, pw.op, h, w,
+                                             _ptr(in_scale), L.stream()), 'conv2d_up_poly')
         return y
     ws, ws_bytes = None, 0
     if mode != MODE_UP2T or planar:      # split-K of the transposed conv is wired for the planar output only

@@ -260,3 +260,50 @@ def test_discriminator_forward_golden(mods):
         logits = D(torch.from_numpy(g[f'img{n}']).to(DEV), None)
         assert tuple(logits.shape) == (n, 1)
         assert rel_err(c(logits), g[f'logits{n}']) < 1e-4, n
+
+
+POLY_UP_CASES = [
+    # n, ci, co, h, w: ragged channel counts (I % 8, O % 64), several tiles per image, both tile shapes of both schemes
+    (2, 16, 64, 32, 32), (1, 13, 70, 34, 40), (2, 72, 130, 64, 64), (1, 8, 3, 32, 128), (3, 24, 24, 66, 36), (1, 128, 64, 128, 128),
+]
+
+
+def _interleave(planes, h, w):
+    """[4,N,O,H+1,W+1] phase planes -> [N,O,2H+1,2W+1]."""
+    _, n, o = planes.shape[:3]
+    full = torch.zeros((n, o, 2 * h + 1, 2 * w + 1), dtype=planes.dtype, device=planes.device)
+    for a in range(2):
+        for b in range(2):
+            full[:, :, a::2, b::2] = planes[a * 2 + b][:, :, :h + 1 - a, :w + 1 - b]
+    return full
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', POLY_UP_CASES)
+@pytest.mark.parametrize('flip', [False, True])
+def test_polyphase_winograd_transposed_conv(mods, n, ci, co, h, w, flip):
+    """shg_conv2d_up_poly_f32 (ee as F(3x3,2x2), eo/oe/oo with 16 multiplies per 2x2 block, strips) against torch CPU
+    conv_transpose2d and against the direct all-phase MFMA kernel, with per-sample input scales (styles)."""
+    import torch.nn.functional as F
+    kk = mods['kernels']
+    rs = np.random.RandomState(n * 100 + ci + co + h)
+    x, wt, s = rnd(rs, n, ci, h, w), rnd(rs, co, ci, 3, 3), torch.from_numpy(rs.rand(n, ci).astype(np.float32) + 0.5)
+    wref = wt.flip([2, 3]) if flip else wt
+    ref = F.conv_transpose2d(x * s[:, :, None, None], wref.transpose(0, 1), stride=2)
+    pw = kk.conv_weight_prep(wt.to(DEV), flip=flip)
+    old = kk.UP_POLY
+    try:
+        kk.UP_POLY = True
+        timer = kk.KernelTimer()
+        kk.set_timer(timer)
+        a = kk.conv2d(x.to(DEV), pw, mode=kk.MODE_UP2T, in_scale=s.to(DEV), planar=True)
+        kk.set_timer(None)
+        torch.cuda.synchronize()
+        assert 'conv_poly_up' in timer.summary()                   # the polyphase route really ran
+        kk.UP_POLY = False
+        b = kk.conv2d(x.to(DEV), pw, mode=kk.MODE_UP2T, in_scale=s.to(DEV), planar=True)
+    finally:
+        kk.UP_POLY = old
+        kk.set_timer(None)
+    fa, fb = _interleave(a, h, w), _interleave(b, h, w)
+    assert rel_err(c(fa), ref.numpy()) < 2e-5
+    assert rel_err(c(fa), c(fb)) < 2e-5
