@@ -35,15 +35,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) float shg_poly_zeros[64];   // zero source for LDS-DMA lanes that fall into padding
 
+struct PolySub {            // one scheme's share of a launch
+    const float* wu;         // transformed weights [OP/64][nchunk][16][64 lanes][KC]
+    int nby, nbx;            // blocks per image
+    int tiles_x, tiles_y;    // tiles per image (flat tiling: tiles_x runs of 64 consecutive blocks, tiles_y = 1)
+    int n_ttiles;            // tiles_x * tiles_y * NB
+};
 struct PolyParams {
     const float* x;          // [NB, I, H, W]
-    const float* wu;         // transformed weights [OP/64][nchunk][16][64 lanes][KC]
     float* y;                // phase planes [4][NB, O, H+1, W+1]
     const float* in_scale;   // [NB, I] or null
     int NB, I, O, OP, H, W;
-    int nby, nbx;            // blocks per image
-    int tiles_x, tiles_y;    // tiles per image
-    int n_ttiles, n_otiles, nchunk;
+    int n_otiles, nchunk;
+    PolySub a, b;            // scheme UA / UB; workgroups [0, a.n_ttiles*n_otiles) run UA, the rest UB
 };
 
 namespace poly {
@@ -55,13 +59,18 @@ constexpr int NXF = KC;
 // Scheme UA: 3x3 output blocks of the `ee` plane from 4x4 input patches.  Scheme UB: 2x2 blocks of eo / oe / oo from 3x3 patches.
 enum { UA = 0, UB = 1 };
 
-template <int SCHEME, int TY, int TX>
+// Tile = 64 blocks.  Rectangular (NBX = 0): TY x TX blocks.  Flat (scheme UA, NBX = blocks per image row, a compile-time
+// constant): 64 CONSECUTIVE blocks of the row-major block list of one image -- a grid of 22 x 22 blocks (65 x 65 phase
+// plane) then costs 8 tiles per image instead of the 9 of an 8 x 8 tiling, and its window spans the image width.
+template <int SCHEME, int TY, int TX, int NBX>
 struct Geo {
-    static_assert(TY * TX == BT, "64 blocks per tile");
+    static_assert(NBX > 0 || TY * TX == BT, "64 blocks per tile");
+    static_assert(NBX == 0 || SCHEME == UA, "flat tiling is for the 3x3 blocks of scheme UA");
     static constexpr int BS = SCHEME == UA ? 3 : 2;                    // block edge in phase-plane pixels
-    static constexpr int PH = SCHEME == UA ? 3 * TY + 1 : 2 * TY + 1;  // window rows
+    static constexpr int RMAX = NBX ? (NBX - 1 + BT + NBX - 1) / NBX : TY;                 // block rows a tile can touch
+    static constexpr int PH = SCHEME == UA ? 3 * RMAX + 1 : 2 * TY + 1;                    // window rows
     // window columns: 16-byte aligned start at or before the first needed column, rounded up to whole float4
-    static constexpr int PW = SCHEME == UA ? ((3 * TX + 1 + 3 + 3) / 4) * 4 : 2 * TX + 4;
+    static constexpr int PW = SCHEME == UA ? ((3 * (NBX ? NBX : TX) + 1 + 3 + 3) / 4) * 4 : 2 * TX + 4;
     static constexpr int PW4 = PW / 4, PATCH4 = PH * PW4, RP = PH * PW, R_SZ = KC * RP;
     static constexpr int NPIECE = (PATCH4 + 63) / 64;
 };
@@ -74,26 +83,27 @@ __device__ __forceinline__ int poly_xcd_remap(int bid, int total) {
     return base + idx;
 }
 
-template <int SCHEME, int TY, int TX>
-__global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
+template <int SCHEME, int TY, int TX, int NBX>
+__device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q, const int bid, float* __restrict__ Vl,
+                                          float* __restrict__ Rl) {
     using namespace poly;
-    using G = Geo<SCHEME, TY, TX>;
+    using G = Geo<SCHEME, TY, TX, NBX>;
     constexpr int PW = G::PW, PW4 = G::PW4, PATCH4 = G::PATCH4, RP = G::RP, R_SZ = G::R_SZ, BS = G::BS, NPIECE = G::NPIECE;
-    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
-    __shared__ __attribute__((aligned(16))) float Rl[2 * R_SZ];      // [2][KC][RP]
+    constexpr bool FLAT = NBX > 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int nwork = p.n_ttiles * p.n_otiles;
-    const int work = poly_xcd_remap(blockIdx.x, nwork);
-    const int otile = work / p.n_ttiles;
-    const int ttile = work - otile * p.n_ttiles;
-    const int txb = ttile % p.tiles_x;
-    const int tyb = (ttile / p.tiles_x) % p.tiles_y;
-    const int n = ttile / (p.tiles_x * p.tiles_y);
-    const int by0 = tyb * TY, bx0 = txb * TX;            // first block of the tile
+    const int nwork = q.n_ttiles * p.n_otiles;
+    const int work = poly_xcd_remap(bid, nwork);
+    const int otile = work / q.n_ttiles;
+    const int ttile = work - otile * q.n_ttiles;
+    const int txb = ttile % q.tiles_x;
+    const int tyb = (ttile / q.tiles_x) % q.tiles_y;
+    const int n = ttile / (q.tiles_x * q.tiles_y);
+    const int id0 = txb * BT;                            // flat: first block id of the tile
+    const int by0 = FLAT ? id0 / (NBX ? NBX : 1) : tyb * TY, bx0 = FLAT ? 0 : txb * TX;      // first block row / column of the window
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
     // window origin in the low-resolution image: both schemes read rows / columns BS*b - 1 ... ; the column start is
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
     };
 
     constexpr int NU = KC / 4;
-    const f32x4* ubase = reinterpret_cast<const f32x4*>(p.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(q.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
     const size_t ustride = (size_t)16 * 64 * KC / 4;
     f32x4 ua[NU], ub[NU];
     auto load_u = [&](f32x4 (&dst)[NU], int c) __attribute__((always_inline)) {
@@ -142,7 +152,8 @@ __global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
     };
 
     // ---- input transform role: channel `wave`, block `lane`
-    const int tty = lane / TX, ttx = lane % TX;
+    const int tty = FLAT ? (id0 + lane) / (NBX ? NBX : 1) - by0 : lane / TX;
+    const int ttx = FLAT ? (id0 + lane) % (NBX ? NBX : 1) : lane % TX;
     const float* rbase = Rl + wave * RP + (BS * tty) * PW + BS * ttx + coff;
     float* vbase = Vl + wave * BT + lane;
     float scv[2];
@@ -281,9 +292,9 @@ __global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) m[xi] = Mx[(xi * 32 + o_l) * 32 + t_l];
         const int t = tb * 32 + t_l;
-        const int by = by0 + t / TX, bx = bx0 + t % TX;
+        const int by = FLAT ? (id0 + t) / (NBX ? NBX : 1) : by0 + t / TX, bx = FLAT ? (id0 + t) % (NBX ? NBX : 1) : bx0 + t % TX;
         const int o = o0 + ob * 32 + o_l;
-        if (o < p.O && by < p.nby && bx < p.nbx) {
+        if (o < p.O && by < q.nby && bx < q.nbx) {
             float* yb = p.y + ((long)n * p.O + o) * plane;             // + phase * NB*O*plane
             const long pstride = (long)p.NB * p.O * plane;
             if constexpr (SCHEME == UA) {
@@ -328,6 +339,22 @@ __global__ __launch_bounds__(1024) void conv_poly_kernel(const PolyParams p) {
     }
 }
 
+// One launch runs both schemes: workgroups [0, nA) take UA tiles, the rest UB tiles -- a single tail round instead of two.
+// LDS: two separate objects (the compiler then knows that the LDS-DMA into the raw windows cannot alias the operand reads
+// from V, and parks no `s_waitcnt vmcnt(0)` in front of a chunk's MFMAs), sized for the larger scheme.
+template <int ATY, int ATX, int ANBX>
+__global__ __launch_bounds__(1024) void conv_poly_up_kernel(const PolyParams p) {
+    using namespace poly;
+    using GA = Geo<UA, ATY, ATX, ANBX>;
+    using GB = Geo<UB, 4, 16, 0>;
+    constexpr int R_MAX = GA::R_SZ > GB::R_SZ ? GA::R_SZ : GB::R_SZ;
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
+    __shared__ __attribute__((aligned(16))) float Rl[2 * R_MAX];     // [2][KC][RP]
+    const int nA = p.a.n_ttiles * p.n_otiles;
+    if ((int)blockIdx.x < nA) poly_body<UA, ATY, ATX, ANBX>(p, p.a, blockIdx.x, Vl, Rl);
+    else poly_body<UB, 4, 16, 0>(p, p.b, blockIdx.x - nA, Vl, Rl);
+}
+
 // The one-pixel strips the 2x2 body blocks of scheme UB do not reach: eo[H, v] = w[2][1] . x[H-1, v] (v < W) and
 // oe[u, W] = w[1][2] . x[u, W-1] (u < H): two single-tap contractions over the input channels along one image row /
 // column.  One workgroup (4 waves) = 64 output channels x 64 strip positions of one image; operands straight from
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(256) void conv_poly_strip_kernel(const PolyParams p
     const int wo = wave >> 1, wp = wave & 1;
     const int nseg_r = (p.W + 63) / 64, nseg_c = (p.H + 63) / 64;
     int seg = blockIdx.x % (nseg_r + nseg_c);
-    const int otile = (blockIdx.x / (nseg_r + nseg_c)) % p.n_otiles;
+    const int otile = (blockIdx.x / (nseg_r + nseg_c)) % p.n_otiles;      // (strips: the GEMM-layout weights, not U)
     const int n = blockIdx.x / ((nseg_r + nseg_c) * p.n_otiles);
     const bool col = seg >= nseg_r;
     if (col) seg -= nseg_r;
@@ -353,13 +380,20 @@ __global__ __launch_bounds__(256) void conv_poly_strip_kernel(const PolyParams p
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int i0 = 0; i0 < p.I; i0 += 2) {
-        const int i = min(i0 + half, p.I - 1);
-        const float a = (i0 + half < p.I) ? wb[(long)i * 9 * 64] : 0.f;
-        float bv = pok ? xb[(long)i * HW] : 0.f;
-        if (sb) bv *= sb[i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    // 16 channels per step: all operand loads of a step are issued before its MFMAs (the loop is latency bound otherwise)
+    for (int i0 = 0; i0 < p.I; i0 += 16) {
+        float a[8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ic = i0 + 2 * k + half;
+            const int i = min(ic, p.I - 1);
+            a[k] = wb[(long)i * 9 * 64];
+            bv[k] = xb[(long)i * HW];
+            if (sb) bv[k] *= sb[i];
+            if (ic >= p.I || !pok) { a[k] = 0.f; bv[k] = 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv[k], acc, 0, 0, 0);
     }
     if (!pok) return;
     const int PWg = p.W + 1;
@@ -458,27 +492,26 @@ extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const flo
     p.x = x; p.y = y; p.in_scale = in_scale;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
     p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
-    // scheme UB: 2x2 body blocks
-    {
-        p.wu = wu_b; p.nby = H / 2; p.nbx = W / 2;
-        const bool wide = p.nbx >= 16;
-        p.tiles_x = shg_cdiv(p.nbx, wide ? 16 : 8); p.tiles_y = shg_cdiv(p.nby, wide ? 4 : 8);
-        p.n_ttiles = p.tiles_x * p.tiles_y * NB;
-        if (wide) hipLaunchKernelGGL((conv_poly_kernel<poly::UB, 4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
-        else hipLaunchKernelGGL((conv_poly_kernel<poly::UB, 8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
-        SHG_CHECK_LAUNCH();
-    }
-    // scheme UA: 3x3 blocks of the ee plane; tile shape by padding waste
-    {
-        p.wu = wu_a; p.nby = shg_cdiv(H + 1, 3); p.nbx = shg_cdiv(W + 1, 3);
-        const long w88 = (long)shg_cdiv(p.nbx, 8) * shg_cdiv(p.nby, 8), w416 = (long)shg_cdiv(p.nbx, 16) * shg_cdiv(p.nby, 4);
-        const bool wide = w416 < w88;
-        p.tiles_x = shg_cdiv(p.nbx, wide ? 16 : 8); p.tiles_y = shg_cdiv(p.nby, wide ? 4 : 8);
-        p.n_ttiles = p.tiles_x * p.tiles_y * NB;
-        if (wide) hipLaunchKernelGGL((conv_poly_kernel<poly::UA, 4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
-        else hipLaunchKernelGGL((conv_poly_kernel<poly::UA, 8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(poly::NT), 0, s, p);
-        SHG_CHECK_LAUNCH();
-    }
+    // scheme UB: 2x2 body blocks, 4 x 16 blocks per tile (W >= 32)
+    p.b.wu = wu_b; p.b.nby = H / 2; p.b.nbx = W / 2;
+    p.b.tiles_x = shg_cdiv(p.b.nbx, 16); p.b.tiles_y = shg_cdiv(p.b.nby, 4);
+    p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
+    // scheme UA: 3x3 blocks of the ee plane; flat tiling for the block-row lengths of the generator's layers, else the
+    // rectangular tile shape with the smaller padding waste
+    p.a.wu = wu_a; p.a.nby = shg_cdiv(H + 1, 3); p.a.nbx = shg_cdiv(W + 1, 3);
+    const bool flat = p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43;
+    const long w88 = (long)shg_cdiv(p.a.nbx, 8) * shg_cdiv(p.a.nby, 8), w416 = (long)shg_cdiv(p.a.nbx, 16) * shg_cdiv(p.a.nby, 4);
+    const bool wide = w416 < w88;
+    if (flat) { p.a.tiles_x = shg_cdiv(p.a.nby * p.a.nbx, 64); p.a.tiles_y = 1; }
+    else { p.a.tiles_x = shg_cdiv(p.a.nbx, wide ? 16 : 8); p.a.tiles_y = shg_cdiv(p.a.nby, wide ? 4 : 8); }
+    p.a.n_ttiles = p.a.tiles_x * p.a.tiles_y * NB;
+    const dim3 grid((p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles);
+    if (flat && p.a.nbx == 11) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 11>), grid, dim3(poly::NT), 0, s, p);
+    else if (flat && p.a.nbx == 22) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 22>), grid, dim3(poly::NT), 0, s, p);
+    else if (flat) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43>), grid, dim3(poly::NT), 0, s, p);
+    else if (wide) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0>), grid, dim3(poly::NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0>), grid, dim3(poly::NT), 0, s, p);
+    SHG_CHECK_LAUNCH();
     // strips
     {
         const int nseg = shg_cdiv(W, 64) + shg_cdiv(H, 64);
