@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # dense fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; 6.3 TB/s is what a float4 copy reaches (same guide)
 GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MAC), whole forward, direct form
-WINO_EXECUTED = 16.0 / 36.0                        # F(2x2,3x3): multiplies per 2x2 outputs vs the direct form
 
 
 def pmc_traffic(resolution, batch, kernel='conv_wino_kernel'):
@@ -197,15 +196,15 @@ def worker(local_rank, a, spawned_world=None, port=None):
         ms = dt / a.steps * 1e3
         ips = world * batch * a.steps / dt
 
-        def cls_conv(name, executed_factor):
+        def cls_conv(name):
             d = tsum.get(name)
             if not d or d['ms'] <= 0:
                 return None
             sec = d['ms'] * 1e-3
             return {'launches_per_step': d['calls'] // psteps, 'ms_per_step': round(d['ms'] / psteps, 3),
                     'avg_launch_us': round(d['ms'] / d['calls'] * 1e3, 1),
-                    'executed_tflops': round(d['work'] * executed_factor / sec / 1e12, 2),
-                    'frac_of_fp32_mfma_peak': round(d['work'] * executed_factor / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'executed_tflops': round(d['executed'] / sec / 1e12, 2),
+                    'frac_of_fp32_mfma_peak': round(d['executed'] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                     'direct_form_tflops': round(d['work'] / sec / 1e12, 2)}
 
         def cls_hbm(name):
@@ -217,22 +216,18 @@ def worker(local_rank, a, spawned_world=None, port=None):
                     'algorithmic_GB_per_step': round(d['work'] / psteps / 1e9, 3), 'achieved_GBps': round(gbs, 1),
                     'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)}
 
-        conv = {k: v for k, v in (('conv_wino', cls_conv('conv_wino', WINO_EXECUTED)),
-                                  ('conv_mfma_s2', cls_conv('conv_mfma_s2', 1.0)),
-                                  ('conv_mfma_up', cls_conv('conv_mfma_up', 1.0)),
-                                  ('conv_mfma_s1', cls_conv('conv_mfma_s1', 1.0)),
-                                  ('conv_mfma_1x1', cls_conv('conv_mfma_1x1', 1.0))) if v}
+        conv = {k: v for k, v in ((n_, cls_conv(n_)) for n_ in sorted(tsum) if n_.startswith('conv_')) if v}
         hbm = {k: v for k, v in ((n, cls_hbm(n)) for n in ('upfirdn2d', 'fir_up_planar', 'torgb', 'fromrgb', 'shu', 'composite_u8'))
                if v}
         conv_ms = sum(tsum[k]['ms'] for k in tsum if k.startswith('conv_'))
-        conv_exec = sum(tsum[k]['work'] * (WINO_EXECUTED if k == 'conv_wino' else 1.0) for k in tsum if k.startswith('conv_'))
+        conv_exec = sum(tsum[k]['executed'] for k in tsum if k.startswith('conv_'))
         conv_alg = sum(tsum[k]['work'] for k in tsum if k.startswith('conv_'))
         dom = conv.get('conv_wino')
         traffic, traffic_src = pmc_traffic(res, batch)
         roof = {'bound': 'mfma', 'kernel': 'conv_wino_kernel (Winograd F(2x2,3x3) 3x3 stride-1 layers, the largest share of a step)',
                 'achieved': dom['executed_tflops'] if dom else None, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': dom['frac_of_fp32_mfma_peak'] if dom else None,
-                'definition': 'flops executed on the matrix cores (16/36 of the direct-form flops) / HIP-event time of the '
+                'definition': 'flops executed on the matrix cores (Winograd F(2x2,3x3): 16/36 of the direct-form flops) / HIP-event time of the '
                               'launches in the instrumented pass / dense fp32 MFMA peak',
                 'avg_launch_us': dom['avg_launch_us'] if dom else None,
                 'direct_form_tflops': dom['direct_form_tflops'] if dom else None,

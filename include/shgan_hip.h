@@ -95,7 +95,7 @@ int shg_upfir_planar_f32(const float* mid, const float* f, float* y, int N, int 
  * 9 multiplies per low-resolution pixel, same result up to fp32 round-off.  y [4][NB,O,H+1,W+1] raw phase planes (no
  * epilogue operands: the consumer is shg_upfir_planar_f32).  wt / wscale from shg_conv_weight_prep_f32; wu_a, wu_b:
  * [OP/64][ceil(I/8)][16][64][8] floats each.  shg_conv2d_up_poly_supported tells whether the geometry is served
- * (H >= 32, H even, W % 4 == 0); otherwise call shg_conv2d_f32. */
+ * (H, W >= 16, H even, W % 4 == 0); otherwise call shg_conv2d_f32. */
 int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP, int flip,
                                      void* stream);
 int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W);

@@ -15,7 +15,7 @@
 //              F(2x2,3x3); G = [[1,0],[.5,.5],[.5,-.5],[0,1]], A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]);
 //   scheme UB: `eo`, `oe`, `oo` of a 2x2 block from its 3x3 input patch with 6 + 6 + 4 = 16 multiplies
 //              (F(2,2) along the 2-tap axis: m1 = (d0-d1) g1, m2 = d1 (g0+g1), m3 = (d2-d1) g0; y0 = m1+m2, y1 = m2+m3);
-//   the row u = H of `eo` and the column v = W of `oe` (one pixel thick) come from strip_kernel below.
+//   the row u = H of `eo` and the column v = W of `oe` (one pixel thick) come from the strip tiles (poly_strip_body).
 // Together (16/9 + 4) = 5.8 multiplies per low-resolution pixel instead of 9: 1.56x fewer MFMA flops, still exact fp32
 // MFMA arithmetic with transform constants 0, +-1, +-1/2.
 //
@@ -47,7 +47,9 @@ struct PolyParams {
     const float* in_scale;   // [NB, I] or null
     int NB, I, O, OP, H, W;
     int n_otiles, nchunk;
-    PolySub a, b;            // scheme UA / UB; workgroups [0, a.n_ttiles*n_otiles) run UA, the rest UB
+    PolySub a, b;            // scheme UA / UB; workgroups [0, a.n_ttiles*n_otiles) run UA, the next b.n_ttiles*n_otiles UB
+    const float* wt;         // GEMM-layout weights [OP/64][IPK][64] (strips); workgroups past UA + UB run four strip tiles each
+    int IPK, n_strip_tiles;
 };
 
 namespace poly {
@@ -339,71 +341,90 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     }
 }
 
-// One launch runs both schemes: workgroups [0, nA) take UA tiles, the rest UB tiles -- a single tail round instead of two.
-// LDS: two separate objects (the compiler then knows that the LDS-DMA into the raw windows cannot alias the operand reads
-// from V, and parks no `s_waitcnt vmcnt(0)` in front of a chunk's MFMAs), sized for the larger scheme.
-template <int ATY, int ATX, int ANBX>
-__global__ __launch_bounds__(1024) void conv_poly_up_kernel(const PolyParams p) {
-    using namespace poly;
-    using GA = Geo<UA, ATY, ATX, ANBX>;
-    using GB = Geo<UB, 4, 16, 0>;
-    constexpr int R_MAX = GA::R_SZ > GB::R_SZ ? GA::R_SZ : GB::R_SZ;
-    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
-    __shared__ __attribute__((aligned(16))) float Rl[2 * R_MAX];     // [2][KC][RP]
-    const int nA = p.a.n_ttiles * p.n_otiles;
-    if ((int)blockIdx.x < nA) poly_body<UA, ATY, ATX, ANBX>(p, p.a, blockIdx.x, Vl, Rl);
-    else poly_body<UB, 4, 16, 0>(p, p.b, blockIdx.x - nA, Vl, Rl);
-}
-
+// One launch runs everything: workgroups [0, nA) take UA tiles, the next nB UB tiles, the last few four strip tiles each
+// -- a single tail round instead of three.  LDS: two separate objects (the compiler then knows that the LDS-DMA into the
+// raw windows cannot alias the operand reads from V, and parks no `s_waitcnt vmcnt(0)` in front of a chunk's MFMAs),
+// sized for the larger scheme.
 // The one-pixel strips the 2x2 body blocks of scheme UB do not reach: eo[H, v] = w[2][1] . x[H-1, v] (v < W) and
 // oe[u, W] = w[1][2] . x[u, W-1] (u < H): two single-tap contractions over the input channels along one image row /
-// column.  One workgroup (4 waves) = 64 output channels x 64 strip positions of one image; operands straight from
-// global memory (wt is the GEMM layout of shg_conv_weight_prep_f32: [OP/64][IP*9][64], row = i*9 + tap).
-__global__ __launch_bounds__(256) void conv_poly_strip_kernel(const PolyParams p, const float* wt, int IPK) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// column -- a tiny, latency-bound problem.  One strip tile (4 waves) = 32 output channels x 32 strip positions of one
+// image; the four waves split the input channels and add their partial tiles through LDS, every wave keeps 32 operand
+// loads in flight.  Strip tiles ride in the tail of the main launch, four per 16-wave workgroup.  Operands come straight from global memory (wt is the GEMM layout of shg_conv_weight_prep_f32:
+// [OP/64][IP*9][64], row = i*9 + tap).
+__device__ __forceinline__ void poly_strip_body(const PolyParams& p, const int tile, const int wave, float* __restrict__ redbuf) {
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(redbuf);      // [4][16][64] of this strip tile
+    const float* wt = p.wt;
+    const int IPK = p.IPK;
+    const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wo = wave >> 1, wp = wave & 1;
-    const int nseg_r = (p.W + 63) / 64, nseg_c = (p.H + 63) / 64;
-    int seg = blockIdx.x % (nseg_r + nseg_c);
-    const int otile = (blockIdx.x / (nseg_r + nseg_c)) % p.n_otiles;      // (strips: the GEMM-layout weights, not U)
-    const int n = blockIdx.x / ((nseg_r + nseg_c) * p.n_otiles);
+    const int nseg_r = (p.W + 31) / 32, nseg_c = (p.H + 31) / 32;
+    const int no32 = p.OP / 32;
+    const bool live = tile < p.n_strip_tiles;                 // (a dead tile still takes part in the barrier)
+    int seg = tile % (nseg_r + nseg_c);
+    const int ot32 = (tile / (nseg_r + nseg_c)) % no32;
+    const int n = live ? tile / ((nseg_r + nseg_c) * no32) : 0;
     const bool col = seg >= nseg_r;
     if (col) seg -= nseg_r;
     const int len = col ? p.H : p.W;
-    const int pos = seg * 64 + wp * 32 + l31;                 // strip position of this lane's B column
+    const int pos = seg * 32 + l31;                           // strip position of this lane's B column
     const int tap = col ? 1 * 3 + 2 : 2 * 3 + 1;
     const int HW = p.H * p.W;
-    const bool pok = pos < len;
+    const bool pok = live && pos < len;
     const float* xb = p.x + (long)n * p.I * HW + (pok ? (col ? pos * p.W + p.W - 1 : (p.H - 1) * p.W + pos) : 0);
-    const float* wb = wt + ((long)otile * IPK + tap) * 64 + wo * 32 + l31;     // + i*9*64
+    const float* wb = wt + ((long)(ot32 >> 1) * IPK + tap) * 64 + (ot32 & 1) * 32 + l31;     // + i*9*64
     const float* sb = p.in_scale ? p.in_scale + (long)n * p.I : nullptr;
+    const int kper = ((p.I + 7) / 8) * 2;                     // channels per wave (even)
+    const int kbeg = wave * kper, kend = min(p.I, kbeg + kper);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // 16 channels per step: all operand loads of a step are issued before its MFMAs (the loop is latency bound otherwise)
-    for (int i0 = 0; i0 < p.I; i0 += 16) {
-        float a[8], bv[8];
+    for (int i0 = kbeg; i0 < kend; i0 += 32) {
+        float a[16], bv[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const int ic = i0 + 2 * k + half;
             const int i = min(ic, p.I - 1);
             a[k] = wb[(long)i * 9 * 64];
             bv[k] = xb[(long)i * HW];
             if (sb) bv[k] *= sb[i];
-            if (ic >= p.I || !pok) { a[k] = 0.f; bv[k] = 0.f; }
+            if (ic >= kend) a[k] = 0.f;                   // (a lane's A operand belongs to output channel l31, its B operand to
+            if (ic >= kend || !pok) bv[k] = 0.f;          //  strip position l31: only B is masked by the position)
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv[k], acc, 0, 0, 0);
+        for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv[k], acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // thread (wave, lane) finishes registers 4*wave .. 4*wave+3 of lane `lane`
     if (!pok) return;
     const int PWg = p.W + 1;
     const long plane = (long)(p.H + 1) * PWg;
     const long pix = col ? (long)pos * PWg + p.W : (long)p.H * PWg + pos;
     float* yb = p.y + (long)(col ? 2 : 1) * p.NB * p.O * plane + (long)n * p.O * plane + pix;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = otile * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < p.O) yb[(long)o * plane] = acc[r];
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+        const int o = ot32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.O) yb[(long)o * plane] = v;
+    }
+}
+
+template <int ATY, int ATX, int ANBX, int BTY, int BTX>
+__global__ __launch_bounds__(1024) void conv_poly_up_kernel(const PolyParams p) {
+    using namespace poly;
+    using GA = Geo<UA, ATY, ATX, ANBX>;
+    using GB = Geo<UB, BTY, BTX, 0>;
+    constexpr int R_MAX = GA::R_SZ > GB::R_SZ ? GA::R_SZ : GB::R_SZ;
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][16][KC][64]
+    __shared__ __attribute__((aligned(16))) float Rl[2 * R_MAX];     // [2][KC][RP]
+    const int nA = p.a.n_ttiles * p.n_otiles, nB = p.b.n_ttiles * p.n_otiles;
+    if ((int)blockIdx.x < nA) poly_body<UA, ATY, ATX, ANBX>(p, p.a, blockIdx.x, Vl, Rl);
+    else if ((int)blockIdx.x < nA + nB) poly_body<UB, BTY, BTX, 0>(p, p.b, blockIdx.x - nA, Vl, Rl);
+    else {
+        const int wave = threadIdx.x >> 6;
+        poly_strip_body(p, (blockIdx.x - nA - nB) * 4 + (wave >> 2), wave & 3, Vl + (wave >> 2) * 4 * 16 * 64);
     }
 }
 
@@ -474,7 +495,7 @@ extern "C" int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wsc
 
 // 1 when shg_conv2d_up_poly_f32 handles this geometry (otherwise use shg_conv2d_f32 mode 2, out_mode 1)
 extern "C" int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W) {
-    return (H >= 32 && W >= 32 && H % 2 == 0 && W % 4 == 0 && I <= 128 * poly::KC && NB >= 1 && O >= 1) ? 1 : 0;
+    return (H >= 16 && W >= 16 && H % 2 == 0 && W % 4 == 0 && I <= 128 * poly::KC && NB >= 1 && O >= 1) ? 1 : 0;
 }
 
 // Phase planes of the stride-2 transposed 3x3 convolution of x * in_scale[n,i]: y [4][NB,O,H+1,W+1] (same contract as
@@ -492,31 +513,30 @@ extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const flo
     p.x = x; p.y = y; p.in_scale = in_scale;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
     p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
-    // scheme UB: 2x2 body blocks, 4 x 16 blocks per tile (W >= 32)
+    // scheme UB: 2x2 body blocks, 4 x 16 blocks per tile (8 x 8 for images narrower than 32)
+    const bool bwide = W >= 32;
     p.b.wu = wu_b; p.b.nby = H / 2; p.b.nbx = W / 2;
-    p.b.tiles_x = shg_cdiv(p.b.nbx, 16); p.b.tiles_y = shg_cdiv(p.b.nby, 4);
+    p.b.tiles_x = shg_cdiv(p.b.nbx, bwide ? 16 : 8); p.b.tiles_y = shg_cdiv(p.b.nby, bwide ? 4 : 8);
     p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
     // scheme UA: 3x3 blocks of the ee plane; flat tiling for the block-row lengths of the generator's layers, else the
     // rectangular tile shape with the smaller padding waste
     p.a.wu = wu_a; p.a.nby = shg_cdiv(H + 1, 3); p.a.nbx = shg_cdiv(W + 1, 3);
-    const bool flat = p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43;
+    const bool flat = bwide && (p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43);
     const long w88 = (long)shg_cdiv(p.a.nbx, 8) * shg_cdiv(p.a.nby, 8), w416 = (long)shg_cdiv(p.a.nbx, 16) * shg_cdiv(p.a.nby, 4);
-    const bool wide = w416 < w88;
+    const bool wide = bwide && w416 < w88;
     if (flat) { p.a.tiles_x = shg_cdiv(p.a.nby * p.a.nbx, 64); p.a.tiles_y = 1; }
     else { p.a.tiles_x = shg_cdiv(p.a.nbx, wide ? 16 : 8); p.a.tiles_y = shg_cdiv(p.a.nby, wide ? 4 : 8); }
     p.a.n_ttiles = p.a.tiles_x * p.a.tiles_y * NB;
-    const dim3 grid((p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles);
-    if (flat && p.a.nbx == 11) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 11>), grid, dim3(poly::NT), 0, s, p);
-    else if (flat && p.a.nbx == 22) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 22>), grid, dim3(poly::NT), 0, s, p);
-    else if (flat) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43>), grid, dim3(poly::NT), 0, s, p);
-    else if (wide) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0>), grid, dim3(poly::NT), 0, s, p);
-    else hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0>), grid, dim3(poly::NT), 0, s, p);
+    // strips: tiles of 32 channels x 32 positions, four per workgroup
+    p.wt = wt; p.IPK = (I + 31) / 32 * 32 * 9;
+    p.n_strip_tiles = (shg_cdiv(W, 32) + shg_cdiv(H, 32)) * (OP / 32) * NB;
+    const dim3 grid((p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles + shg_cdiv(p.n_strip_tiles, 4));
+    if (!bwide) hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 8, 8>), grid, dim3(poly::NT), 0, s, p);
+    else if (flat && p.a.nbx == 11) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 11, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (flat && p.a.nbx == 22) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 22, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (flat) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (wide) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
     SHG_CHECK_LAUNCH();
-    // strips
-    {
-        const int nseg = shg_cdiv(W, 64) + shg_cdiv(H, 64);
-        hipLaunchKernelGGL(conv_poly_strip_kernel, dim3(nseg * p.n_otiles * NB), dim3(256), 0, s, p, wt, (I + 31) / 32 * 32 * 9);
-        SHG_CHECK_LAUNCH();
-    }
     return SHG_OK;
 }
