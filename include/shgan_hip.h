@@ -101,6 +101,18 @@ int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wscale, float*
 int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W);
 int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O,
                            int OP, int H, int W, const float* in_scale, void* stream);
+/* Polyphase-Winograd form of the FIR-filtered stride-2 3x3 convolution (conv2d_resample.py:116-120), same reduction of the
+ * multiply count.  shg_fir_down_planar_f32 applies the 4x4 pre-filter (padding 2) to x [N,C,H,W] and writes the (H+1)x(W+1)
+ * result as its four polyphase planes xp [4][N*C][H/2+1][PP] (PP = a multiple of 4 >= W/2+1); shg_conv2d_down_poly_f32 then
+ * computes y [NB,O,OH,OW] = act(conv3x3_stride2 + bias)*gain + residual (OH = H/2, OW = W/2; OH, OW >= 16, OW % 4 == 0). */
+int shg_fir_down_planar_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int PP, int flip, float gain,
+                            void* stream);
+int shg_conv_weight_prep_down_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP, int flip,
+                                       void* stream);
+int shg_conv2d_down_poly_supported(int NB, int I, int O, int OH, int OW);
+int shg_conv2d_down_poly_f32(const float* xp, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O, int OP, int OH,
+                             int OW, int PP, const float* in_scale, const float* bias, int act, float alpha, float gain,
+                             float clamp, const float* residual, void* stream);
 /* 1x1 convolution with I <= 8 input channels (encoder fromrgb, stylegan.py:640-642): y = act(W*wgain @ x + bias). */
 int shg_conv1x1_thin_in_f32(const float* x, const float* w, const float* bias, float* y, int N, int I, int O, int HW, float wgain,
                             int act, float alpha, float gain, float clamp, void* stream);

@@ -25,6 +25,15 @@
 // double buffering with one barrier per 8-channel chunk, MFMA stream skewed one k-step across the barrier, exchange
 // epilogue through LDS.  Output: raw phase planes [4][NB,O,H+1,W+1] for shg_upfir_planar_f32 (which applies the 4x4
 // FIR of conv2d_resample.py:138, the demodulation coefficient and the layer tail).
+//
+// The stride-2 3x3 convolution of the "down" layers (conv2d_resample.py:116-120, after its FIR pre-filter) is the
+// transpose of the above and gets the same treatment on the four polyphase planes P_ab[u,v] = xf[2u+a, 2v+b] of the
+// filtered input (written in that layout by shg_fir_down_planar_f32):
+//      y[p,q] = sum_{ky,kx in {0,2}} w[ky][kx] P_ee[p+ky/2, q+kx/2] + sum_{ky in {0,2}} w[ky][1] P_eo[p+ky/2, q]
+//             + sum_{kx in {0,2}} w[1][kx] P_oe[p, q+kx/2] + w[1][1] P_oo[p,q]
+//   scheme DA: the P_ee term as F(3x3,2x2) -> raw partial sums in y;
+//   scheme DB: the other three terms of a 2x2 output block with 16 multiplies, added to the partial sums, then the
+//              fused layer tail (bias, lrelu_agc, gain, skip).  Two launches (DB consumes DA's output).
 #include "shg_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -50,6 +59,12 @@ struct PolyParams {
     PolySub a, b;            // scheme UA / UB; workgroups [0, a.n_ttiles*n_otiles) run UA, the next b.n_ttiles*n_otiles UB
     const float* wt;         // GEMM-layout weights [OP/64][IPK][64] (strips); workgroups past UA + UB run four strip tiles each
     int IPK, n_strip_tiles;
+    // down schemes: x = polyphase planes [4][NB, I, PH2, PP] (PP % 4 == 0), y = [NB, O, H, W] with H, W the OUTPUT extent
+    int PH2, PP;
+    const float* bias;       // [O] or null
+    const float* residual;   // like y, added after the activation, or null
+    int act;
+    float alpha, gain, clamp;
 };
 
 namespace poly {
@@ -59,21 +74,29 @@ constexpr int NT = 1024;
 constexpr int NXF = KC;
 
 // Scheme UA: 3x3 output blocks of the `ee` plane from 4x4 input patches.  Scheme UB: 2x2 blocks of eo / oe / oo from 3x3 patches.
-enum { UA = 0, UB = 1 };
+// DA / DB: the same for the stride-2 convolution, on the polyphase planes of the filtered input.
+enum { UA = 0, UB = 1, DA = 2, DB = 3 };
 
 // Tile = 64 blocks.  Rectangular (NBX = 0): TY x TX blocks.  Flat (scheme UA, NBX = blocks per image row, a compile-time
 // constant): 64 CONSECUTIVE blocks of the row-major block list of one image -- a grid of 22 x 22 blocks (65 x 65 phase
 // plane) then costs 8 tiles per image instead of the 9 of an 8 x 8 tiling, and its window spans the image width.
 template <int SCHEME, int TY, int TX, int NBX>
 struct Geo {
+    static constexpr bool A = SCHEME == UA || SCHEME == DA;             // 3x3 blocks from 4x4 patches
     static_assert(NBX > 0 || TY * TX == BT, "64 blocks per tile");
-    static_assert(NBX == 0 || SCHEME == UA, "flat tiling is for the 3x3 blocks of scheme UA");
-    static constexpr int BS = SCHEME == UA ? 3 : 2;                    // block edge in phase-plane pixels
+    static_assert(NBX == 0 || A, "flat tiling is for the 3x3 blocks of schemes UA / DA");
+    static constexpr int BS = A ? 3 : 2;                               // block edge in output pixels
     static constexpr int RMAX = NBX ? (NBX - 1 + BT + NBX - 1) / NBX : TY;                 // block rows a tile can touch
-    static constexpr int PH = SCHEME == UA ? 3 * RMAX + 1 : 2 * TY + 1;                    // window rows
+    static constexpr int PH = A ? 3 * RMAX + 1 : 2 * TY + 1;                               // window rows (UB; DB: see below)
     // window columns: 16-byte aligned start at or before the first needed column, rounded up to whole float4
-    static constexpr int PW = SCHEME == UA ? ((3 * (NBX ? NBX : TX) + 1 + 3 + 3) / 4) * 4 : 2 * TX + 4;
-    static constexpr int PW4 = PW / 4, PATCH4 = PH * PW4, RP = PH * PW, R_SZ = KC * RP;
+    static constexpr int PW = SCHEME == UA ? ((3 * (NBX ? NBX : TX) + 1 + 3 + 3) / 4) * 4
+                            : SCHEME == DA ? (NBX ? ((3 * NBX + 1 + 3) / 4) * 4 : ((3 * TX + 1 + 3 + 3) / 4) * 4)
+                            : 2 * TX + 4;
+    // DB: three windows per channel, one per plane: eo (2TY+1) x 2TX, oe 2TY x (2TX+4), oo 2TY x 2TX
+    static constexpr int DB_W0 = 2 * TX, DB_W1 = 2 * TX + 4, DB_W2 = 2 * TX;
+    static constexpr int DB_N0 = (2 * TY + 1) * DB_W0, DB_N1 = 2 * TY * DB_W1, DB_N2 = 2 * TY * DB_W2;
+    static constexpr int RP = SCHEME == DB ? DB_N0 + DB_N1 + DB_N2 : PH * PW;
+    static constexpr int PW4 = PW / 4, PATCH4 = RP / 4, R_SZ = KC * RP;
     static constexpr int NPIECE = (PATCH4 + 63) / 64;
 };
 }   // namespace poly
@@ -92,6 +115,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     using G = Geo<SCHEME, TY, TX, NBX>;
     constexpr int PW = G::PW, PW4 = G::PW4, PATCH4 = G::PATCH4, RP = G::RP, R_SZ = G::R_SZ, BS = G::BS, NPIECE = G::NPIECE;
     constexpr bool FLAT = NBX > 0;
+    constexpr bool DOWN = SCHEME == DA || SCHEME == DB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,12 +131,13 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     const int id0 = txb * BT;                            // flat: first block id of the tile
     const int by0 = FLAT ? id0 / (NBX ? NBX : 1) : tyb * TY, bx0 = FLAT ? 0 : txb * TX;      // first block row / column of the window
     const int o0 = otile * BO;
-    const int HW = p.H * p.W;
-    // window origin in the low-resolution image: both schemes read rows / columns BS*b - 1 ... ; the column start is
-    // rounded down to a multiple of 4 floats (UB: 2*bx0 - 4, i.e. three columns of slack; UA: 0..3 columns)
-    const int wy0 = BS * by0 - 1;
-    const int wx0 = SCHEME == UA ? ((3 * bx0 - 1) & ~3) : 2 * bx0 - 4;
-    const int coff = (BS * bx0 - 1) - wx0;               // window column of the first needed input column
+    const int HW = DOWN ? p.PH2 * p.PP : p.H * p.W;      // input channel stride
+    // window origin: the up schemes read rows / columns BS*b - 1 ... of the low-resolution image, the down schemes rows /
+    // columns BS*b ... of their polyphase planes; the column start is rounded down to a multiple of 4 floats
+    // (UB: 2*bx0 - 4, i.e. three columns of slack; UA / DA: 0..3 columns; DB: 2*bx0 is a multiple of 4)
+    const int wy0 = DOWN ? BS * by0 : BS * by0 - 1;
+    const int wx0 = SCHEME == UA ? ((3 * bx0 - 1) & ~3) : SCHEME == DA ? ((3 * bx0) & ~3) : SCHEME == UB ? 2 * bx0 - 4 : 2 * bx0;
+    const int coff = (DOWN ? BS * bx0 : BS * bx0 - 1) - wx0;           // window column of the first needed input column
 
     const bool xformer = wave < NXF;
     constexpr int NLD = 16 - NXF;
@@ -120,11 +145,28 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     int roff[NPIECE];
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-        const int q = j * 64 + lane;
-        const int py = q / PW4, p4 = q - py * PW4;
-        const int iy = wy0 + py, ix = wx0 + 4 * p4;
-        const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
-        roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
+        const int e = j * 64 + lane;                     // float4 index inside the channel's LDS image
+        if constexpr (SCHEME == DB) {
+            // three windows: plane 1 (eo), 2 (oe), 3 (oo); all start at row 2*by0, column 2*bx0 of their plane
+            constexpr int N0 = G::DB_N0 / 4, N1 = G::DB_N1 / 4, W0 = G::DB_W0 / 4, W1 = G::DB_W1 / 4, W2 = G::DB_W2 / 4;
+            const int pl = e < N0 ? 1 : (e < N0 + N1 ? 2 : 3);
+            const int r4 = e < N0 ? e : (e < N0 + N1 ? e - N0 : e - N0 - N1);
+            const int w4 = pl == 1 ? W0 : (pl == 2 ? W1 : W2);
+            const int py = r4 / w4, p4 = r4 - py * w4;
+            const int iy = wy0 + py, ix = wx0 + 4 * p4;
+            const bool ok = e < PATCH4 && iy < p.PH2 && ix + 3 < p.PP;
+            roff[j] = ok ? (pl * p.NB + n) * p.I * HW + iy * p.PP + ix : -1;
+        } else {
+            const int py = e / PW4, p4 = e - py * PW4;
+            const int iy = wy0 + py, ix = wx0 + 4 * p4;
+            if constexpr (SCHEME == DA) {
+                const bool ok = e < PATCH4 && iy < p.PH2 && ix + 3 < p.PP;
+                roff[j] = ok ? n * p.I * HW + iy * p.PP + ix : -1;
+            } else {
+                const bool ok = e < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
+                roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
+            }
+        }
     }
     const bool ract_last = lane < PATCH4 - 64 * (NPIECE - 1);
     auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
@@ -156,7 +198,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     // ---- input transform role: channel `wave`, block `lane`
     const int tty = FLAT ? (id0 + lane) / (NBX ? NBX : 1) - by0 : lane / TX;
     const int ttx = FLAT ? (id0 + lane) % (NBX ? NBX : 1) : lane % TX;
-    const float* rbase = Rl + wave * RP + (BS * tty) * PW + BS * ttx + coff;
+    const float* rbase = Rl + wave * RP + (SCHEME == DB ? 0 : (BS * tty) * PW + BS * ttx + coff);
     float* vbase = Vl + wave * BT + lane;
     float scv[2];
 #pragma unroll
@@ -168,7 +210,32 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
         const float* rb = rbase + buf * R_SZ;
         float* vb = vbase + buf * V_SZ;
-        if constexpr (SCHEME == UA) {
+        if constexpr (SCHEME == DB) {
+            // eo window rows 2ty .. 2ty+2, columns 2tx, 2tx+1: F(2,2) down the rows; positions j*2 + c
+            const float* we = rb + (2 * tty) * G::DB_W0 + 2 * ttx;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const float d0 = we[cc] * sc, d1 = we[G::DB_W0 + cc] * sc, d2 = we[2 * G::DB_W0 + cc] * sc;
+                vb[(0 * 2 + cc) * KC * BT] = d0 - d1;
+                vb[(1 * 2 + cc) * KC * BT] = d1;
+                vb[(2 * 2 + cc) * KC * BT] = d2 - d1;
+            }
+            // oe window rows 2ty, 2ty+1, columns 2tx .. 2tx+2: F(2,2) along the columns; positions 6 + r*3 + j
+            const float* wo = rb + G::DB_N0 + (2 * tty) * G::DB_W1 + 2 * ttx;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float e0 = wo[r * G::DB_W1] * sc, e1 = wo[r * G::DB_W1 + 1] * sc, e2 = wo[r * G::DB_W1 + 2] * sc;
+                vb[(6 + r * 3 + 0) * KC * BT] = e0 - e1;
+                vb[(6 + r * 3 + 1) * KC * BT] = e1;
+                vb[(6 + r * 3 + 2) * KC * BT] = e2 - e1;
+            }
+            // oo window: positions 12 + r*2 + c
+            const float* wq = rb + G::DB_N0 + G::DB_N1 + (2 * tty) * G::DB_W2 + 2 * ttx;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) vb[(12 + r * 2 + cc) * KC * BT] = wq[r * G::DB_W2 + cc] * sc;
+        } else if constexpr (G::A) {
             // B^T d B on the 4x4 patch (rows first, two rows of LDS reads in flight at a time)
             float f[4][4];
 #pragma unroll
@@ -278,9 +345,32 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
 
     // ---- epilogue: exchange the 16 M_xi of every (channel, block) through LDS, inverse transform, raw plane stores
     float* Mx = Vl;                           // [16][32][32]
-    const int PWg = p.W + 1;
-    const long plane = (long)(p.H + 1) * PWg;
+    const int PWg = DOWN ? p.W : p.W + 1;     // output row pitch
+    const long plane = DOWN ? (long)p.H * p.W : (long)(p.H + 1) * PWg;
     const int o_l = tid >> 5, t_l = tid & 31;
+    // scheme DB: the partial sums of scheme DA, the skip tensor and the bias of all four passes are requested up front
+    // (one memory latency instead of four)
+    f32x2 pre_part[SCHEME == DB ? 4 : 1][2], pre_res[SCHEME == DB ? 4 : 1][2];
+    float pre_bias[2] = {0.f, 0.f};
+    if constexpr (SCHEME == DB) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int ob = pass >> 1, t = (pass & 1) * 32 + t_l;
+            const int by = by0 + t / TX, bx = bx0 + t % TX;
+            const int o = min(o0 + ob * 32 + o_l, p.O - 1);
+            if ((pass & 1) == 0) pre_bias[ob] = p.bias ? p.bias[o] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pre_part[pass][j] = f32x2{0.f, 0.f};
+                pre_res[pass][j] = f32x2{0.f, 0.f};
+                if (by < q.nby && bx < q.nbx && 2 * by + j < p.H) {
+                    const long off = ((long)n * p.O + o) * plane + (long)(2 * by + j) * PWg + 2 * bx;
+                    pre_part[pass][j] = *reinterpret_cast<const f32x2*>(p.y + off);
+                    if (p.residual) pre_res[pass][j] = *reinterpret_cast<const f32x2*>(p.residual + off);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int ob = pass >> 1, tb = pass & 1;
@@ -299,7 +389,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         if (o < p.O && by < q.nby && bx < q.nbx) {
             float* yb = p.y + ((long)n * p.O + o) * plane;             // + phase * NB*O*plane
             const long pstride = (long)p.NB * p.O * plane;
-            if constexpr (SCHEME == UA) {
+            if constexpr (G::A) {
                 // A^T m A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
                 float t3[3][4];
 #pragma unroll
@@ -308,15 +398,38 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
                     t3[1][cc] = m[1 * 4 + cc] - m[2 * 4 + cc];
                     t3[2][cc] = m[1 * 4 + cc] + m[2 * 4 + cc] - m[3 * 4 + cc];
                 }
+                constexpr int EXT = DOWN ? 0 : 1;                 // the ee plane of the up path is (H+1) x (W+1)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int u = 3 * by + i;
-                    if (u > p.H) continue;
+                    if (u >= p.H + EXT) continue;
                     const float y0 = t3[i][0] + t3[i][1] + t3[i][2], y1 = t3[i][1] - t3[i][2], y2 = t3[i][1] + t3[i][2] - t3[i][3];
                     float* yr = yb + (long)u * PWg + 3 * bx;
                     yr[0] = y0;
-                    if (3 * bx + 1 <= p.W) yr[1] = y1;
-                    if (3 * bx + 2 <= p.W) yr[2] = y2;
+                    if (3 * bx + 1 < p.W + EXT) yr[1] = y1;
+                    if (3 * bx + 2 < p.W + EXT) yr[2] = y2;
+                }
+            } else if constexpr (SCHEME == DB) {
+                // y[p0+j][q0+c] = partial (scheme DA) + eo + oe + oo terms, then bias / activation / skip (W even: both
+                // columns of a block are inside the image and 8-byte aligned)
+                const int p0 = 2 * by, q0 = 2 * bx;
+                const float bs = pre_bias[ob];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (p0 + j >= p.H) continue;
+                    float* yr = yb + (long)(p0 + j) * PWg + q0;
+                    const f32x2 part = pre_part[pass][j];
+                    const f32x2 rs = pre_res[pass][j];
+                    f32x2 out;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        float v = part[cc] + m[j * 2 + cc] + m[(j + 1) * 2 + cc]                       // eo: m_j + m_{j+1}
+                                + m[6 + j * 3 + cc] + m[6 + j * 3 + cc + 1]                          // oe
+                                + m[12 + j * 2 + cc] + bs;
+                        v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
+                        out[cc] = v + rs[cc];
+                    }
+                    *reinterpret_cast<f32x2*>(yr) = out;
                 }
             } else {
                 const int u0 = 2 * by, v0 = 2 * bx;                    // all four pixels of a body block are inside the image
@@ -428,6 +541,16 @@ __global__ __launch_bounds__(1024) void conv_poly_up_kernel(const PolyParams p) 
     }
 }
 
+// Stride-2 convolution: one scheme per launch (DB consumes the partial sums DA wrote).
+template <int SCHEME, int TY, int TX, int NBX>
+__global__ __launch_bounds__(1024) void conv_poly_down_kernel(const PolyParams p) {
+    using namespace poly;
+    using G = Geo<SCHEME, TY, TX, NBX>;
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];
+    __shared__ __attribute__((aligned(16))) float Rl[2 * G::R_SZ];
+    poly_body<SCHEME, TY, TX, NBX>(p, SCHEME == DA ? p.a : p.b, blockIdx.x, Vl, Rl);
+}
+
 // U for both schemes from w [O,I,3,3] * scale[o]; tap (ky,kx) = w[ky*3+kx] (flip: 8 - index), as the transposed kernel of
 // conv_mfma.hip indexes them.  Layout as conv_wino.hip: wu[otile][chunk][xi][lane][KC].
 __global__ __launch_bounds__(256) void poly_weight_kernel(const float* w, const float* scale, float* wu, int O, int I, int OP,
@@ -460,13 +583,38 @@ __global__ __launch_bounds__(256) void poly_weight_kernel(const float* w, const 
             u[r * 4 + 2] = 0.5f * (gq[r][0] - gq[r][1]);
             u[r * 4 + 3] = gq[r][1];
         }
-    } else {
+    } else if (scheme == poly::UB) {
         const float g0 = g[0][1], g1 = g[2][1];        // eo: tap on x[u], tap on x[u-1]
         const float h0 = g[1][0], h1 = g[1][2];        // oe: tap on x[v], tap on x[v-1]
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) { u[0 * 2 + cc] = g1; u[1 * 2 + cc] = g0 + g1; u[2 * 2 + cc] = g0; }
 #pragma unroll
         for (int r = 0; r < 2; ++r) { u[6 + r * 3 + 0] = h1; u[6 + r * 3 + 1] = h0 + h1; u[6 + r * 3 + 2] = h0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[12 + k] = g[1][1];
+    } else if (scheme == poly::DA) {
+        // correlation taps on the ee plane: q[k][l] = w[2k][2l]
+        const float q00 = g[0][0], q01 = g[0][2], q10 = g[2][0], q11 = g[2][2];
+        float gq[4][2];
+        gq[0][0] = q00; gq[0][1] = q01;
+        gq[1][0] = 0.5f * (q00 + q10); gq[1][1] = 0.5f * (q01 + q11);
+        gq[2][0] = 0.5f * (q00 - q10); gq[2][1] = 0.5f * (q01 - q11);
+        gq[3][0] = q10; gq[3][1] = q11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u[r * 4 + 0] = gq[r][0];
+            u[r * 4 + 1] = 0.5f * (gq[r][0] + gq[r][1]);
+            u[r * 4 + 2] = 0.5f * (gq[r][0] - gq[r][1]);
+            u[r * 4 + 3] = gq[r][1];
+        }
+    } else {
+        // DB, correlation F(2,2): m1 = (d0-d1) g0, m2 = d1 (g0+g1), m3 = (d2-d1) g1
+        const float g0 = g[0][1], g1 = g[2][1];        // eo plane: taps on P_eo[p], P_eo[p+1]
+        const float h0 = g[1][0], h1 = g[1][2];        // oe plane: taps on P_oe[q], P_oe[q+1]
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) { u[0 * 2 + cc] = g0; u[1 * 2 + cc] = g0 + g1; u[2 * 2 + cc] = g1; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { u[6 + r * 3 + 0] = h0; u[6 + r * 3 + 1] = h0 + h1; u[6 + r * 3 + 2] = h1; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[12 + k] = g[1][1];
     }
@@ -537,6 +685,74 @@ extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const flo
     else if (flat) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43, 4, 16>), grid, dim3(poly::NT), 0, s, p);
     else if (wide) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
     else hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---- stride-2 3x3 convolution (mode 1 of shg_conv2d_f32 after the FIR pre-filter) -----------------------------------------
+
+extern "C" int shg_conv_weight_prep_down_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP,
+                                                  int flip, void* stream) {
+    SHG_CHECK_ARG(w && wscale && wu_a && wu_b, "weight_prep_down_poly: null pointer");
+    SHG_CHECK_ARG(O >= 1 && I >= 1 && OP % 64 == 0 && OP >= O, "weight_prep_down_poly: bad shape");
+    const int nchunk = shg_cdiv(I, poly::KC);
+    const long total = (long)OP * nchunk * poly::KC;
+    hipLaunchKernelGGL(poly_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu_a, O, I, OP,
+                       nchunk, flip, (int)poly::DA);
+    SHG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(poly_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu_b, O, I, OP,
+                       nchunk, flip, (int)poly::DB);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// Geometry of the polyphase planes of the filtered input for an OH x OW output: PH2 = OH + 1 rows, pitch PP = OW + 1
+// rounded up to a multiple of 4 floats.  1 when shg_conv2d_down_poly_f32 serves the geometry.
+extern "C" int shg_conv2d_down_poly_supported(int NB, int I, int O, int OH, int OW) {
+    return (OH >= 16 && OW >= 16 && OW % 4 == 0 && OH % 2 == 0 && I <= 128 * poly::KC && NB >= 1 && O >= 1) ? 1 : 0;
+}
+
+// y [NB,O,OH,OW] = act(conv3x3_stride2(xf) + bias) * gain + residual, xf given as its four polyphase planes
+// xp [4][NB,I,OH+1,PP] (shg_fir_down_planar_f32).
+extern "C" int shg_conv2d_down_poly_f32(const float* xp, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O, int OP,
+                                        int OH, int OW, int PP, const float* in_scale, const float* bias, int act, float alpha,
+                                        float gain, float clamp, const float* residual, void* stream) {
+    SHG_CHECK_ARG(xp && wu_a && wu_b && y, "conv2d_down_poly: null pointer");
+    SHG_CHECK_ARG(shg_conv2d_down_poly_supported(NB, I, O, OH, OW), "conv2d_down_poly: unsupported geometry (use shg_conv2d_f32 mode 1)");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_down_poly: OP must be a multiple of 64 and >= O");
+    SHG_CHECK_ARG(PP % 4 == 0 && PP >= OW + 1, "conv2d_down_poly: plane pitch must be a multiple of 4 and >= OW + 1");
+    SHG_CHECK_ARG(4L * NB * I * (OH + 1) * PP < 2147483647L && (long)NB * O * OH * OW < 2147483647L, "conv2d_down_poly: tensor too large");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(xp) & 15) | (reinterpret_cast<uintptr_t>(y) & 7) | (reinterpret_cast<uintptr_t>(residual) & 7)) == 0,
+                  "conv2d_down_poly: xp must be 16-byte, y / residual 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    PolyParams p{};
+    p.x = xp; p.y = y; p.in_scale = in_scale; p.bias = bias; p.residual = residual;
+    p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = OH; p.W = OW; p.PH2 = OH + 1; p.PP = PP;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
+    // scheme DA: 3x3 output blocks (flat tiling for the generator's block-row lengths)
+    p.a.wu = wu_a; p.a.nby = shg_cdiv(OH, 3); p.a.nbx = shg_cdiv(OW, 3);
+    const bool flat = p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43;
+    const long w88 = (long)shg_cdiv(p.a.nbx, 8) * shg_cdiv(p.a.nby, 8), w416 = (long)shg_cdiv(p.a.nbx, 16) * shg_cdiv(p.a.nby, 4);
+    const bool wide = OW >= 32 && w416 < w88;
+    if (flat) { p.a.tiles_x = shg_cdiv(p.a.nby * p.a.nbx, 64); p.a.tiles_y = 1; }
+    else { p.a.tiles_x = shg_cdiv(p.a.nbx, wide ? 16 : 8); p.a.tiles_y = shg_cdiv(p.a.nby, wide ? 4 : 8); }
+    p.a.n_ttiles = p.a.tiles_x * p.a.tiles_y * NB;
+    const dim3 ga(p.a.n_ttiles * p.n_otiles);
+    if (flat && p.a.nbx == 11) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 1, 64, 11>), ga, dim3(poly::NT), 0, s, p);
+    else if (flat && p.a.nbx == 22) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 1, 64, 22>), ga, dim3(poly::NT), 0, s, p);
+    else if (flat) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 1, 64, 43>), ga, dim3(poly::NT), 0, s, p);
+    else if (wide) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 4, 16, 0>), ga, dim3(poly::NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 8, 8, 0>), ga, dim3(poly::NT), 0, s, p);
+    SHG_CHECK_LAUNCH();
+    // scheme DB: 2x2 output blocks + the layer tail
+    const bool bwide = OW >= 32;
+    p.b.wu = wu_b; p.b.nby = OH / 2; p.b.nbx = OW / 2;
+    p.b.tiles_x = shg_cdiv(p.b.nbx, bwide ? 16 : 8); p.b.tiles_y = shg_cdiv(p.b.nby, bwide ? 4 : 8);
+    p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
+    const dim3 gb(p.b.n_ttiles * p.n_otiles);
+    if (bwide) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 4, 16, 0>), gb, dim3(poly::NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 8, 8, 0>), gb, dim3(poly::NT), 0, s, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -34,6 +34,9 @@ struct UfdParams {
     int act;                 // 0 none, 1 lrelu_agc
     float alpha, act_gain, clamp;
     int has_epilogue;
+    // fir_same only: polyphase-planar output for the stride-2 convolution (conv_wino_poly.hip): when pl_pp > 0 the result
+    // element (oy, ox) goes to plane (oy&1)*2 + (ox&1), row oy>>1, column ox>>1 of y [4][NC][pl_ph2][pl_pp]
+    int pl_ph2, pl_pp;
     // timing studies, -DSHG_ABLATE build only (env SHG_FIR_DBG: 1 skip window loads, 2 skip FIR math, 4 skip stores)
 #ifdef SHG_ABLATE
     int dbg;
@@ -185,7 +188,11 @@ __global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
                 for (int ky = 0; ky < FH; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < FW; ++kx) v += win[t + ky][kx] * fr[ky * FW + kx];
-                if (oy < p.OH && ox < p.OW) yp[oy * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
+                if (oy < p.OH && ox < p.OW) {
+                    if (p.pl_pp > 0)
+                        p.y[((long)((oy & 1) * 2 + (ox & 1)) * p.NC + nc) * p.pl_ph2 * p.pl_pp + (oy >> 1) * p.pl_pp + (ox >> 1)] = v;
+                    else yp[oy * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
+                }
             }
         }
         __syncthreads();
@@ -445,6 +452,21 @@ extern "C" int shg_upfirdn2d_epilogue_f32(const float* x, const float* f, float*
     p.scale = scale; p.bias = bias; p.noise = noise; p.residual = residual;
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp; p.has_epilogue = 1;
+    return ufd_launch(p, (hipStream_t)stream);
+}
+
+// FIR pre-filter of the stride-2 convolution (conv2d_resample.py:116-120: upfirdn2d with padding 2 for the 4x4 filter) written
+// as the four polyphase planes of the (H+1) x (W+1) result: y [4][N*C][H/2+1][PP], plane (a,b) element (u,v) = xf[2u+a][2v+b]
+// (PP >= W/2+1, a multiple of 4 floats; entries outside a plane's extent are left untouched).
+extern "C" int shg_fir_down_planar_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int PP, int flip,
+                                       float gain, void* stream) {
+    UfdParams p;
+    int rc = ufd_fill(p, x, f, y, N, C, H, W, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, flip, gain);
+    if (rc != SHG_OK) return rc;
+    SHG_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "fir_down_planar: H and W must be even");
+    SHG_CHECK_ARG(PP % 4 == 0 && PP >= W / 2 + 1, "fir_down_planar: plane pitch must be a multiple of 4 and >= W/2 + 1");
+    SHG_CHECK_ARG(4L * N * C * (H / 2 + 1) * PP <= 2147483647L, "fir_down_planar: output is too large");
+    p.pl_ph2 = H / 2 + 1; p.pl_pp = PP;
     return ufd_launch(p, (hipStream_t)stream);
 }
 

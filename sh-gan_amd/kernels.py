@@ -297,26 +297,34 @@ def assemble_input(real, mask):
 class PreppedWeight:
     """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq).  ``wu`` (Winograd
     F(2x2,3x3) layout, shg_conv_weight_prep_wino_f32) is built on first use by a stride-1 3x3 convolution."""
-    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', 'wu_up', '_w', '_wscale', '_flip')
+    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', 'wu_up', 'wu_down', '_w', '_wscale', '_flip')
 
     def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1, w=None, wscale=None, flip=False):
         self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.groups = wt, wsq, o, i, op, kh, kw, groups
-        self.wu, self.wu_up, self._w, self._wscale, self._flip = None, None, w, wscale, flip
+        self.wu, self.wu_up, self.wu_down, self._w, self._wscale, self._flip = None, None, None, w, wscale, flip
+
+    def _poly(self, entry):
+        if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
+            raise _lib.ShgError('PreppedWeight: polyphase forms need an ungrouped 3x3 weight')
+        L = _Launch()
+        w, ws = L.req(self._w, 'w'), L.req(self._wscale, 'wscale')
+        size = (self.op // 64) * ((self.i + 7) // 8) * 16 * 64 * 8
+        wa, wb = L.new((size,)), L.new((size,))
+        with L:
+            check(getattr(_lib.get_lib(), entry)(_ptr(w), _ptr(ws), _ptr(wa), _ptr(wb), self.o, self.i, self.op,
+                                                 int(bool(self._flip)), L.stream()), entry)
+        return wa, wb
+
+    def down_poly(self):
+        """(wu_a, wu_b): polyphase-Winograd weights of the stride-2 convolution (shg_conv_weight_prep_down_poly_f32)."""
+        if self.wu_down is None:
+            self.wu_down = self._poly('shg_conv_weight_prep_down_poly_f32')
+        return self.wu_down
 
     def up_poly(self):
         """(wu_a, wu_b): polyphase-Winograd weights of the stride-2 transposed convolution (shg_conv_weight_prep_up_poly_f32)."""
         if self.wu_up is None:
-            if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
-                raise _lib.ShgError('PreppedWeight.up_poly: needs an ungrouped 3x3 weight')
-            L = _Launch()
-            w, ws = L.req(self._w, 'w'), L.req(self._wscale, 'wscale')
-            nchunk = (self.i + 7) // 8
-            size = (self.op // 64) * nchunk * 16 * 64 * 8
-            wa, wb = L.new((size,)), L.new((size,))
-            with L:
-                check(_lib.get_lib().shg_conv_weight_prep_up_poly_f32(_ptr(w), _ptr(ws), _ptr(wa), _ptr(wb), self.o, self.i, self.op,
-                                                                      int(bool(self._flip)), L.stream()), 'conv_weight_prep_up_poly')
-            self.wu_up = (wa, wb)
+            self.wu_up = self._poly('shg_conv_weight_prep_up_poly_f32')
         return self.wu_up
 
     def wino(self):
@@ -362,6 +370,7 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
 WINO = True
 WINO_MIN = 16
 UP_POLY = True          # stride-2 transposed 3x3 convolutions in the polyphase-Winograd form (conv_wino_poly.hip)
+DOWN_POLY = True        # FIR-filtered stride-2 3x3 convolutions likewise (fir_down_planar + conv2d_down_poly)
 
 MODE_SAME, MODE_DOWN2, MODE_UP2T = 0, 1, 2
 _CONV_CLASS = {MODE_SAME: 'conv_mfma_s1', MODE_DOWN2: 'conv_mfma_s2', MODE_UP2T: 'conv_mfma_up'}
@@ -425,6 +434,48 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
             _ptr(x), _ptr(pw.wt), _ptr(y), nb, i, pw.o, pw.op, h, w, pw.kh, pw.kw, mode, pad, pw.groups, pw.wt.shape[1],
             _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise), nmode, float(noise_strength), a, al, g, cl, _ptr(residual),
             1 if planar else 0, _ptr(ws), ws_bytes, L.stream()), 'conv2d')
+    return y
+
+
+DOWN_POLY_MIN_I, DOWN_POLY_MIN_OUT = 128, 32     # below: the per-tile fixed cost of the 16-position kernels outweighs the saved
+                                                  # multiplies (measured, tools/conv_bench_down.py), the direct stride-2 kernel is used
+
+
+def down_poly_supported(x, pw, force=False):
+    """True when the FIR + stride-2 3x3 convolution of x [N,I,H,W] runs in the polyphase-Winograd form."""
+    n, i, h, w = x.shape
+    if not force and (i < DOWN_POLY_MIN_I or min(h, w) // 2 < DOWN_POLY_MIN_OUT):
+        return False
+    return bool(DOWN_POLY and pw.groups == 1 and pw.kh == 3 and pw.kw == 3 and pw._w is not None and h % 2 == 0 and w % 2 == 0
+                and x.is_cuda and _lib.get_lib().shg_conv2d_down_poly_supported(n, i, pw.o, h // 2, w // 2))
+
+
+def fir_conv_down2(x, f, pw, bias=None, act=False, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0, residual=None, flip_filter=False):
+    """y = act(conv3x3_stride2(upfirdn2d(x, f, padding=2)) + bias) (conv2d_resample.py:116-120 + the conv2d_layer tail):
+    the 4x4 FIR writes the polyphase planes of its result, the convolution runs as two polyphase-Winograd launches."""
+    L = _Launch()
+    x, f = L.req(x, 'x'), L.req(f, 'f')
+    if tuple(f.shape) != (4, 4):
+        raise _lib.ShgError('fir_conv_down2: f must be 4x4')
+    n, i, h, w = x.shape
+    oh, ow = h // 2, w // 2
+    pp = (ow + 1 + 3) // 4 * 4
+    wa, wb = pw.down_poly()
+    L.view(wa, 'weights')
+    xp = L.new((4, n, i, oh + 1, pp))
+    y = L.new((n, pw.o, oh, ow))
+    bias, residual = L.req(bias, 'bias'), L.req(residual, 'residual')
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise _lib.ShgError('fir_conv_down2: residual shape mismatch')
+    a, al, g, cl = _act_args(act, gain, alpha, act_gain, clamp)
+    lib = _lib.get_lib()
+    with _timed(L, 'upfirdn2d', 4.0 * (x.numel() + n * i * (h + 1) * (w + 1))):
+        check(lib.shg_fir_down_planar_f32(_ptr(x), _ptr(f), _ptr(xp), n, i, h, w, pp, int(bool(flip_filter)), 1.0, L.stream()),
+              'fir_down_planar')
+    nba, nbb = ((oh + 2) // 3) * ((ow + 2) // 3), (oh // 2) * (ow // 2)
+    with _timed(L, 'conv_poly_down', 2.0 * n * pw.o * i * 9 * oh * ow, 2.0 * n * pw.o * i * 16.0 * (nba + nbb)):
+        check(lib.shg_conv2d_down_poly_f32(_ptr(xp), _ptr(wa), _ptr(wb), _ptr(y), n, i, pw.o, pw.op, oh, ow, pp, None, _ptr(bias),
+                                           a, al, g, cl, _ptr(residual), L.stream()), 'conv2d_down_poly')
     return y
 
 

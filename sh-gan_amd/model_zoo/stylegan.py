@@ -222,6 +222,8 @@ class conv2d_layer(nn.Module):
             fw, fh = f.shape[1], f.shape[0]
             p = self.padding
             pads = [p + (fw - 1) // 2, p + (fw - 2) // 2, p + (fh - 1) // 2, p + (fh - 2) // 2]
+            if tuple(f.shape) == (4, 4) and p == 1 and kernels.down_poly_supported(x, self.prepped()):
+                return kernels.fir_conv_down2(x, f, self.prepped(), bias=b, **ak)      # polyphase-Winograd form
             y = kernels.upfirdn2d(x, f, padx0=pads[0], padx1=pads[1], pady0=pads[2], pady1=pads[3])
             return kernels.conv2d(y, self.prepped(), mode=kernels.MODE_DOWN2, pad=0, bias=b, **ak)
         # generic composition

@@ -308,3 +308,44 @@ def test_polyphase_winograd_transposed_conv(mods, n, ci, co, h, w, flip):
     fa, fb = _interleave(a, h, w), _interleave(b, h, w)
     assert rel_err(c(fa), ref.numpy()) < 2e-5
     assert rel_err(c(fa), c(fb)) < 2e-5
+
+
+POLY_DOWN_CASES = [
+    # n, ci, co, h, w (input extent; output h/2 x w/2): flat tiles (output rows of 11 / 22 / 43 blocks), both rectangular
+    # shapes, 8 x 8 block tiles for narrow outputs, ragged channel counts
+    (2, 16, 64, 64, 64), (1, 13, 70, 36, 40), (2, 24, 130, 128, 128), (1, 8, 24, 32, 256), (1, 64, 64, 256, 256), (1, 8, 8, 64, 96),
+    (3, 40, 40, 32, 32),
+]
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', POLY_DOWN_CASES)
+def test_polyphase_winograd_stride2_conv(mods, n, ci, co, h, w):
+    """fir_down_planar + shg_conv2d_down_poly_f32 (P_ee term as F(3x3,2x2), the other planes with 16 multiplies per 2x2
+    block, fused bias / lrelu_agc / skip) against the oracle's FIR + torch CPU strided convolution, and against the
+    direct route (upfirdn2d + MFMA stride-2 kernel)."""
+    import torch.nn.functional as F
+    kk, orc = mods['kernels'], mods['orc']
+    rs = np.random.RandomState(n * 100 + ci + co + h)
+    x, wt, bias = rnd(rs, n, ci, h, w), rnd(rs, co, ci, 3, 3), rnd(rs, co)
+    res = rnd(rs, n, co, h // 2, w // 2)
+    f = torch.from_numpy(rs.rand(4, 4).astype(np.float32))                      # asymmetric filter
+    xf = orc.upfirdn2d(x, f, padding=[2, 2, 2, 2])
+    ref = orc.lrelu_agc(F.conv2d(xf, wt * 0.05, stride=2) + bias.view(1, -1, 1, 1), gain=0.7) + res
+    pw = kk.conv_weight_prep(wt.to(DEV), gain=0.05)
+    assert kk.down_poly_supported(x.to(DEV), pw, force=True)
+    timer = kk.KernelTimer()
+    kk.set_timer(timer)
+    try:
+        y = kk.fir_conv_down2(x.to(DEV), f.to(DEV), pw, bias=bias.to(DEV), act=True, gain=0.7, residual=res.to(DEV))
+    finally:
+        kk.set_timer(None)
+    torch.cuda.synchronize()
+    assert 'conv_poly_down' in timer.summary()
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_err(c(y), ref.numpy()) < 2e-5
+    yd = kk.conv2d(kk.upfirdn2d(x.to(DEV), f.to(DEV), padx0=2, padx1=2, pady0=2, pady1=2), pw, mode=kk.MODE_DOWN2, pad=0,
+                   bias=bias.to(DEV), act=True, gain=0.7, residual=res.to(DEV))
+    assert rel_err(c(y), c(yd)) < 2e-5
+    # no activation, no bias, no skip: the raw sum of the two schemes
+    y0 = kk.fir_conv_down2(x.to(DEV), f.to(DEV), pw)
+    assert rel_err(c(y0), F.conv2d(xf, wt * 0.05, stride=2).numpy()) < 2e-5
