@@ -188,11 +188,14 @@ __global__ __launch_bounds__(256, 4) void fir_same_kernel(const UfdParams p) {
                 for (int ky = 0; ky < FH; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < FW; ++kx) v += win[t + ky][kx] * fr[ky * FW + kx];
-                if (oy < p.OH && ox < p.OW) {
-                    if (p.pl_pp > 0)
-                        p.y[((long)((oy & 1) * 2 + (ox & 1)) * p.NC + nc) * p.pl_ph2 * p.pl_pp + (oy >> 1) * p.pl_pp + (ox >> 1)] = v;
-                    else yp[oy * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
-                }
+                if (p.pl_pp > 0) {
+                    // every entry of the four planes is written: positions beyond the filtered image (pitch padding, the
+                    // last row / column of the odd planes) get ZERO -- the Winograd transforms of the consumer mix a
+                    // patch's columns, so stale memory there would leak into valid outputs
+                    if ((oy >> 1) < p.pl_ph2 && (ox >> 1) < p.pl_pp)
+                        p.y[((long)((oy & 1) * 2 + (ox & 1)) * p.NC + nc) * p.pl_ph2 * p.pl_pp + (oy >> 1) * p.pl_pp + (ox >> 1)] =
+                            (oy < p.OH && ox < p.OW) ? v : 0.f;
+                } else if (oy < p.OH && ox < p.OW) yp[oy * p.OW + ox] = ufd_finish(p, pl, v, oy * p.OW + ox);
             }
         }
         __syncthreads();
@@ -386,9 +389,11 @@ static int ufd_launch(UfdParams& p, hipStream_t s) {
     const int gz = p.NC < 32768 ? p.NC : 32768;
     if (p.upx == 1 && p.upy == 1 && p.dnx == 1 && p.dny == 1 && p.fh == 4 && p.fw == 4) {
         // each workgroup walks several planes with the next window prefetched; ~8k workgroups in total
-        const int tiles = shg_cdiv(p.OW, 64) * shg_cdiv(p.OH, 32);
+        // (planar output: the grid covers the whole 2*pl_ph2 x 2*pl_pp extent of the planes, padding included)
+        const int cov_w = p.pl_pp > 0 ? 2 * p.pl_pp : p.OW, cov_h = p.pl_pp > 0 ? 2 * p.pl_ph2 : p.OH;
+        const int tiles = shg_cdiv(cov_w, 64) * shg_cdiv(cov_h, 32);
         int gzs = 8192 / tiles; if (gzs < 1) gzs = 1; if (gzs > p.NC) gzs = p.NC;
-        dim3 grid(shg_cdiv(p.OW, 64), shg_cdiv(p.OH, 32), gzs);
+        dim3 grid(shg_cdiv(cov_w, 64), shg_cdiv(cov_h, 32), gzs);
         const bool vec4 = p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && p.px0 >= 0 && p.px0 <= 4;
         if (vec4) hipLaunchKernelGGL((fir_same_kernel<4, 4, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((fir_same_kernel<4, 4, false>), grid, dim3(256), 0, s, p);
@@ -457,7 +462,7 @@ extern "C" int shg_upfirdn2d_epilogue_f32(const float* x, const float* f, float*
 
 // FIR pre-filter of the stride-2 convolution (conv2d_resample.py:116-120: upfirdn2d with padding 2 for the 4x4 filter) written
 // as the four polyphase planes of the (H+1) x (W+1) result: y [4][N*C][H/2+1][PP], plane (a,b) element (u,v) = xf[2u+a][2v+b]
-// (PP >= W/2+1, a multiple of 4 floats; entries outside a plane's extent are left untouched).
+// (PP >= W/2+1, a multiple of 4 floats; entries outside a plane's extent are written as zeros).
 extern "C" int shg_fir_down_planar_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int PP, int flip,
                                        float gain, void* stream) {
     UfdParams p;

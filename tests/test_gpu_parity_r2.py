@@ -333,6 +333,10 @@ def test_polyphase_winograd_stride2_conv(mods, n, ci, co, h, w):
     ref = orc.lrelu_agc(F.conv2d(xf, wt * 0.05, stride=2) + bias.view(1, -1, 1, 1), gain=0.7) + res
     pw = kk.conv_weight_prep(wt.to(DEV), gain=0.05)
     assert kk.down_poly_supported(x.to(DEV), pw, force=True)
+    # poison the allocator's free blocks: the intermediate planes come from torch.empty, and whatever they do not overwrite
+    # (pitch padding, rows / columns outside a plane) must not reach a valid output through the Winograd transforms
+    junk = torch.full((max(8 * n * ci * (h + 8) * (w + 16), 1 << 22),), float('nan'), device=DEV)
+    del junk
     timer = kk.KernelTimer()
     kk.set_timer(timer)
     try:
