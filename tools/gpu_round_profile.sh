@@ -1,0 +1,19 @@
+#!/bin/bash
+# Everything a profiles/<tag>_* set holds, in one GPU-box visit: rocprofv3 kernel stats of the bench command, the bench
+# JSON lines (512x16 with the CPU baseline, 256x32), the per-layer micro-benchmarks.  Output: gpurun_out/<tag>/.
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline > $OUT/prof_stdout.log 2>&1 )
+cd $GRAFT_REPO_ROOT
+F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+cp "$F" $OUT/${TAG}_bench512x16_kernel_stats.csv
+python tools/prof_summary.py "$F" 7 > $OUT/${TAG}_summary.txt
+rm -rf $OUT/prof
+python bench.py --steps 20 --warmup 3 ${BENCH_ARGS} > $OUT/${TAG}_bench512x16.json.log 2> $OUT/bench512.err
+python bench.py --steps 20 --warmup 3 --resolution 256 --no-cpu-baseline > $OUT/${TAG}_bench256x32.json.log 2> $OUT/bench256.err
+python tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>/dev/null
+python tools/conv_bench_down.py > $OUT/${TAG}_conv_bench_down.txt 2>/dev/null
+python tools/fir_bench.py > $OUT/${TAG}_fir_bench.txt 2>/dev/null
+cat $OUT/${TAG}_summary.txt; head -c 300 $OUT/${TAG}_bench512x16.json.log; echo; head -c 300 $OUT/${TAG}_bench256x32.json.log
