@@ -38,26 +38,31 @@ def _digest(extra=()):
     return h.hexdigest()
 
 
-def lib_path(ablate=False):
+def lib_path(ablate=False, variant=None):
+    if variant:
+        return os.path.join(LIBDIR, f'libshgan_hip_{variant}.so')
     return os.path.join(LIBDIR, 'libshgan_hip_ablate.so' if ablate else LIBNAME)
 
 
-def build(force=False, verbose=True, ablate=False):
+def build(force=False, verbose=True, ablate=False, variant=None, defines=()):
     """``ablate=True`` builds the timing-study variant (-DSHG_ABLATE: the SHG_*_DBG / SHG_CONV_VARIANT environment switches
-    that make kernels skip work) as a SEPARATE library for tools/; the product library has no such switches."""
+    that make kernels skip work) as a SEPARATE library for tools/; the product library has no such switches.
+    ``variant='name', defines=['-DX=1']`` builds libshgan_hip_<name>.so with extra compile-time knobs for A/B runs in tools/."""
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = ['-DSHG_ABLATE'] if ablate else []
-    stamp = os.path.join(LIBDIR, '.build_digest_ablate' if ablate else '.build_digest')
+    extra = (['-DSHG_ABLATE'] if ablate else []) + list(defines)
+    if variant:
+        ablate = True            # (shares the .abl.o object names / separate stamp below)
+    stamp = os.path.join(LIBDIR, f'.build_digest_{variant}' if variant else ('.build_digest_ablate' if ablate else '.build_digest'))
     dig = _digest(extra)
-    if not force and os.path.exists(lib_path(ablate)) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if not force and os.path.exists(lib_path(ablate, variant)) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         if verbose:
-            print(f'[build] {os.path.basename(lib_path(ablate))} up to date')
-        return lib_path(ablate)
+            print(f'[build] {os.path.basename(lib_path(ablate, variant))} up to date')
+        return lib_path(ablate, variant)
     hipcc = _hipcc()
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace('.hip', '.abl.o' if ablate else '.o'))
+        obj = os.path.join(LIBDIR, src.replace('.hip', (f'.{variant}.o' if variant else '.abl.o') if ablate else '.o'))
         objs.append(obj)
         cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
@@ -70,7 +75,7 @@ def build(force=False, verbose=True, ablate=False):
             raise RuntimeError(f'hipcc failed on {src}')
         if verbose and out.strip():
             print(out.decode(errors='replace'))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path(ablate)] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path(ablate, variant)] + objs
     if verbose:
         print('[build]', ' '.join(cmd))
     subprocess.check_call(cmd)
@@ -78,8 +83,10 @@ def build(force=False, verbose=True, ablate=False):
         os.remove(obj)
     with open(stamp, 'w') as fh:
         fh.write(dig)
-    return lib_path(ablate)
+    return lib_path(ablate, variant)
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, ablate='--ablate' in sys.argv)
+    var = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--variant=')]
+    build(force='--force' in sys.argv, ablate='--ablate' in sys.argv, variant=var[0] if var else None,
+          defines=[a for a in sys.argv[1:] if a.startswith('-D')])
