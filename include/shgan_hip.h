@@ -164,6 +164,14 @@ int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int
  * real [N,3,H,W] in [-1,1], mask [N,H,W] in {0,1} -> x [N,4,H,W]. */
 int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N, int H, int W, void* stream);
 
+/* ---- next row N2: freeform-mask rasteriser (lib/data_factory/ds_ffhq.py:145-217).  The host makes the random draws in the
+ * reference's order and emits 8-word int32 records per mask (RECT / DISC / QUAD + 4 EDGE / POINT, see csrc/mask_raster.hip);
+ * the device draws them exactly as Pillow's ImageDraw.line(width) / ellipse would.  records [total][8], offsets [B+1],
+ * flips [B][2], disc_table [max_half+1][2*max_half+1][2]; mask [B,1,s,s] (1 keep / 0 hole), holes [B] += hole pixel counts
+ * (zero it first).  s: multiple of 32, <= 512. */
+int shg_mask_raster_f32(const int* records, const int* offsets, const int* flips, const int* disc_table, int max_half, float* mask,
+                        int* holes, int B, int s, void* stream);
+
 /* ---- next row N3 (training-side critic, forward only): minibatch_std_layer (stylegan.py:686-704).
  * x [N,C,H,W] -> y [N,C+F,H,W]; N % G == 0, C % F == 0; stat [N/G * F] is caller-owned scratch. */
 int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, int H, int W, int G, int F, void* stream);
