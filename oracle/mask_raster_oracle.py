@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 f32 = np.float32
-RECT, DISC, QUAD, EDGE, POINT = 0, 1, 2, 3, 4
+RECT, DISC, QUAD, EDGE, POINT, SEG = 0, 1, 2, 3, 4, 5
 
 
 def round_up(f):
@@ -85,6 +85,23 @@ def fill_quad(im, head, edges):
             x_pos = x_end + 1
 
 
+def wide_line_edges(x0, y0, x1, y1, width, big, s):
+    """Pillow's ImagingDrawWideLine + add_edge: (head, edges) of the quad of one thick segment."""
+    dx, dy = x1 - x0, y1 - y0
+    small = (width - 1) / 2.0
+    rmax, rmin = round_up(small) / big, round_down(small) / big
+    dxmin, dxmax = round_down(rmin * dy), round_down(rmax * dy)
+    dymin, dymax = round_up(rmin * dx), round_up(rmax * dx)
+    v = [(x0 - dxmin, y0 + dymax), (x1 - dxmin, y1 + dymax), (x1 + dxmax, y1 - dymin), (x0 + dxmax, y0 - dymin)]
+    edges = []
+    for k in range(4):
+        (xa, ya), (xb, yb) = v[k], v[(k + 1) % 4]
+        dxe = f32(0.0) if ya == yb else f32(xb - xa) / f32(yb - ya)
+        edges.append((EDGE, xa, ya, min(ya, yb), max(ya, yb), dxe, min(xa, xb), max(xa, xb)))
+    ys = [p[1] for p in v]
+    return (QUAD, max(min(ys), 0), min(max(ys), s)), edges
+
+
 def rasterize(records, flip0, flip1, s, disc_table):
     """records [n,8] int32 -> uint8 keep mask [s,s] (1 = keep, 0 = hole) = rect layer AND NOT flipped brush layer."""
     keep = np.ones((s, s), np.uint8)
@@ -107,6 +124,16 @@ def rasterize(records, flip0, flip1, s, disc_table):
         elif t == POINT:
             if 0 <= r[2] < s and 0 <= r[1] < s:
                 brush[int(r[2]), int(r[1])] = 1
+            i += 1
+        elif t == SEG:
+            x0, y0, x1, y1, width = (int(v) for v in r[1:6])
+            if x0 == x1 and y0 == y1:
+                if 0 <= y0 < s and 0 <= x0 < s:
+                    brush[y0, x0] = 1
+            else:
+                big = float(np.asarray(r[6:8], dtype=np.int32).view(np.float64)[0])
+                head, edges = wide_line_edges(x0, y0, x1, y1, width, big, s)
+                fill_quad(brush, head, edges)
             i += 1
         elif t == QUAD:
             edges = []

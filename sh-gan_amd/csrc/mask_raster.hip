@@ -7,6 +7,8 @@
 //   EDGE  (3, x0, y0, ymin, ymax, dx, xmin, xmax)   filled by its polygon_generic scan-line rule (float32 slopes, ROUND_UP /
 //                                                   ROUND_DOWN span ends, corner joining, horizontal edges as plain lines)
 //   POINT (4, x, y)                               zero-length segment
+//   SEG   (5, x0, y0, x1, y1, width, hypot lo, hypot hi)   the same segment with the quad built HERE (the host only supplies
+//                                                   hypot(dx, dy) as a double: libm's value, not the device's)
 // mask = keep layer AND NOT (brush layer, flipped up-down / left-right per the two flip flags), 1 = keep, 0 = hole.
 // One thread per image row: the row lives in registers as a bit vector (<= 512 columns), records are read with
 // wave-uniform addresses.  Integer / float32 arithmetic only, every float product and sum rounded separately (no FMA):
@@ -57,6 +59,32 @@ __device__ __forceinline__ float mr_ex(const MrEdge& e, int y) {
 #pragma clang fp contract(off)
     const float a = (float)(y - e.y0) * e.dx;
     return a + (float)e.x0;
+}
+
+__device__ __forceinline__ int mr_round_up_d(double f) { return (int)(f >= 0.0 ? floor(f + 0.5) : -floor(fabs(f) + 0.5)); }
+__device__ __forceinline__ int mr_round_down_d(double f) { return (int)(f >= 0.0 ? ceil(f - 0.5) : -ceil(fabs(f) - 0.5)); }
+
+__device__ __forceinline__ void mr_add_edge(MrEdge& e, int x0, int y0, int x1, int y1) {      // Pillow's add_edge
+    e.xmin = min(x0, x1); e.xmax = max(x0, x1);
+    e.ymin = min(y0, y1); e.ymax = max(y0, y1);
+    e.dx = y0 == y1 ? 0.f : ((float)(x1 - x0)) / (float)(y1 - y0);
+    e.x0 = x0; e.y0 = y0;
+}
+
+// Pillow's ImagingDrawWideLine: the quad of a segment of the given width; returns the clamped scan range in ymin / ymax
+__device__ __forceinline__ void mr_wide_line(MrEdge (&e)[4], int x0, int y0, int x1, int y1, int width, double big, int s, int& ymin,
+                                             int& ymax) {
+    const int dx = x1 - x0, dy = y1 - y0;
+    const double small = (width - 1) / 2.0;
+    const double rmax = (double)mr_round_up_d(small) / big, rmin = (double)mr_round_down_d(small) / big;
+    const int dxmin = mr_round_down_d(rmin * dy), dxmax = mr_round_down_d(rmax * dy);
+    const int dymin = mr_round_up_d(rmin * dx), dymax = mr_round_up_d(rmax * dx);
+    const int vx[4] = {x0 - dxmin, x1 - dxmin, x1 + dxmax, x0 + dxmax};
+    const int vy[4] = {y0 + dymax, y1 + dymax, y1 - dymin, y0 - dymin};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mr_add_edge(e[k], vx[k], vy[k], vx[(k + 1) & 3], vy[(k + 1) & 3]);
+    ymin = max(min(min(vy[0], vy[1]), min(vy[2], vy[3])), 0);
+    ymax = min(max(max(vy[0], vy[1]), max(vy[2], vy[3])), s);
 }
 
 // Pillow's polygon_generic restricted to one scan line y of a 4-edge polygon; [ymin, YMAX] is the clamped scan range.
@@ -165,6 +193,20 @@ __global__ __launch_bounds__(256) void mask_raster_kernel(const MaskParams p) {
             r += 1;
         } else if (type == 4) {
             if (live && q[2] == yb) mr_span(brush, q[1], q[1], s);
+            r += 1;
+        } else if (type == 5) {
+            const int x0 = q[1], y0 = q[2], x1 = q[3], y1 = q[4], width = q[5];
+            // no row further than `width` from the segment's row range can be touched: skip the geometry for those
+            if (live && yb >= min(y0, y1) - width && yb <= max(y0, y1) + width) {
+                if (x0 == x1 && y0 == y1) { if (y0 == yb) mr_span(brush, x0, x0, s); }
+                else {
+                    MrEdge e[4];
+                    int ymin, ymax;
+                    const double big = __hiloint2double(q[7], q[6]);
+                    mr_wide_line(e, x0, y0, x1, y1, width, big, s, ymin, ymax);
+                    if (yb >= ymin && yb <= ymax) mr_quad_row(brush, e, yb, ymax, s);
+                }
+            }
             r += 1;
         } else {                                                 // QUAD header + 4 EDGE records
             const int ymin = q[1], ymax = q[2];

@@ -27,7 +27,7 @@ import torch
 from . import _lib, kernels
 from ._lib import check
 
-RECT, DISC, QUAD, EDGE, POINT = 0, 1, 2, 3, 4
+RECT, DISC, QUAD, EDGE, POINT, SEG = 0, 1, 2, 3, 4, 5
 REC = 8                                   # int32 words per primitive record
 MAX_HALF = 32                             # disc radii served by the span table
 
@@ -91,6 +91,20 @@ def thick_polyline_records(path, width, s):
     return out
 
 
+def segment_records(path, width):
+    """Records of ``ImageDraw.line(path, width=width)`` with the quad geometry left to the device: one SEG per segment,
+    carrying hypot(dx, dy) as computed by the host's libm (the one input of Pillow's quad that is not exact arithmetic)."""
+    p = np.asarray(path, dtype=np.int32)
+    n = len(p) - 1
+    rec = np.zeros((n, REC), dtype=np.int32)
+    rec[:, 0] = SEG
+    rec[:, 1:3], rec[:, 3:5] = p[:-1], p[1:]
+    rec[:, 5] = width
+    d = (p[1:] - p[:-1]).astype(np.float64)
+    rec[:, 6:8] = np.hypot(d[:, 0], d[:, 1]).view(np.int32).reshape(n, 2)          # little endian: lo, hi
+    return rec
+
+
 def brush_records(max_tries, s, min_num_vertex=4, max_num_vertex=18, mean_angle=2 * math.pi / 5, angle_range=2 * math.pi / 15,
                   min_width=12, max_width=48):
     """The draws of ``RandomBrush`` (ds_ffhq.py:145-197) in the reference's order -> (records [n,8], flip0, flip1)."""
@@ -110,7 +124,7 @@ def brush_records(max_tries, s, min_num_vertex=4, max_num_vertex=18, mean_angle=
             py = min(max(path[-1][1] + st * math.sin(a), 0), s)
             path.append((int(px), int(py)))
         thick = int(rng.uniform(min_width, max_width))
-        recs.extend(thick_polyline_records(path, thick, s))
+        recs.append(segment_records(path, thick))
         discs = np.zeros((len(path), REC), dtype=np.int32)
         discs[:, 0] = DISC
         discs[:, 1:3] = np.asarray(path, dtype=np.int32)
