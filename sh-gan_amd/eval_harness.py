@@ -32,6 +32,14 @@ def synthetic_batch(n, resolution, z_dim=512, seed=0, device='cuda', masks='free
     with ``seed`` ('freeform') or Bernoulli(0.7) per pixel ('bernoulli', cheap for throughput runs)."""
     rs = np.random.RandomState(seed)
     real_u8 = rs.randint(0, 256, size=(n, 3, resolution, resolution)).astype(np.uint8)
+    if masks == 'freeform' and torch.device(device).type == 'cuda' and resolution % 32 == 0 and resolution <= 512:
+        # same masks bit for bit, drawn on the device (sh-gan_amd/masks.py): host RNG draws + HIP rasteriser, no H2D of pixels
+        from . import masks as dev_masks
+        np.random.seed(seed)
+        m = dev_masks.random_masks(n, resolution, [0, 1], device=device)
+        z = torch.from_numpy(rs.standard_normal((n, z_dim)).astype(np.float32))
+        real = (torch.from_numpy(real_u8.astype(np.float32)) / 127.5 - 1.0).to(device)
+        return assemble_input(real, m), z.to(device), real_u8, m.cpu().numpy().astype(np.uint8)
     if masks == 'freeform':
         np.random.seed(seed)
         mask = np.stack([RandomMask(resolution, [0, 1]) for _ in range(n)]).astype(np.uint8)
