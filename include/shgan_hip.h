@@ -172,6 +172,11 @@ int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N
 int shg_mask_raster_f32(const int* records, const int* offsets, const int* flips, const int* disc_table, int max_half, float* mask,
                         int* holes, int B, int s, void* stream);
 
+/* ---- next row N1: FID statistics (lib/evaluator/eva_fid.py:251-263).  S [DP,DP] float64 += sum_b w_b [x_b,1][x_b,1]^T on the
+ * fp64 matrix cores: S[:D,:D] = sum x x^T, S[:D,D] = sum x, S[D,D] = count (tiles on / above the diagonal only).
+ * feats [B,D] float32 (float64 when is_f64), weights [B] or NULL, DP >= D+1 a multiple of 32. */
+int shg_fid_accumulate_f64(const void* feats, int is_f64, const float* weights, double* S, int B, int D, int DP, void* stream);
+
 /* ---- next row N3 (training-side critic, forward only): minibatch_std_layer (stylegan.py:686-704).
  * x [N,C,H,W] -> y [N,C+F,H,W]; N % G == 0, C % F == 0; stat [N/G * F] is caller-owned scratch. */
 int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, int H, int W, int G, int F, void* stream);

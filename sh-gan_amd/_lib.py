@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -68,6 +68,7 @@ _SIGS = {
     'shg_conv2d_down_poly_supported': [c_i, c_i, c_i, c_i, c_i],
     'shg_conv2d_down_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_mask_raster_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp],
+    'shg_fid_accumulate_f64': [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_minibatch_std_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
 }
 
