@@ -105,6 +105,19 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     return _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
 
 
+def upfirdn2d_backward(dy, f, x_shape, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """Gradient of ``upfirdn2d`` with respect to its input (training row N3): the same operator with up and down swapped,
+    the filter flipped and the padding of upfirdn2d.py:174-192 -- dy [N,C,OH,OW] -> dx of shape ``x_shape``."""
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    px0, _, py0, _ = _parse_padding(padding)
+    _, _, ih, iw = x_shape
+    _, _, oh, ow = dy.shape
+    fw, fh = _get_filter_size(f)
+    p = [fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1, fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1]
+    return upfirdn2d(dy, f, up=[downx, downy], down=[upx, upy], padding=p, flip_filter=(not flip_filter), gain=gain)
+
+
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
     """FIR-filter keeping the spatial size (zero boundary); extra ``padding`` grows/crops it."""
     px0, px1, py0, py1 = _parse_padding(padding)

@@ -353,3 +353,20 @@ def test_polyphase_winograd_stride2_conv(mods, n, ci, co, h, w):
     # no activation, no bias, no skip: the raw sum of the two schemes
     y0 = kk.fir_conv_down2(x.to(DEV), f.to(DEV), pw)
     assert rel_err(c(y0), F.conv2d(xf, wt * 0.05, stride=2).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('up,down,pad,fshape,shape', [(2, 1, [2, 1, 2, 1], (4, 4), (2, 3, 8, 9)), (1, 2, [1, 1, 1, 1], (4, 4), (1, 2, 16, 14)),
+                                                      (1, 1, [2, 2, 2, 2], (4, 4), (2, 2, 9, 9)), ([2, 1], [1, 3], [3, 2, 1, 2], (3, 5), (1, 2, 7, 12))])
+def test_upfirdn2d_backward_is_the_swapped_operator(mods, up, down, pad, fshape, shape):
+    """Next row N3: d/dx of upfirdn2d (upfirdn2d.py:174-192) = upfirdn2d with up <-> down, flipped filter; checked against
+    torch autograd through the CPU oracle."""
+    orc, ufd = mods['orc'], mods['ufd']
+    rs = np.random.RandomState(19)
+    x = rnd(rs, *shape).requires_grad_(True)
+    f = rnd(rs, *fshape)
+    y = orc.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=1.7)
+    dy = rnd(rs, *y.shape)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    dx = ufd.upfirdn2d_backward(dy.to(DEV), f.to(DEV), tuple(shape), up=up, down=down, padding=pad, gain=1.7)
+    assert tuple(dx.shape) == tuple(shape)
+    assert rel_err(c(dx), ref.numpy()) < 1e-5
