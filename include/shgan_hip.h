@@ -84,6 +84,16 @@ int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu
 int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
                         const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
                         float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* stream);
+/* Winograd F(4x4,3x3) form of the same convolution (conv_wino4.hip; 4x fewer MFMA flops than the direct form, about 1e-5
+ * relative round-off per layer): wu has shg_conv_wino4_weight_elems(OP, I) floats, [OP/64][ceil(I/8)][4][72][64] in the
+ * register layout of the kernel.  shg_conv2d_wino4_supported tells whether the geometry is served (H >= 16, W >= 32,
+ * W % 4 == 0, I <= 1024); otherwise call shg_conv2d_wino_f32 / shg_conv2d_f32. */
+long shg_conv_wino4_weight_elems(int OP, int I);
+int shg_conv_weight_prep_wino4_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip, void* stream);
+int shg_conv2d_wino4_supported(int NB, int I, int O, int H, int W);
+int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                         const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
+                         float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* stream);
 /* mode 2 with out_mode 1 writes the four sub-pixel phases as planes [4][NB,O,H+1,W+1] (coalesced); this kernel applies the
  * 4x4 FIR of conv2d_resample.py:138 (pad 1) straight from the planes and fuses the synthesis-layer tail:
  * y [N,C,2H,2W] = lrelu_agc(FIR(mid)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.  H, W = low-res extents. */

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -48,6 +48,10 @@ _SIGS = {
     'shg_conv_wino_chunk': [],
     'shg_conv_weight_prep_wino_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_wino_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_conv_wino4_weight_elems': [c_i, c_i],
+    'shg_conv_weight_prep_wino4_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'shg_conv2d_wino4_supported': [c_i] * 5,
+    'shg_conv2d_wino4_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_upfir_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_conv1x1_thin_in_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_torgb_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -102,6 +106,7 @@ def get_lib():
     lib.shg_last_error.argtypes = []
     lib.shg_last_error.restype = ctypes.c_char_p
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv_wino4_weight_elems.restype = c_l
     ver = lib.shg_abi_version()
     if ver != ABI_VERSION:
         raise RuntimeError(f'libshgan_hip.so ABI {ver} != expected {ABI_VERSION}: rebuild with sh-gan_amd/build.py')

@@ -1,0 +1,398 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Same operator as conv_wino.hip -- the stride-1 3x3 'same' convolutions (pad 1) of conv2d_resample.py:145-147 as called
+// from stylegan.py:226-238 and, modulated, stylegan.py:103-193 -- with the larger Winograd tile: every 4x4 block of outputs
+// comes from a 6x6 input block with 36 instead of 144 multiplications per (input, output) channel pair (F(2x2,3x3): 64),
+//      Y = A^T [ (G g G^T) .* (B^T d B) ] A ,    interpolation points 0, +-1, +-2, inf (Lavin & Gray).
+// Arithmetic stays fp32 on exact-fp32 MFMA; the transform constants (1/4, 1/6, 1/24, 2, 4, 5, 8) cost about one decimal
+// digit against F(2x2,3x3): measured 1e-5 relative per layer at 512 channels, 5e-6 on the full generator (tolerance of the
+// path: 1e-3).  F(2x2,3x3) stays available (kernels.WINO4 = False) and tested.
+//
+// GEMM view: 36 independent products M_xi[o,t] = sum_i U_xi[i,o] V_xi[i,t] over 64 output channels x 32 blocks (4 x 8
+// blocks = 16 x 32 pixels) = 72 accumulator tiles of 32x32 on 8 waves: waves 0-3 own four positions (8 tiles) each, waves
+// 4-7 five positions (10 tiles) each -- one wave of either kind per SIMD.  K is consumed in chunks of 8 input channels:
+//   * U (pre-transformed weights, [O/64][chunk][k-step][unit][lane]) goes straight into registers: a ring of one chunk
+//     (4 k-steps x 8 or 10 operands), every slot re-loaded for the next chunk right after its MFMAs were issued;
+//   * the raw 18 x 40 window of a channel arrives by 16-byte LDS-DMA (waves 4-7, two channels each);
+//   * waves 0-3 transform two channels each (B^T d B on the 6x6 patch, styles applied) into V [36][8][32] in LDS;
+//   * V and the raw windows are double buffered, one barrier per chunk.
+// Epilogue: the 36 M_xi of an (o, t) pair live in different waves -> exchanged through LDS in four passes of 16 channels x
+// 32 blocks; each thread applies A^T . A, the fused layer tail (demodulation coefficient, noise, bias, lrelu_agc, skip) and
+// stores its 4x4 pixels as four 16-byte rows.
+#include "shg_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float shg_wino4_zeros[64];
+
+struct Wino4Params {
+    const float* x;          // [NB, I, H, W]
+    const float* wu;         // transformed weights [OP/64][nchunk][4 k-steps][72 units][64 lanes]
+    float* y;                // [NB, O, H, W]
+    const float* in_scale;   // [NB, I] or null
+    const float* out_scale;  // [NB, O] or null
+    const float* bias;       // [O] or null
+    const float* noise;      // see noise_mode
+    const float* residual;   // like y, added after the activation
+    int NB, I, O, OP, H, W;
+    int tiles_x, tiles_y;    // tiles per image
+    int n_ttiles, n_otiles, nchunk;
+    int noise_mode;          // 0 none, 1 [H,W], 2 [NB,H,W]
+    float noise_strength;
+    int act;
+    float alpha, gain, clamp;
+};
+
+namespace wino4 {
+constexpr int KC = 8, BO = 64, BT = 32, NPOS = 36, NW = 8, NT = NW * 64, NUNIT = 2 * NPOS;    // unit = (position, 32-channel block)
+constexpr int V_SZ = NPOS * KC * BT;                        // floats per V buffer (36.9 KB)
+template <int TY, int TX>
+struct Tile {
+    static_assert(TY * TX == BT, "32 blocks per tile");
+    static constexpr int PH = 4 * TY + 2, PW = 4 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4, RP = PH * PW, R_SZ = KC * RP;
+    static constexpr int NPIECE = (PATCH4 + 63) / 64;
+};
+static_assert(2 * V_SZ >= NPOS * 16 * 32, "epilogue exchange buffer lives in the V region");
+}   // namespace wino4
+
+__device__ __forceinline__ int wino4_xcd_remap(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// 1-D input transform of F(4,3): B^T d, B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
+__device__ __forceinline__ void wino4_bt(const float (&d)[6], float (&o)[6]) {
+    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    o[1] = a + b; o[2] = a - b;
+    o[3] = c + e; o[4] = c - e;
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// 1-D output transform: A^T m, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+__device__ __forceinline__ void wino4_at(const float (&m)[6], float (&o)[4]) {
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    o[0] = m[0] + s12 + s34;
+    o[1] = d12 + 2.f * d34;
+    o[2] = s12 + 4.f * s34;
+    o[3] = d12 + 8.f * d34 + m[5];
+}
+
+template <int TY, int TX>
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p) {
+    using namespace wino4;
+    using T = Tile<TY, TX>;
+    constexpr int PW = T::PW, PW4 = T::PW4, PATCH4 = T::PATCH4, RP = T::RP, R_SZ = T::R_SZ, NPIECE = T::NPIECE;
+    __shared__ __attribute__((aligned(16))) float Vl[2 * V_SZ];      // [2][36][KC][32]
+    __shared__ __attribute__((aligned(16))) float Rl[2 * R_SZ];      // [2][KC][RP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int nwork = p.n_ttiles * p.n_otiles;
+    const int work = wino4_xcd_remap(blockIdx.x, nwork);
+    const int otile = work / p.n_ttiles;
+    const int ttile = work - otile * p.n_ttiles;
+    const int txb = ttile % p.tiles_x;
+    const int tyb = (ttile / p.tiles_x) % p.tiles_y;
+    const int n = ttile / (p.tiles_x * p.tiles_y);
+    const int oy0 = tyb * (4 * TY), ox0 = txb * (4 * TX);
+    const int o0 = otile * BO;
+    const int HW = p.H * p.W;
+
+    // ---- staging roles: waves 0..3 transform two channels each; waves 4..7 fetch the raw windows of two channels each
+    const bool xformer = wave < 4;
+    int roff[NPIECE];
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+        const int q = j * 64 + lane;
+        const int py = q / PW4, p4 = q - py * PW4;
+        const int iy = oy0 - 1 + py, ix = ox0 - 4 + 4 * p4;
+        const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
+        roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
+    }
+    const bool ract_last = lane < PATCH4 - 64 * (NPIECE - 1);
+    auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = (wave - 4) * 2 + q;
+            const int ch = c * KC + k;
+            const bool chok = ch < p.I;
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) {
+                const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino4_zeros;
+                if (j < NPIECE - 1 || ract_last)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- input transform role: channel 2*wave + half, block l31 (ty = l31 / TX, tx = l31 % TX)
+    const int tty = l31 / TX, ttx = l31 % TX;
+    const float* rbase = Rl + (2 * wave + half) * RP + (4 * tty) * PW + 4 * ttx + 3;     // patch (0,0) = window (4ty, 4tx + 3)
+    float* vbase = Vl + (2 * wave + half) * BT + l31;            // + xi*KC*BT
+    // styles of this wave's two channels for every chunk, one lane per chunk (up to 128 chunks)
+    float sca[2], scb[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int ch = (v * 64 + lane) * KC + 2 * wave;
+        sca[v] = (p.in_scale && xformer && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
+        scb[v] = (p.in_scale && xformer && ch + 1 < p.I) ? p.in_scale[(long)n * p.I + ch + 1] : 1.f;
+    }
+    auto transform = [&](int c, int buf) __attribute__((always_inline)) {
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? sca[0] : sca[1]), c & 63));
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scb[0] : scb[1]), c & 63));
+        const float sc = half ? s1 : s0;
+        const float* rb = rbase + buf * R_SZ;
+        float* vb = vbase + buf * V_SZ;
+        // columns first: t[.][cc] = B^T d[.][cc]; then rows
+        float t[6][6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            float d[6], o[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) d[r] = rb[r * PW + cc] * sc;
+            wino4_bt(d, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[r][cc] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float o[6];
+            wino4_bt(t[r], o);
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) vb[(r * 6 + cc) * KC * BT] = o[cc];
+        }
+    };
+
+    // ---- epilogue geometry (all threads): 16 x 32 (channel, block) items per pass
+    float* Mx = Vl;                           // [36][16][32]
+    const long plane = (long)p.H * p.W;
+    const int o_l = tid >> 5, t_l = tid & 31;
+    const int by = t_l / TX, bx = t_l % TX;
+    const int oy = oy0 + 4 * by, ox = ox0 + 4 * bx;
+    auto finish = [&](int pass) __attribute__((always_inline)) {
+        const int ob = pass >> 1, h = pass & 1;
+        const int o = o0 + ob * 32 + 16 * h + o_l;
+        // A^T m A: rows of m first (over the position columns), then columns
+        float tmp[6][4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float m[6], a4[4];
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) m[cc] = Mx[((r * 6 + cc) * 16 + o_l) * 32 + t_l];
+            wino4_at(m, a4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tmp[r][k] = a4[k];
+        }
+        if (o < p.O && oy < p.H && ox < p.W) {
+            const float osc = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
+            const float bs = p.bias ? p.bias[o] : 0.f;
+            const long base = ((long)n * p.O + o) * plane;
+            float yv[4][4];                                       // output column k of the block needs tmp[.][k]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float col[6] = {tmp[0][k], tmp[1][k], tmp[2][k], tmp[3][k], tmp[4][k], tmp[5][k]};
+                float a4[4];
+                wino4_at(col, a4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yv[i][k] = a4[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (oy + i >= p.H) continue;
+                const long pix = (long)(oy + i) * p.W + ox;       // W % 4 == 0, ox % 4 == 0: 16-byte aligned, all four inside
+                f32x4 nz = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+                if (p.noise_mode) nz = *reinterpret_cast<const f32x4*>(p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + pix);
+                if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + base + pix);
+                f32x4 out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = yv[i][k] * osc + nz[k] * p.noise_strength + bs;
+                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
+                    out[k] = v + rs[k];
+                }
+                *reinterpret_cast<f32x4*>(p.y + base + pix) = out;
+            }
+        }
+    };
+
+    // ---- the two wave classes.  Transform waves (0..3) own 4 positions x 2 channel blocks = 8 accumulator tiles, fetch waves
+    // (4..7) own 5 x 2 = 10: each SIMD hosts one wave of either class, so the matrix pipes are loaded evenly (18 tiles) and
+    // the transform's temporaries live in the registers the two missing accumulators would take.
+    auto body = [&](auto nu_c, auto xf_c) __attribute__((always_inline)) {
+        constexpr int NU = decltype(nu_c)::value;                // accumulator tiles of this wave
+        constexpr bool XF = decltype(xf_c)::value;
+        constexpr int NP = NU / 2;
+        const int pfirst = XF ? 4 * wave : 16 + 5 * (wave - 4);
+        // weights: a register ring of one chunk; slot (ks, j) = MFMA A operand of unit 2*pfirst + j at k-step ks
+        const float* ubase = p.wu + ((size_t)otile * p.nchunk * 4 * NUNIT + 2 * pfirst) * 64 + lane;
+        constexpr size_t ustride = (size_t)4 * NUNIT * 64;       // floats per chunk
+        float ur[4][NU];
+        auto load_u = [&](int c, int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) ur[ks][j] = ubase[(size_t)c * ustride + (ks * NUNIT + j) * 64];
+        };
+        f32x16 acc[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const float* bbase = Vl + (pfirst * KC + half) * BT + l31;   // + pidx*KC*BT + ks*2*BT
+
+        // prologue
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) load_u(0, ks);
+        if constexpr (!XF) {
+            dma_raw(0, 0);
+            if (p.nchunk > 1) dma_raw(1, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (XF) transform(0, 0);
+        __syncthreads();
+
+        for (int c = 0; c < p.nchunk; ++c) {
+            const int buf = c & 1;
+            const bool more = c + 1 < p.nchunk;
+            const float* bb = bbase + buf * V_SZ;
+            if constexpr (!XF) {
+                if (c + 2 < p.nchunk) dma_raw(c + 2, buf);       // raw(c) was consumed during chunk c-1
+            } else {
+                if (more) transform(c + 1, buf ^ 1);             // raw(c+1) landed before the previous barrier
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = bb[(q * KC + ks * 2) * BT];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[ks][j], b[j >> 1], acc[j], 0, 0, 0);
+                if (more) load_u(c + 1, ks);                     // this slot's operands of the next chunk
+            }
+            if constexpr (!XF) {
+                // the DMA of raw(c+2) went out before this chunk's 4*NU weight loads: in-order retirement makes "at most 4*NU
+                // outstanding" mean "the window has landed" without waiting for the weights
+                if (c + 2 < p.nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NU) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+
+        // epilogue: four passes (channel block ob, row half h) of 16 channels x 32 blocks x 36 positions through LDS
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int ob = pass >> 1, h = pass & 1;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * h + rr;
+                    const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;       // row inside the 16-row half
+                    Mx[((pfirst + q) * 16 + lr) * 32 + l31] = acc[2 * q + ob][r];
+                }
+            }
+            __syncthreads();
+            finish(pass);
+            if (pass < 3) __syncthreads();
+        }
+    };
+    if (xformer) body(std::integral_constant<int, 8>{}, std::true_type{});
+    else body(std::integral_constant<int, 10>{}, std::false_type{});
+}
+
+// U = G g G^T per (o, i), G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]; g = w[o,i] * scale[o].
+// Layout wu[otile][chunk][k-step][unit][lane]: unit u = (position u/2, channel block u%2); lane = (i & 1) * 32
+// + o % 32 holds the MFMA A operand of k-step (i % 8) / 2.
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* w, const float* scale, float* wu, int O, int I, int OP,
+                                                           int nchunk, int flip) {
+    constexpr int KC = wino4::KC;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)OP * nchunk * KC;
+    if (e >= total) return;
+    const int o = (int)(e % OP);
+    const int i = (int)(e / OP);
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        g[t / 3][t % 3] = (o < O && i < I) ? w[((long)o * I + i) * 9 + tt] * scale[o] : 0.f;
+    }
+    float gg[6][3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const float a = g[0][cc], b = g[1][cc], c = g[2][cc];
+        gg[0][cc] = a * 0.25f;
+        gg[1][cc] = (-a - b - c) * (1.f / 6.f);
+        gg[2][cc] = (-a + b - c) * (1.f / 6.f);
+        gg[3][cc] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+        gg[4][cc] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+        gg[5][cc] = c;
+    }
+    const int k = i % KC, chunk = i / KC;
+    const int ln = (k & 1) * 32 + (o & 31), ks = k >> 1, obk = (o & 63) >> 5;
+    float* base = wu + ((size_t)(o >> 6) * nchunk + chunk) * (4 * wino4::NUNIT * 64);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float a = gg[r][0], b = gg[r][1], c = gg[r][2];
+        const float row[6] = {a * 0.25f, (-a - b - c) * (1.f / 6.f), (-a + b - c) * (1.f / 6.f),
+                              a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f), a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f), c};
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+            const int u = (r * 6 + cc) * 2 + obk;
+            base[((size_t)ks * wino4::NUNIT + u) * 64 + ln] = row[cc];
+        }
+    }
+}
+
+// floats of the F(4x4,3x3) weight tensor for (OP, I)
+extern "C" long shg_conv_wino4_weight_elems(int OP, int I) {
+    return (long)(OP / 64) * shg_cdiv(I, wino4::KC) * 4 * wino4::NUNIT * 64;
+}
+
+extern "C" int shg_conv_weight_prep_wino4_f32(const float* w, const float* wscale, float* wu, int O, int I, int OP, int flip,
+                                              void* stream) {
+    SHG_CHECK_ARG(w && wscale && wu, "weight_prep_wino4: null pointer");
+    SHG_CHECK_ARG(O >= 1 && I >= 1 && OP % 64 == 0 && OP >= O, "weight_prep_wino4: bad shape");
+    const int nchunk = shg_cdiv(I, wino4::KC);
+    const long total = (long)OP * nchunk * wino4::KC;
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3(shg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wscale, wu, O, I, OP,
+                       nchunk, flip);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// 1 when shg_conv2d_wino4_f32 serves the geometry (otherwise shg_conv2d_wino_f32 / shg_conv2d_f32)
+extern "C" int shg_conv2d_wino4_supported(int NB, int I, int O, int H, int W) {
+    return (H >= 16 && W >= 32 && W % 4 == 0 && I <= 128 * wino4::KC && NB >= 1 && O >= 1) ? 1 : 0;
+}
+
+// y = act(out_scale[n,o] * conv3x3_same(x * in_scale[n,i], w) + noise*noise_strength + bias[o]) + residual, stride 1, pad 1.
+extern "C" int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                    const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                    int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                    const float* residual, void* stream) {
+    SHG_CHECK_ARG(x && wu && y, "conv2d_wino4: null pointer");
+    SHG_CHECK_ARG(shg_conv2d_wino4_supported(NB, I, O, H, W), "conv2d_wino4: unsupported geometry (use shg_conv2d_wino_f32)");
+    SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino4: OP must be a multiple of 64 and >= O");
+    SHG_CHECK_ARG((long)NB * I * H * W < 2147483647L && (long)NB * O * H * W < 2147483647L, "conv2d_wino4: tensor too large");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(noise) |
+                    reinterpret_cast<uintptr_t>(residual)) & 15) == 0, "conv2d_wino4: x / y / noise / residual must be 16-byte aligned");
+    Wino4Params p{};
+    p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
+    p.noise = noise_mode ? noise : nullptr; p.residual = residual;
+    p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
+    p.tiles_x = shg_cdiv(W, 32); p.tiles_y = shg_cdiv(H, 16);
+    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino4::KC);
+    p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    hipLaunchKernelGGL((conv_wino4_kernel<4, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(wino4::NT), 0, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

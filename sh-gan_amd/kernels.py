@@ -297,11 +297,11 @@ def assemble_input(real, mask):
 class PreppedWeight:
     """GEMM-layout weights produced by shg_conv_weight_prep_f32 (+ the demodulation table wsq).  ``wu`` (Winograd
     F(2x2,3x3) layout, shg_conv_weight_prep_wino_f32) is built on first use by a stride-1 3x3 convolution."""
-    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', 'wu_up', 'wu_down', '_w', '_wscale', '_flip')
+    __slots__ = ('wt', 'wsq', 'o', 'i', 'op', 'kh', 'kw', 'groups', 'wu', 'wu4', 'wu_up', 'wu_down', '_w', '_wscale', '_flip')
 
     def __init__(self, wt, wsq, o, i, op, kh, kw, groups=1, w=None, wscale=None, flip=False):
         self.wt, self.wsq, self.o, self.i, self.op, self.kh, self.kw, self.groups = wt, wsq, o, i, op, kh, kw, groups
-        self.wu, self.wu_up, self.wu_down, self._w, self._wscale, self._flip = None, None, None, w, wscale, flip
+        self.wu, self.wu4, self.wu_up, self.wu_down, self._w, self._wscale, self._flip = None, None, None, None, w, wscale, flip
 
     def _poly(self, entry):
         if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
@@ -341,6 +341,19 @@ class PreppedWeight:
                                                                    int(bool(self._flip)), L.stream()), 'conv_weight_prep_wino')
         return self.wu
 
+    def wino4(self):
+        """Winograd F(4x4,3x3) weights (shg_conv_weight_prep_wino4_f32), built on first use."""
+        if self.wu4 is None:
+            if self._w is None or self.groups != 1 or self.kh != 3 or self.kw != 3:
+                raise _lib.ShgError('PreppedWeight.wino4: needs an ungrouped 3x3 weight')
+            L = _Launch()
+            w, ws = L.req(self._w, 'w'), L.req(self._wscale, 'wscale')
+            self.wu4 = L.new((int(_lib.get_lib().shg_conv_wino4_weight_elems(self.op, self.i)),))
+            with L:
+                check(_lib.get_lib().shg_conv_weight_prep_wino4_f32(_ptr(w), _ptr(ws), _ptr(self.wu4), self.o, self.i, self.op,
+                                                                    int(bool(self._flip)), L.stream()), 'conv_weight_prep_wino4')
+        return self.wu4
+
 
 def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
     """w [O,I,kh,kw] (or [G*Og, I, kh, kw] with ``groups``) -> PreppedWeight (one layout for all conv modes)."""
@@ -369,6 +382,8 @@ def conv_weight_prep(w, demod=False, gain=1.0, flip=False, groups=1):
 # test set ``kernels.WINO = False`` to keep everything on the direct implicit-GEMM kernel.
 WINO = True
 WINO_MIN = 16
+WINO4 = True            # F(4x4,3x3) (conv_wino4.hip) where it is served and the image has at least WINO4_MIN rows; else F(2x2,3x3)
+WINO4_MIN = 32
 UP_POLY = True          # stride-2 transposed 3x3 convolutions in the polyphase-Winograd form (conv_wino_poly.hip)
 DOWN_POLY = True        # FIR-filtered stride-2 3x3 convolutions likewise (fir_down_planar + conv2d_down_poly)
 
@@ -405,8 +420,16 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
         raise _lib.ShgError('conv2d: residual shape mismatch')
     if (WINO and mode == MODE_SAME and pad == 1 and pw.kh == 3 and pw.kw == 3 and pw.groups == 1 and h >= WINO_MIN and w >= WINO_MIN
             and w % 4 == 0 and x.data_ptr() % 16 == 0 and i <= 1024 and (pw.wu is not None or pw._w is not None)):
-        wu = pw.wino()
         direct = 2.0 * nb * pw.o * i * 9 * oh * ow                                # direct-form (algorithmic) flops
+        if WINO4 and h >= WINO4_MIN and lib.shg_conv2d_wino4_supported(nb, i, pw.o, h, w):
+            wu = pw.wino4()
+            executed = 2.0 * nb * pw.o * i * 36.0 * ((h + 3) // 4) * ((w + 3) // 4)
+            with _timed(L, 'conv_wino4', direct, executed):
+                check(lib.shg_conv2d_wino4_f32(
+                    _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise),
+                    nmode, float(noise_strength), a, al, g, cl, _ptr(residual), L.stream()), 'conv2d_wino4')
+            return y
+        wu = pw.wino()
         with _timed(L, 'conv_wino', direct, direct * 16.0 / 36.0):
             check(lib.shg_conv2d_wino_f32(
                 _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise), nmode,

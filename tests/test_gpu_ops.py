@@ -173,26 +173,85 @@ def test_wino_conv_vs_torch_cpu_and_direct(mods, n, ci, co, h, w):
         ref = orc.lrelu_agc(ref + bias.view(1, -1, 1, 1), gain=0.5) + res
         args = dict(mode=0, pad=1, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
                     noise_strength=0.25, act=True, gain=0.5, residual=res.to(DEV))
-        old = kk.WINO
+        old = kk.WINO, kk.WINO4
         try:
-            kk.WINO = True
+            kk.WINO, kk.WINO4 = True, False
             pw = kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip)
             y = kk.conv2d(x.to(DEV), pw, **args)
             assert (pw.wu is not None) == (w % 4 == 0), 'Winograd dispatch: taken iff the 16-byte window DMA applies'
+            assert pw.wu4 is None
             kk.WINO = False
             yd = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip), **args)
         finally:
-            kk.WINO = old
+            kk.WINO, kk.WINO4 = old
         assert rel_err(c(y), ref.numpy()) < 2e-5
         assert rel_err(c(y), c(yd)) < 2e-5
     # plain form: no fused operands, linear output
-    kk_old = kk.WINO
+    old = kk.WINO, kk.WINO4
     try:
-        kk.WINO = True
+        kk.WINO, kk.WINO4 = True, False
         y = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV)), mode=0, pad=1)
     finally:
-        kk.WINO = kk_old
+        kk.WINO, kk.WINO4 = old
     assert rel_err(c(y), F.conv2d(x, wt, padding=1).numpy()) < 2e-5
+
+
+WINO4_CASES = [
+    # n, ci, co, h, w : ragged channel counts (I % 8, O % 64, O % 32), extents that are no multiple of the 16 x 32 tile or of 4
+    (2, 64, 64, 32, 32), (1, 13, 70, 33, 36), (3, 8, 3, 40, 64), (2, 72, 130, 35, 68), (1, 128, 64, 64, 96), (2, 5, 5, 32, 44),
+    (1, 512, 96, 48, 32),     # 64 K-chunks: the style table spans a whole wave
+    (1, 16, 16, 32, 33), (2, 16, 16, 16, 32),      # W % 4 != 0 -> direct kernel; fewer than WINO4_MIN rows -> F(2x2,3x3)
+]
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', WINO4_CASES)
+def test_wino4_conv_vs_torch_cpu_and_direct(mods, n, ci, co, h, w):
+    """Winograd F(4x4,3x3) kernel (shg_conv2d_wino4_f32) vs torch CPU conv2d (fp64) and vs the direct MFMA kernel, with the
+    whole fused tail and flipped weights.  Tolerance 1e-4 of the output range: the 4x4 transform's constants cost about one
+    decimal digit against the direct form (measured 3e-6..1.2e-5)."""
+    import torch.nn.functional as F
+    kk, orc = mods['kernels'], mods['orc']
+    rs = np.random.RandomState(n * 100 + ci + co + h)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = torch.from_numpy(rs.standard_normal((co, ci, 3, 3)).astype(np.float32))
+    s_in = torch.from_numpy(rs.rand(n, ci).astype(np.float32) + 0.5)
+    s_out = torch.from_numpy(rs.rand(n, co).astype(np.float32) + 0.5)
+    bias = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((n, 1, h, w)).astype(np.float32))
+    res = torch.from_numpy(rs.standard_normal((n, co, h, w)).astype(np.float32))
+    served = w % 4 == 0 and h >= kk.WINO4_MIN
+    for flip in (False, True):
+        wref = wt.flip([2, 3]) if flip else wt
+        ref = F.conv2d((x * s_in[:, :, None, None]).double(), wref.double() * 0.1, padding=1) * s_out[:, :, None, None].double() + noise.double() * 0.25
+        ref = orc.lrelu_agc((ref + bias.view(1, -1, 1, 1).double()).float(), gain=0.5) + res
+        args = dict(mode=0, pad=1, in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV), noise=noise.to(DEV),
+                    noise_strength=0.25, act=True, gain=0.5, residual=res.to(DEV))
+        old = kk.WINO, kk.WINO4
+        try:
+            kk.WINO, kk.WINO4 = True, True
+            pw = kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip)
+            y = kk.conv2d(x.to(DEV), pw, **args)
+            assert (pw.wu4 is not None) == served, 'F(4x4) dispatch'
+            kk.WINO = False
+            yd = kk.conv2d(x.to(DEV), kk.conv_weight_prep(wt.to(DEV), gain=0.1, flip=flip), **args)
+        finally:
+            kk.WINO, kk.WINO4 = old
+        e_ref, e_dir = rel_err(c(y), ref.numpy()), rel_err(c(y), c(yd))
+        print(f'wino4 n{n} i{ci} o{co} {h}x{w} flip{int(flip)}: vs fp64 {e_ref:.2e} vs direct {e_dir:.2e}')
+        assert e_ref < 1e-4 and e_dir < 1e-4
+        if served:
+            assert not torch.equal(y, yd)
+    # plain form: no fused operands, linear output; the batch handled image by image gives the same bits
+    old = kk.WINO, kk.WINO4
+    try:
+        kk.WINO, kk.WINO4 = True, True
+        pw = kk.conv_weight_prep(wt.to(DEV))
+        y = kk.conv2d(x.to(DEV), pw, mode=0, pad=1)
+        y0 = kk.conv2d(x[:1].to(DEV), pw, mode=0, pad=1)
+    finally:
+        kk.WINO, kk.WINO4 = old
+    assert rel_err(c(y), F.conv2d(x.double(), wt.double(), padding=1).numpy()) < 1e-4
+    assert torch.equal(y[:1], y0)
 
 
 def test_mfma_conv_fused_epilogue(mods):
