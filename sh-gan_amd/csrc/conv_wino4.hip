@@ -25,8 +25,20 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) float shg_wino4_zeros[64];
+
+#ifdef SHG_W4_TRACE
+// timeline study (tools/w4_variant.sh trace -DSHG_W4_TRACE=1): workgroup 0 records clock64() at six points of chunks 8..15
+__device__ long long shg_wino4_trace_buf[8 * 8 * 8];
+extern "C" int shg_wino4_trace_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shg_wino4_trace_buf), sizeof(shg_wino4_trace_buf));
+}
+#define W4_TRACE(slot) do { if (blockIdx.x == 0 && c >= 8 && c < 16 && lane == 0) shg_wino4_trace_buf[(wave * 8 + (c - 8)) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define W4_TRACE(slot) do { } while (0)
+#endif
 
 struct Wino4Params {
     const float* x;          // [NB, I, H, W]
@@ -44,6 +56,13 @@ struct Wino4Params {
     float noise_strength;
     int act;
     float alpha, gain, clamp;
+    // timing studies (tools/w4_variant.sh <tag> -DSHG_WINO4_DBG=<bits>: 1 skip weight loads, 2 skip window DMA, 4 skip transform,
+    // 8 skip MFMA, 16 skip epilogue); the product build folds every `p.dbg & ...` branch away
+#ifdef SHG_WINO4_DBG
+    static constexpr int dbg = SHG_WINO4_DBG;
+#else
+    static constexpr int dbg = 0;
+#endif
 };
 
 namespace wino4 {
@@ -52,8 +71,11 @@ constexpr int V_SZ = NPOS * KC * BT;                        // floats per V buff
 template <int TY, int TX>
 struct Tile {
     static_assert(TY * TX == BT, "32 blocks per tile");
-    static constexpr int PH = 4 * TY + 2, PW = 4 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4, RP = PH * PW, R_SZ = KC * RP;
-    static constexpr int NPIECE = (PATCH4 + 63) / 64;
+    // a channel's window is PH x PW floats, fetched as NPIECE whole-wave pieces of 64 x 16 bytes; its LDS slot RP is rounded up to
+    // whole pieces so that every lane of every piece is active (lanes past the window store zeros into the padding): a
+    // partially masked piece becomes a branch, and a branch makes the compiler wait for ALL outstanding loads behind it.
+    static constexpr int PH = 4 * TY + 2, PW = 4 * TX + 8, PW4 = PW / 4, PATCH4 = PH * PW4;
+    static constexpr int NPIECE = (PATCH4 + 63) / 64, RP = NPIECE * 256, R_SZ = KC * RP;
 };
 static_assert(2 * V_SZ >= NPOS * 16 * 32, "epilogue exchange buffer lives in the V region");
 }   // namespace wino4
@@ -66,8 +88,9 @@ __device__ __forceinline__ int wino4_xcd_remap(int bid, int total) {
 }
 
 // 1-D input transform of F(4,3): B^T d, B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
-__device__ __forceinline__ void wino4_bt(const float (&d)[6], float (&o)[6]) {
-    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+template <class T>
+__device__ __forceinline__ void wino4_bt(const T (&d)[6], T (&o)[6]) {
+    const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
     o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     o[1] = a + b; o[2] = a - b;
     o[3] = c + e; o[4] = c - e;
@@ -116,26 +139,31 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
         roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
     }
-    const bool ract_last = lane < PATCH4 - 64 * (NPIECE - 1);
+    auto dma_piece = [&](int c, int buf, int q, int j) __attribute__((always_inline)) {
+        if (p.dbg & 2) return;
+        const int k = (wave - 4) * 2 + q;
+        const int ch = c * KC + k;
+        const bool chok = ch < p.I;                              // (also false for chunks past the end)
+        const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino4_zeros;
+        // Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: the compiler orders every later LDS read (and,
+        // with 40+ loads in flight, every use of a loaded register) behind an LDS-DMA it knows about with `s_waitcnt vmcnt(0)`,
+        // i.e. it waits for the weight loads issued a few instructions earlier.  The windows are ordered by hand (the counted
+        // vmcnt before the chunk's barrier); to the compiler's own counts these are unknown extra loads, which only makes its
+        // waits for older loads conservative.
+        const unsigned lds = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "m0", "memory");
+    };
     auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = (wave - 4) * 2 + q;
-            const int ch = c * KC + k;
-            const bool chok = ch < p.I;
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < NPIECE; ++j) {
-                const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino4_zeros;
-                if (j < NPIECE - 1 || ract_last)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256), 16, 0, 0);
-            }
-        }
+            for (int j = 0; j < NPIECE; ++j) dma_piece(c, buf, q, j);
     };
 
     // ---- input transform role: channel 2*wave + half, block l31 (ty = l31 / TX, tx = l31 % TX)
     const int tty = l31 / TX, ttx = l31 % TX;
-    const float* rbase = Rl + (2 * wave + half) * RP + (4 * tty) * PW + 4 * ttx + 3;     // patch (0,0) = window (4ty, 4tx + 3)
+    const float* rbase = Rl + (2 * wave + half) * RP + (4 * tty) * PW + 4 * ttx;         // patch (0,0) = window (4ty, 4tx + 3)
     float* vbase = Vl + (2 * wave + half) * BT + l31;            // + xi*KC*BT
     // styles of this wave's two channels for every chunk, one lane per chunk (up to 128 chunks)
     float sca[2], scb[2];
@@ -145,30 +173,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         sca[v] = (p.in_scale && xformer && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
         scb[v] = (p.in_scale && xformer && ch + 1 < p.I) ? p.in_scale[(long)n * p.I + ch + 1] : 1.f;
     }
-    auto transform = [&](int c, int buf) __attribute__((always_inline)) {
+    // The transform of one chunk, cut into stages that the main loop places between the wave's MFMAs:
+    //   read(r)  : row r of the 6x6 patch as three ds_read_b128 (window columns 4tx .. 4tx+11, the patch is 3..8).  With the
+    //              40-float row pitch the 16-lane groups of a b128 read touch all 64 banks once; single-dword reads of the same
+    //              patch are 4-way conflicted (lane pitch 16 B) and were a third of the kernel's LDS time;
+    //   row(r)   : u[r][.] = d[r][.] B, style applied;
+    //   col(j)   : V[.][j] = B^T u[.][j], six positions written to V.
+    auto style_of = [&](int c) __attribute__((always_inline)) {
         const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? sca[0] : sca[1]), c & 63));
         const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scb[0] : scb[1]), c & 63));
-        const float sc = half ? s1 : s0;
-        const float* rb = rbase + buf * R_SZ;
-        float* vb = vbase + buf * V_SZ;
-        // columns first: t[.][cc] = B^T d[.][cc]; then rows
-        float t[6][6];
+        return half ? s1 : s0;
+    };
+    auto tr_read = [&](int r, f32x4 (&w)[3], int buf) __attribute__((always_inline)) {
+        if (p.dbg & 4) return;
+        const f32x4* rb = reinterpret_cast<const f32x4*>(rbase + buf * R_SZ + r * PW);
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-            float d[6], o[6];
+        for (int q = 0; q < 3; ++q) w[q] = rb[q];
+    };
+    auto tr_row = [&](int r, const f32x4 (&w)[3], float (&u)[6][6], float sc) __attribute__((always_inline)) {
+        if (p.dbg & 4) return;
+        const float di[6] = {w[0][3] * sc, w[1][0] * sc, w[1][1] * sc, w[1][2] * sc, w[1][3] * sc, w[2][0] * sc};
+        wino4_bt(di, u[r]);
+    };
+    auto tr_col = [&](int j, const float (&u)[6][6], int buf) __attribute__((always_inline)) {
+        if (p.dbg & 4) return;
+        float* vb = vbase + buf * V_SZ + j * KC * BT;
+        const float di[6] = {u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]};
+        float o[6];
+        wino4_bt(di, o);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = rb[r * PW + cc] * sc;
-            wino4_bt(d, o);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) t[r][cc] = o[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            float o[6];
-            wino4_bt(t[r], o);
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) vb[(r * 6 + cc) * KC * BT] = o[cc];
-        }
+        for (int i = 0; i < 6; ++i) vb[i * 6 * KC * BT] = o[i];
     };
 
     // ---- epilogue geometry (all threads): 16 x 32 (channel, block) items per pass
@@ -246,46 +280,129 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         const float* bbase = Vl + (pfirst * KC + half) * BT + l31;   // + pidx*KC*BT + ks*2*BT
 
-        // prologue
+        // prologue: weights of k-steps 0..2 of chunk 0 (slot 3 is filled at the top of the chunk that uses it), the first windows
+        // and the first transform
+        float b[2][NP];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) load_u(0, ks);
+        for (int ks = 0; ks < 3; ++ks) load_u(0, ks);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) ur[3][j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) b[1][q] = 0.f;
         if constexpr (!XF) {
             dma_raw(0, 0);
-            if (p.nchunk > 1) dma_raw(1, 1);
+            dma_raw(1, 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), as an instruction the compiler's wait-count tracking sees
         __syncthreads();
-        if constexpr (XF) transform(0, 0);
+        if constexpr (XF) {
+            f32x4 w[3];
+            float u[6][6];
+            const float sc = style_of(0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                tr_read(r, w, 0);
+                tr_row(r, w, u, sc);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) tr_col(j, u, 0);
+        }
         __syncthreads();
 
+        // Main loop.  Issue order is pinned instruction group by instruction group (sched_barrier): every MFMA is followed by the
+        // load that refills its weight slot (one texture instruction per 64-cycle MFMA instead of bursts from eight waves at
+        // once), by one piece of the window DMA (fetch waves) or by one stage of the next chunk's input transform (transform
+        // waves: ~20 VALU + a few LDS instructions, issued while the MFMA occupies the matrix pipe).  The MFMA stream is skewed by
+        // one k-step against the barriers: the last k-step's operands stay in registers and are multiplied after the barrier,
+        // while the first B operands of the next chunk are on their way from LDS.
+        // Every iteration issues the same loads (past the end: re-fetches / zeros) so the compiler's wait counts for the weight
+        // ring stay exact.
+#ifdef SHG_W4_PRIO
+        if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
+#endif
+        const int last = p.nchunk - 1;
+        auto fetch = [&](const float* bb, int ks, int pb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) b[pb][q] = bb[(q * KC + ks * 2) * BT];
+        };
+        auto mma = [&](int ks, int pb, int j) __attribute__((always_inline)) {
+            if (!(p.dbg & 8)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[ks][j], b[pb][j >> 1], acc[j], 0, 0, 0);
+        };
+        auto refill = [&](int c, int ks, int j) __attribute__((always_inline)) {
+            if (!(p.dbg & 1)) ur[ks][j] = ubase[(size_t)c * ustride + (ks * NUNIT + j) * 64];
+        };
         for (int c = 0; c < p.nchunk; ++c) {
             const int buf = c & 1;
-            const bool more = c + 1 < p.nchunk;
+            const int cn = c < last ? c + 1 : last;
             const float* bb = bbase + buf * V_SZ;
-            if constexpr (!XF) {
-                if (c + 2 < p.nchunk) dma_raw(c + 2, buf);       // raw(c) was consumed during chunk c-1
-            } else {
-                if (more) transform(c + 1, buf ^ 1);             // raw(c+1) landed before the previous barrier
+            f32x4 w[2][3];
+            float u[6][6];
+            float sc = 1.f;
+            if constexpr (XF) sc = style_of(cn);
+            W4_TRACE(0);
+            fetch(bb, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // MFMA m of the chunk: group m / NU (0 = k-step 3 of the previous chunk -- zeros the first time round --, 1..3 = k-steps
+            // 0..2), unit m % NU.  The load that refills a weight slot is issued RFD MFMAs after the MFMA that read the slot: issued
+            // right behind it, the load waits until the MFMA has released the register (about 30 cycles per MFMA when the wave has
+            // the pipe to itself).
+            constexpr int RFD = 2;
+            auto refill_m = [&](int m) __attribute__((always_inline)) {
+                if (m / NU == 0) refill(c, 3, m % NU);
+                else refill(cn, m / NU - 1, m % NU);
+            };
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                mma(3, 1, j);
+                if constexpr (!XF) {
+                    if (j < 2 * NPIECE) dma_piece(c + 2, buf, j / NPIECE, j % NPIECE);   // raw(c) was consumed during chunk c-1
+                }
+                if (j >= RFD) refill_m(j - RFD);
+                if constexpr (XF) {
+                    if (j < 6) tr_read(j, w[j & 1], buf ^ 1);                     // raw(c+1) landed before the previous barrier
+                    if (j >= 1 && j < 7) tr_row(j - 1, w[(j - 1) & 1], u, sc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            W4_TRACE(1);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                if (ks == 1) W4_TRACE(2);
+                if (ks == 2) W4_TRACE(3);
+                fetch(bb, ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    mma(ks, ks & 1, j);
+                    refill_m((ks + 1) * NU + j - RFD);
+                    if constexpr (XF) {
+                        if (ks == 0 && j < 6) tr_col(j, u, buf ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                float b[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q) b[q] = bb[(q * KC + ks * 2) * BT];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[ks][j], b[j >> 1], acc[j], 0, 0, 0);
-                if (more) load_u(c + 1, ks);                     // this slot's operands of the next chunk
-            }
-            if constexpr (!XF) {
-                // the DMA of raw(c+2) went out before this chunk's 4*NU weight loads: in-order retirement makes "at most 4*NU
-                // outstanding" mean "the window has landed" without waiting for the weights
-                if (c + 2 < p.nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NU) : "memory");
-            }
+            for (int m = 4 * NU - RFD; m < 4 * NU; ++m) refill_m(m);
+            // the last window piece went out ahead of all but 2*NPIECE - 1 - RFD of the chunk's 4*NU weight loads: in-order retirement makes
+            // "at most that many outstanding" mean "the window has landed" without waiting for the weights
+            W4_TRACE(4);
+            if constexpr (!XF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NU - 2 * NPIECE + 1 + RFD) : "memory");
+            // raw barrier: __syncthreads() carries a release fence that the compiler lowers to `s_waitcnt vmcnt(0)`, i.e. a wait for
+            // the weight loads just issued.  LDS traffic is ordered by lgkmcnt(0), the DMA by the count above.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();
+            W4_TRACE(5);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            W4_TRACE(6);
         }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) mma(3, 1, j);
 
         // epilogue: four passes (channel block ob, row half h) of 16 channels x 32 blocks x 36 positions through LDS
+        if (p.dbg & 16) {
+            if (acc[0][0] == 12345.f) p.y[0] = acc[1][1];
+            return;
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int ob = pass >> 1, h = pass & 1;

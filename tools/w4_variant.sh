@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build libshgan_hip_<tag>.so that differs from the product library only in conv_wino4.hip compiled with extra -D knobs
+# (A/B timing runs: SHG_VARIANT=<tag> python tools/wino4_check.py).  usage: tools/w4_variant.sh <tag> [-DKNOB=1 ...]
+set -e
+cd "$(dirname "$0")/../sh-gan_amd"
+TAG=$1; shift
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function"
+mkdir -p lib/objcache
+for f in csrc/*.hip; do
+  b=$(basename $f .hip); [ $b = conv_wino4 ] && continue
+  if [ ! -f lib/objcache/$b.o ] || [ $f -nt lib/objcache/$b.o ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o lib/objcache/$b.o & fi
+done
+wait
+/opt/rocm/bin/hipcc $FLAGS "$@" -c csrc/conv_wino4.hip -o lib/objcache/conv_wino4.$TAG.obj
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libshgan_hip_$TAG.so lib/objcache/*.o lib/objcache/conv_wino4.$TAG.obj
+echo built lib/libshgan_hip_$TAG.so
