@@ -35,9 +35,13 @@ __device__ long long shg_wino4_trace_buf[8 * 8 * 8];
 extern "C" int shg_wino4_trace_read(long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shg_wino4_trace_buf), sizeof(shg_wino4_trace_buf));
 }
-#define W4_TRACE(slot) do { if (blockIdx.x == 0 && c >= 8 && c < 16 && lane == 0) shg_wino4_trace_buf[(wave * 8 + (c - 8)) * 8 + (slot)] = clock64(); } while (0)
+#define W4_TRACE(slot) do { if (blockIdx.x == 0 && c >= SHG_W4_TRACE - 1 && c < SHG_W4_TRACE + 6 && lane == 0) shg_wino4_trace_buf[(wave * 8 + (c - (SHG_W4_TRACE - 1))) * 8 + (slot)] = clock64(); } while (0)
+#define W4_TRACE_T(slot) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[((threadIdx.x >> 6) * 8 + 7) * 8 + (slot)] = clock64(); } while (0)
+#define W4_TRACE_E(slot) do { if (SHG_W4_TRACE == 100 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[(threadIdx.x >> 6) * 64 + (slot)] = clock64(); } while (0)
 #else
 #define W4_TRACE(slot) do { } while (0)
+#define W4_TRACE_T(slot) do { } while (0)
+#define W4_TRACE_E(slot) do { } while (0)
 #endif
 
 struct Wino4Params {
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    W4_TRACE_T(0);
 
     const int nwork = p.n_ttiles * p.n_otiles;
     const int work = wino4_xcd_remap(blockIdx.x, nwork);
@@ -211,52 +216,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
     const int o_l = tid >> 5, t_l = tid & 31;
     const int by = t_l / TX, bx = t_l % TX;
     const int oy = oy0 + 4 * by, ox = ox0 + 4 * bx;
-    auto finish = [&](int pass) __attribute__((always_inline)) {
-        const int ob = pass >> 1, h = pass & 1;
-        const int o = o0 + ob * 32 + 16 * h + o_l;
-        // A^T m A: rows of m first (over the position columns), then columns
-        float tmp[6][4];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            float m[6], a4[4];
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) m[cc] = Mx[((r * 6 + cc) * 16 + o_l) * 32 + t_l];
-            wino4_at(m, a4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tmp[r][k] = a4[k];
-        }
-        if (o < p.O && oy < p.H && ox < p.W) {
-            const float osc = p.out_scale ? p.out_scale[(long)n * p.O + o] : 1.f;
-            const float bs = p.bias ? p.bias[o] : 0.f;
-            const long base = ((long)n * p.O + o) * plane;
-            float yv[4][4];                                       // output column k of the block needs tmp[.][k]
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float col[6] = {tmp[0][k], tmp[1][k], tmp[2][k], tmp[3][k], tmp[4][k], tmp[5][k]};
-                float a4[4];
-                wino4_at(col, a4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) yv[i][k] = a4[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (oy + i >= p.H) continue;
-                const long pix = (long)(oy + i) * p.W + ox;       // W % 4 == 0, ox % 4 == 0: 16-byte aligned, all four inside
-                f32x4 nz = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
-                if (p.noise_mode) nz = *reinterpret_cast<const f32x4*>(p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) + pix);
-                if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + base + pix);
-                f32x4 out;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = yv[i][k] * osc + nz[k] * p.noise_strength + bs;
-                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
-                    out[k] = v + rs[k];
-                }
-                *reinterpret_cast<f32x4*>(p.y + base + pix) = out;
-            }
-        }
-    };
-
     // ---- the two wave classes.  Transform waves (0..3) own 4 positions x 2 channel blocks = 8 accumulator tiles, fetch waves
     // (4..7) own 5 x 2 = 10: each SIMD hosts one wave of either class, so the matrix pipes are loaded evenly (18 tiles) and
     // the transform's temporaries live in the registers the two missing accumulators would take.
@@ -320,6 +279,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
 #ifdef SHG_W4_PRIO
         if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
 #endif
+#ifdef SHG_W4_PRIO
+        if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
+#endif
+        W4_TRACE_T(1);
         const int last = p.nchunk - 1;
         auto fetch = [&](const float* bb, int ks, int pb) __attribute__((always_inline)) {
 #pragma unroll
@@ -329,7 +292,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
             if (!(p.dbg & 8)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[ks][j], b[pb][j >> 1], acc[j], 0, 0, 0);
         };
         auto refill = [&](int c, int ks, int j) __attribute__((always_inline)) {
+#ifdef SHG_W4_SAMEADDR
+            if (!(p.dbg & 1)) ur[ks][j] = ubase[(SHG_W4_SAMEADDR == 2 ? (size_t)(ks * NUNIT + j) * 64 : 0)];   // (study: L1-resident weights)
+#else
             if (!(p.dbg & 1)) ur[ks][j] = ubase[(size_t)c * ustride + (ks * NUNIT + j) * 64];
+#endif
         };
         for (int c = 0; c < p.nchunk; ++c) {
             const int buf = c & 1;
@@ -398,14 +365,84 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
         for (int j = 0; j < NU; ++j) mma(3, 1, j);
 
+        W4_TRACE_T(2);
         // epilogue: four passes (channel block ob, row half h) of 16 channels x 32 blocks x 36 positions through LDS
         if (p.dbg & 16) {
             if (acc[0][0] == 12345.f) p.y[0] = acc[1][1];
             return;
         }
+        // Operands of the fused tail.  Every load is unconditional (absent operands read a block of zeros) and the loads of pass
+        // p+1 are issued BEFORE the stores of pass p: a conditional load makes the compiler wait with vmcnt(0), and on this chip
+        // vmcnt also counts stores -- the tail then waited for its own previous row to reach memory (1200 cycles per row, 5000 of a
+        // pass's 6500).  Out-of-range rows / channels are clamped for the loads and masked for the stores.
+        const ShgAct actc = shg_act_make(p.act, p.alpha, p.gain, p.clamp);
+        const bool col_ok = oy < p.H && ox < p.W;
+        const int oxc = ox < p.W ? ox : 0;
+        long rowoff[4];
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) rowoff[i] = (long)(oy + i < p.H ? oy + i : p.H - 1) * p.W + oxc;   // W % 4 == 0, ox % 4 == 0: 16-byte rows
+        f32x4 nz[4];
+        {
+            const float* np_ = p.noise_mode ? p.noise + (p.noise_mode == 2 ? (long)n * plane : 0) : shg_wino4_zeros;
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) nz[i] = *reinterpret_cast<const f32x4*>(np_ + (p.noise_mode ? rowoff[i] : 0));
+        }
+        struct TailOps { float osc, bs; f32x4 rs[4]; };
+        auto tail_load = [&](int pass, TailOps& t) __attribute__((always_inline)) {
+            const int oo = o0 + (pass >> 1) * 32 + 16 * (pass & 1) + o_l;
+            const int oc = oo < p.O ? oo : p.O - 1;
+            t.osc = p.out_scale ? p.out_scale[(long)n * p.O + oc] : 1.f;
+            t.bs = p.bias ? p.bias[oc] : 0.f;
+            const float* rp = p.residual ? p.residual + ((long)n * p.O + oc) * plane : shg_wino4_zeros;
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) t.rs[i] = *reinterpret_cast<const f32x4*>(rp + (p.residual ? rowoff[i] : 0));
+        };
+        auto finish = [&](int pass, TailOps& t) __attribute__((always_inline)) {
+            const int ob = pass >> 1, h = pass & 1;
+            const int o = o0 + ob * 32 + 16 * h + o_l;
+            W4_TRACE_E(pass * 8 + 1);
+            // A^T m A: rows of m first (over the position columns), then columns
+            float tmp[6][4];
+    #pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float m[6], a4[4];
+    #pragma unroll
+                for (int cc = 0; cc < 6; ++cc) m[cc] = Mx[((r * 6 + cc) * 16 + o_l) * 32 + t_l];
+                wino4_at(m, a4);
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) tmp[r][k] = a4[k];
+            }
+            W4_TRACE_E(pass * 8 + 2);
+            f32x4 out[4];
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {                             // output column k of the block needs tmp[.][k]
+                const float col[6] = {tmp[0][k], tmp[1][k], tmp[2][k], tmp[3][k], tmp[4][k], tmp[5][k]};
+                float a4[4];
+                wino4_at(col, a4);
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = a4[i] * t.osc + nz[i][k] * p.noise_strength + t.bs;
+                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
+                    out[i][k] = v + t.rs[i][k];
+                }
+            }
+            W4_TRACE_E(pass * 8 + 4);
+            if (pass < 3) tail_load(pass + 1, t);                     // ahead of this pass's stores
+            W4_TRACE_E(pass * 8 + 5);
+            if (o < p.O && col_ok) {
+                float* yp = p.y + ((long)n * p.O + o) * plane;
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (oy + i < p.H) *reinterpret_cast<f32x4*>(yp + rowoff[i]) = out[i];
+            }
+        };
+
+        TailOps tops;
+        tail_load(0, tops);
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int ob = pass >> 1, h = pass & 1;
+            W4_TRACE_E(pass * 8 + 0);
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
@@ -416,7 +453,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
                 }
             }
             __syncthreads();
-            finish(pass);
+            finish(pass, tops);
+            W4_TRACE_E(pass * 8 + 3);
+            W4_TRACE_T(3 + pass);
             if (pass < 3) __syncthreads();
         }
     };
