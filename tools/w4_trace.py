@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 buf = np.zeros(8 * 8 * 8, dtype=np.int64)
 assert lib.shg_wino4_trace_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 T = buf.reshape(8, 8, 8)[:, 7, :]
-t = buf.reshape(8, 8, 8)[:, :7, :7]
+t = buf.reshape(8, 8, 8)[:, :7, :int(os.environ.get('NSLOT', 7))]
 t0 = t[:, 0, 0].min()
 print('clock64 ticks relative to the first traced barrier release; columns: start | after carried group | ks0 | ks1 | ks2 done | before barrier | after barrier')
 for c in range(7):
