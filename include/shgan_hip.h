@@ -161,6 +161,12 @@ int shg_modconv_style_prep_grouped_f32(const shg_style_group* groups, int G, int
 /* ---- A16-A19: Spectral Hint Unit (shgan.py:312-336).
  * rfft2(norm='forward') + row shift of [C] planes of 64x64 per sample (x + n*x_batch_stride) -> T [N,2C,64,33]. */
 int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N, int C, void* stream);
+/* SHU spectral stage in one launch (shgan.py:320-321 conv0 + ReLU, :143-160 heterogeneous filter incl. the band sum):
+ * S[n,o,p] = sum_k cw[k,p] * sum_i W1[o*bands+k, i] * relu(sum_j W0[i,j] T[n,j,p] + b0[i]);  T, S: [N,64,P], P % 64 == 0;
+ * w0p [32][2][64] / w1p [bands*32][2][64]: weights in MFMA operand order, element [ks][mo][l] = W[mo*32 + (l & 31)][2*ks + (l >> 5)]
+ * (for w1p the rows of band k are W1[o*bands+k, :]); cw [bands,P].  Then shg_shu_split_irfft2_f32 with bands = 1. */
+int shg_shu_spectral_f32(const float* T, const float* w0p, const float* b0, const float* w1p, const float* cw, float* S,
+                         int N, int C2, int P, int bands, void* stream);
 /* band-weighted sum (bands > 1: Y [N,2C*bands,64,33], cw [bands,64,33]) -> Gaussian split -> unshift -> irfft2 at
  * r = 4,8,16,32,64: out[l] planes [C][r][r] per sample at out[l] + n*out_batch_stride[l]; accumulate=1 adds in place
  * (shgan.py:378-382).  gauss[l] = [r, r/2+1] table (shgan.py:281-310). */

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -61,6 +61,7 @@ _SIGS = {
     'shg_dense_grouped_f32': [ctypes.POINTER(DenseGroup), c_i, c_i, c_fp],
     'shg_modconv_style_prep_grouped_f32': [ctypes.POINTER(StyleGroup), c_i, c_i, c_fp],
     'shg_shu_rfft2_shift_f32': [c_fp, c_l, c_fp, c_i, c_i, c_fp],
+    'shg_shu_spectral_f32': [c_fp] * 6 + [c_i] * 4 + [c_fp],
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_assemble_input_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],

@@ -1,8 +1,9 @@
 // Spectral Hint Unit kernels (gfx950): rFFT2 + row shift, and band-weighted sum + Gaussian split +
 // row unshift + irFFT2 at five resolutions.  Reference: lib/model_zoo/shgan.py:312-336 (SHU.forward),
 // :143-160 (heterogeneous_filter), :281-310 (Gaussian-split tables); index conventions in
-// SURVEY.md appendix B.  The two 1x1 convolutions in between (64->64 +bias+ReLU, 64->384) run on the
-// MFMA implicit-GEMM kernel (conv_mfma.hip) as single-tap convolutions.
+// SURVEY.md appendix B.  The two 1x1 convolutions in between (64->64 +bias+ReLU, 64->384) and the band sum of
+// the heterogeneous filter are one kernel (shu_spectral_kernel) that never writes the [N,384,64,33] tensor;
+// other geometries run them on the MFMA implicit-GEMM kernel (conv_mfma.hip) as single-tap convolutions.
 //
 // The transform is always 64x64 (shu_input_res = 64), so a plane fits in LDS many times over: one
 // workgroup owns one (sample, channel) plane, keeps the whole spectrum in LDS and never goes back to
@@ -109,6 +110,84 @@ extern "C" int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, floa
     SHG_CHECK_ARG(x && T, "shu_rfft2: null pointer");
     SHG_CHECK_ARG(N >= 1 && N <= 65535 && C >= 1, "shu_rfft2: bad shape");
     hipLaunchKernelGGL(shu_rfft2_shift_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride, T, C);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---- fused spectral stage: S[n,o,p] = sum_k cw[k,p] * sum_i W1[o*B+k, i] * relu(sum_j W0[i,j] T[n,j,p] + b0[i])
+// (SHU conv0 + ReLU `shgan.py:320-321`, heterogeneous_filter `shgan.py:143-160`: 1x1 conv to O*B channels, view [O,B], weighted sum
+// over the B bands with the position-dependent table cw).  cw depends on the position only, so it moves into the B operand:
+//   S[o,p] = sum_{(k,i)} W1[o*B+k, i] * (cw[k,p] * t[i,p])          -- ONE GEMM with K = B*64 instead of B GEMMs and a reduction.
+// Workgroup = one sample x 64 consecutive spectral positions (64*33 = 33 such tiles), 4 waves = the 2 x 2 tiles of 32 x 32 of both
+// products on v_mfma_f32_32x32x2_f32; T tile and t in LDS (32 KB), weights pre-packed per k-step in MFMA A-operand order
+// (w0p [32][2][64], w1p [B*32][2][64]: lane l of row block mo holds W[mo*32 + (l & 31)][2*ks + (l >> 5)]).
+struct ShuSpectralParams {
+    const float* T; const float* w0p; const float* b0; const float* w1p; const float* cw; float* S;
+    int P, B;       // positions per plane (64*33), bands
+};
+
+__global__ __launch_bounds__(256) void shu_spectral_kernel(const ShuSpectralParams p) {
+    __shared__ __attribute__((aligned(16))) float Tl[64][64];       // [channel][position]
+    __shared__ __attribute__((aligned(16))) float tl[64][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int mo = wave >> 1, nt = wave & 1;
+    const int n = blockIdx.y, p0 = blockIdx.x * 64;
+    const float* Tn = p.T + (long)n * 64 * p.P + p0;
+    // T tile: 64 channels x 64 positions, rows of 256 bytes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * 256 + tid, ch = e >> 4, c4 = e & 15;
+        *reinterpret_cast<float4*>(&Tl[ch][4 * c4]) = *reinterpret_cast<const float4*>(Tn + (long)ch * p.P + 4 * c4);
+    }
+    float cwv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cwv[k] = k < p.B ? p.cw[(long)k * p.P + p0 + nt * 32 + l31] : 0.f;
+    __syncthreads();
+    shu_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {   // t = relu(W0 T + b0)
+        const float* ap = p.w0p + mo * 64 + lane;
+#pragma unroll 8
+        for (int ks = 0; ks < 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 128], Tl[2 * ks + half][nt * 32 + l31], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            tl[row][nt * 32 + l31] = fmaxf(acc[r] + p.b0[row], 0.f);
+            acc[r] = 0.f;
+        }
+    }
+    __syncthreads();
+    {   // S = [W1_0 | W1_1 | ...] (cw (.) t)
+        const float* ap = p.w1p + mo * 64 + lane;
+        for (int k = 0; k < p.B; ++k) {
+            const float cwk = cwv[0];
+#pragma unroll 8
+            for (int ks = 0; ks < 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(k * 32 + ks) * 128], cwk * tl[2 * ks + half][nt * 32 + l31], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) cwv[q] = cwv[q + 1];     // (rotate: keeps the band index static)
+        }
+    }
+    float* Sn = p.S + (long)n * 64 * p.P + p0 + nt * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Sn[(long)row * p.P] = acc[r];
+    }
+}
+
+// T [N,64,P] (P = 64*33 positions, a multiple of 64), w0p / w1p: MFMA-ordered weights (see above), b0 [64], cw [B,P], B <= 8
+// -> S [N,64,P].  The shipped SHU geometry only (2C = 64 spectral channels); other shapes: shg_conv2d_f32 twice.
+extern "C" int shg_shu_spectral_f32(const float* T, const float* w0p, const float* b0, const float* w1p, const float* cw, float* S,
+                                    int N, int C2, int P, int bands, void* stream) {
+    SHG_CHECK_ARG(T && w0p && b0 && w1p && cw && S, "shu_spectral: null pointer");
+    SHG_CHECK_ARG(C2 == 64 && P % 64 == 0 && bands >= 1 && bands <= 8 && N >= 1 && N <= 65535,
+                  "shu_spectral: built for 64 spectral channels, P %% 64 == 0, at most 8 bands");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(S)) & 15) == 0, "shu_spectral: T / S must be 16-byte aligned");
+    ShuSpectralParams p{T, w0p, b0, w1p, cw, S, P, bands};
+    hipLaunchKernelGGL(shu_spectral_kernel, dim3(P / 64, N), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

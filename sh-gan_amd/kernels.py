@@ -675,6 +675,30 @@ def shu_rfft2_shift(x):
     return t
 
 
+def mfma_pack_rows(w):
+    """w [..., 64, 64] (rows = output channels) -> [..., 32, 2, 64]: the A operands of v_mfma_f32_32x32x2_f32 per k-step,
+    element [ks][mo][l] = w[mo*32 + (l & 31)][2*ks + (l >> 5)] (layout of shg_shu_spectral_f32)."""
+    l = torch.arange(64, device=w.device)
+    rows = torch.arange(2, device=w.device)[:, None] * 32 + (l & 31)[None, :]            # [2, 64]
+    cols = 2 * torch.arange(32, device=w.device)[:, None] + (l >> 5)[None, :]             # [32, 64]
+    return w[..., rows[None, :, :], cols[:, None, :]].contiguous()
+
+
+def shu_spectral(t, w0p, b0, w1p, cw):
+    """t [N,64,64,33] -> S [N,64,64,33]: conv0 + ReLU + heterogeneous filter + band sum in one launch (shg_shu_spectral_f32)."""
+    L = _Launch()
+    t, w0p, b0, w1p, cw = L.req(t, 't'), L.req(w0p, 'w0p'), L.req(b0, 'b0'), L.req(w1p, 'w1p'), L.req(cw, 'cw')
+    n, c2, h, w = t.shape
+    bands = cw.shape[0]
+    if tuple(w0p.shape) != (32, 2, 64) or tuple(w1p.shape) != (bands * 32, 2, 64) or cw.numel() != bands * h * w:
+        raise _lib.ShgError('shu_spectral: packed weight / cw shapes do not match')
+    out = L.new((n, c2, h, w))
+    with _timed(L, 'shu', 4.0 * (t.numel() + out.numel())):
+        check(_lib.get_lib().shg_shu_spectral_f32(_ptr(t), _ptr(w0p), _ptr(b0), _ptr(w1p), _ptr(cw), _ptr(out), n, c2, h * w, bands,
+                                                  L.stream()), 'shu_spectral')
+    return out
+
+
 def shu_split_irfft2(y, cw, gauss, outs, accumulate):
     """y: [N, 2C*B, 64, 33]; cw: [B,64,33] or None; gauss: list of 5 tables (r=4..64);
     outs: list of 5 tensors/views [N,C,r,r] with contiguous channel planes (or None to skip)."""

@@ -205,24 +205,41 @@ class SHU(nn.Module):
         self.register_buffer('_cw', make_cweight(dfilter_freedom, (input_res, input_res // 2 + 1), dfilter_type),
                              persistent=False)
 
+    FUSED_SPECTRAL = True      # conv0 + ReLU + heterogeneous filter + band sum in one launch (False: two 1x1 convolutions)
+
+    def _packed(self):
+        """MFMA-ordered copies of the conv0 / heterogeneous-filter weights (per parameter version)."""
+        def build():
+            w0 = self.conv0.weight.detach()[:, :, 0, 0] * self.conv0.weight_gain                    # [out, in]
+            i, ob = self.df1.weight.shape
+            w1 = self.df1.weight.detach().t().reshape(ob // self._cw.shape[0], self._cw.shape[0], i).permute(1, 0, 2)   # [B][o][i]
+            b0 = self.conv0.bias.detach() * self.conv0.bias_gain if self.conv0.bias is not None else \
+                torch.zeros(w0.shape[0], device=w0.device)
+            return kernels.mfma_pack_rows(w0), b0.contiguous(), kernels.mfma_pack_rows(w1).reshape(-1, 2, 64)
+        return _cache_of(self).get('spec', [q for q in (self.conv0.weight, self.conv0.bias, self.df1.weight) if q is not None], build)
+
     def _spectral(self, x):
+        """-> (y, cw): y [N,2C*B,64,33] with its band table, or the band-summed [N,2C,64,33] and None."""
         t = kernels.shu_rfft2_shift(x)                 # [N,2C,64,33]: Re | Im, DC on row 31
+        if self.FUSED_SPECTRAL and t.shape[1] == 64 and self._cw.shape[0] <= 8:
+            w0p, b0, w1p = self._packed()
+            return kernels.shu_spectral(t, w0p, b0, w1p, self._cw), None
         t = self.conv0(t, relu=True)                   # 1x1 conv + bias + ReLU on the MFMA kernel
-        return self.df1.band_conv(t)                   # [N,2C*6,64,33]
+        return self.df1.band_conv(t), self._cw         # [N,2C*6,64,33]
 
     def forward(self, x):
-        y = self._spectral(x)
+        y, cw = self._spectral(x)
         n, c = x.shape[0], self.out_channels
         outs = [torch.empty((n, c, r, r), device=x.device, dtype=torch.float32) for r in self.reslist]
-        kernels.shu_split_irfft2(y, self._cw, [getattr(self, f'_gauss{r}') for r in self.reslist], outs, accumulate=False)
+        kernels.shu_split_irfft2(y, cw, [getattr(self, f'_gauss{r}') for r in self.reslist], outs, accumulate=False)
         return dict(zip(self.reslist, outs))
 
     def forward_accumulate(self, x, feats):
         """Fused form used by the encoder: feats[r][:, -C:] += hint_r, in place."""
-        y = self._spectral(x)
+        y, cw = self._spectral(x)
         c = self.out_channels
         outs = [feats[r][:, feats[r].shape[1] - c:] for r in self.reslist]
-        kernels.shu_split_irfft2(y, self._cw, [getattr(self, f'_gauss{r}') for r in self.reslist], outs, accumulate=True)
+        kernels.shu_split_irfft2(y, cw, [getattr(self, f'_gauss{r}') for r in self.reslist], outs, accumulate=True)
         return feats
 
 

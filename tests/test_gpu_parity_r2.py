@@ -370,3 +370,34 @@ def test_upfirdn2d_backward_is_the_swapped_operator(mods, up, down, pad, fshape,
     dx = ufd.upfirdn2d_backward(dy.to(DEV), f.to(DEV), tuple(shape), up=up, down=down, padding=pad, gain=1.7)
     assert tuple(dx.shape) == tuple(shape)
     assert rel_err(c(dx), ref.numpy()) < 1e-5
+
+
+def test_shu_fused_spectral_kernel_vs_two_convolutions(mods):
+    """SHU spectral stage (shgan.py:320-321 conv0 + ReLU, :143-160 heterogeneous filter + band sum): the one-launch kernel
+    (shg_shu_spectral_f32 -> split with one band) against the route through two 1x1 convolutions and the six-band split, and
+    against the oracle; random conv0 bias so the ReLU clips differently per channel."""
+    shgan, orc = mods['shgan'], mods['orc']
+    torch.manual_seed(5)
+    shu = shgan.SHU(32, 32, [2, 3], 'piecewise_linear', input_res=64, lowest_res=4, tail_sigma_mult=3).to(DEV).eval()
+    with torch.no_grad():
+        shu.conv0.bias.normal_(0, 0.02)
+        shu.df1.weight.normal_(1 / 64, 0.5 / 64)
+    x = torch.randn(3, 32, 64, 64, device=DEV)
+    old = shgan.SHU.FUSED_SPECTRAL
+    try:
+        shgan.SHU.FUSED_SPECTRAL = True
+        a = shu(x)
+        shgan.SHU.FUSED_SPECTRAL = False
+        b = shu(x)
+    finally:
+        shgan.SHU.FUSED_SPECTRAL = old
+    ref = orc.shu_forward({'encoder.shu.' + k: v.detach().cpu() for k, v in shu.state_dict().items()}, x.cpu())
+    for r in (4, 8, 16, 32, 64):
+        assert not torch.equal(a[r], b[r])
+        assert rel_err(c(a[r]), c(b[r])) < 2e-5, r
+        assert rel_err(c(a[r]), ref[r].numpy()) < 1e-4, r
+    # a changed parameter must invalidate the packed weights
+    with torch.no_grad():
+        shu.conv0.weight.mul_(0.5)
+    a2 = shu(x)
+    assert rel_err(c(a2[64]), c(a[64])) > 1e-3

@@ -34,3 +34,19 @@ try:
     print(f'shu_split_irfft2     {us:7.1f} us  {by/1e6:6.1f} MB  {by/us/1e6:6.3f} TB/s')
 except Exception as e:
     print('split bench skipped:', repr(e)[:200])
+
+# whole SHU forward (rfft2 -> spectral stage -> split + irfft2), fused spectral kernel vs two 1x1 convolutions
+from shgan_amd.model_zoo import shgan
+shu = shgan.SHU(32, 32, [2, 3], 'piecewise_linear', input_res=64, lowest_res=4, tail_sigma_mult=3).cuda().eval()
+for fused in (True, False):
+    shgan.SHU.FUSED_SPECTRAL = fused
+    us = timeit(lambda: shu(x))
+    print(f'SHU.forward N={N} fused_spectral={fused}: {us:7.1f} us (incl. host launch overhead of {3 if fused else 4} launches + 5 output allocations)')
+shgan.SHU.FUSED_SPECTRAL = True
+t = kk.shu_rfft2_shift(x)
+w0p, b0, w1p = shu._packed()
+us = timeit(lambda: kk.shu_spectral(t, w0p, b0, w1p, shu._cw))
+print(f'shu_spectral         {us:7.1f} us  ({2 * N * 2112 * (64 * 64 + 6 * 64 * 64) / us / 1e6:6.1f} TFLOP/s)')
+s1 = kk.shu_spectral(t, w0p, b0, w1p, shu._cw)
+us = timeit(lambda: kk.shu_split_irfft2(s1, None, gauss, outs, False))
+print(f'shu_split_irfft2 B=1 {us:7.1f} us')
