@@ -161,6 +161,13 @@ int shg_modconv_style_prep_grouped_f32(const shg_style_group* groups, int G, int
 /* ---- A16-A19: Spectral Hint Unit (shgan.py:312-336).
  * rfft2(norm='forward') + row shift of [C] planes of 64x64 per sample (x + n*x_batch_stride) -> T [N,2C,64,33]. */
 int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N, int C, void* stream);
+/* Weight gradient of y = conv2d(x, w, stride, pad) (conv2d_gradfix.py:140-146, the cuDNN backward-weight call):
+ * dw[o,i,ky,kx] = sum_{n,oy,ox} g[n,o,oy,ox] * x[n,i,oy*stride-pad+ky, ox*stride-pad+kx]; 3x3 or 1x1, stride 1 or 2; deterministic
+ * (K slices summed in order).  For conv_transpose2d pass dL/dy as `x` and the layer input as `g`: dw comes out as [Cin,Cout,kh,kw].
+ * Input gradients are compositions of the forward entry points (conv <-> transposed conv, conv2d_gradfix.py:118-135). */
+size_t shg_conv2d_wgrad_workspace_bytes(int NB, int I, int O, int OH, int OW, int kh, int kw);
+int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, int NB, int I, int O, int H, int W, int OH, int OW,
+                         int kh, int kw, int stride, int pad, void* workspace, size_t ws_bytes, void* stream);
 /* SHU spectral stage in one launch (shgan.py:320-321 conv0 + ReLU, :143-160 heterogeneous filter incl. the band sum):
  * S[n,o,p] = sum_k cw[k,p] * sum_i W1[o*bands+k, i] * relu(sum_j W0[i,j] T[n,j,p] + b0[i]);  T, S: [N,64,P], P % 64 == 0;
  * w0p [32][2][64] / w1p [bands*32][2][64]: weights in MFMA operand order, element [ks][mo][l] = W[mo*32 + (l & 31)][2*ks + (l >> 5)]

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -61,6 +61,8 @@ _SIGS = {
     'shg_dense_grouped_f32': [ctypes.POINTER(DenseGroup), c_i, c_i, c_fp],
     'shg_modconv_style_prep_grouped_f32': [ctypes.POINTER(StyleGroup), c_i, c_i, c_fp],
     'shg_shu_rfft2_shift_f32': [c_fp, c_l, c_fp, c_i, c_i, c_fp],
+    'shg_conv2d_wgrad_workspace_bytes': [c_i] * 7,
+    'shg_conv2d_wgrad_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_shu_spectral_f32': [c_fp] * 6 + [c_i] * 4 + [c_fp],
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
@@ -107,6 +109,7 @@ def get_lib():
     lib.shg_last_error.argtypes = []
     lib.shg_last_error.restype = ctypes.c_char_p
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv_wino4_weight_elems.restype = c_l
     ver = lib.shg_abi_version()
     if ver != ABI_VERSION:

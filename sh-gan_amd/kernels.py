@@ -675,6 +675,25 @@ def shu_rfft2_shift(x):
     return t
 
 
+def conv2d_wgrad(x, g, kh, kw, stride=1, pad=0):
+    """Weight gradient of y = conv2d(x, w, stride, pad): x [NB,I,H,W], g = dL/dy [NB,O,OH,OW] -> dw [O,I,kh,kw]
+    (shg_conv2d_wgrad_f32; for conv_transpose2d call it with (dL/dy, x) and read the result as [Cin,Cout,kh,kw])."""
+    L = _Launch()
+    x, g = L.req(x, 'x'), L.req(g, 'g')
+    nb, i, h, w = x.shape
+    nb2, o, oh, ow = g.shape
+    if nb != nb2:
+        raise _lib.ShgError('conv2d_wgrad: batch sizes differ')
+    lib = _lib.get_lib()
+    dw = L.new((o, i, kh, kw))
+    ws_bytes = int(lib.shg_conv2d_wgrad_workspace_bytes(nb, i, o, oh, ow, kh, kw))
+    ws = L.new((ws_bytes // 4,)) if ws_bytes else None
+    with _timed(L, 'conv_wgrad', 2.0 * nb * o * i * kh * kw * oh * ow):
+        check(lib.shg_conv2d_wgrad_f32(_ptr(x), _ptr(g), _ptr(dw), nb, i, o, h, w, oh, ow, kh, kw, int(stride), int(pad), _ptr(ws), ws_bytes,
+                                       L.stream()), 'conv2d_wgrad')
+    return dw
+
+
 def mfma_pack_rows(w):
     """w [..., 64, 64] (rows = output channels) -> [..., 32, 2, 64]: the A operands of v_mfma_f32_32x32x2_f32 per k-step,
     element [ks][mo][l] = w[mo*32 + (l & 31)][2*ks + (l >> 5)] (layout of shg_shu_spectral_f32)."""

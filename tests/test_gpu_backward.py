@@ -1,0 +1,87 @@
+"""N3 (training step) building blocks on the GPU: convolution backward -- input gradient through the opposite operator, weight
+gradient on shg_conv2d_wgrad_f32 -- against torch CPU autograd in float64 (conv2d_gradfix.py:107-165 is the reference's form;
+its cuDNN weight-gradient call has no CPU path, so torch's own autograd of F.conv2d / F.conv_transpose2d is the oracle)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def gf():
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    return dict(gf=conv2d_gradfix, kernels=kernels)
+
+
+def c(a):
+    return a.detach().cpu().numpy()
+
+
+CONV_CASES = [
+    # n, ci, co, h, w, k, stride, pad: ragged channels (I, O % 32), rows shorter / longer than the 64-pixel chunk, both strides
+    (2, 8, 16, 16, 16, 3, 1, 1), (3, 37, 70, 20, 24, 3, 1, 1), (1, 64, 64, 64, 96, 3, 1, 1), (2, 24, 40, 12, 12, 3, 1, 0),
+    (2, 16, 32, 33, 33, 3, 2, 0), (1, 40, 24, 65, 129, 3, 2, 0), (2, 12, 20, 16, 16, 3, 2, 1),
+    (2, 20, 36, 16, 16, 1, 1, 0), (1, 4, 64, 32, 32, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,k,stride,pad', CONV_CASES)
+def test_conv2d_backward_vs_torch_autograd(gf, n, ci, co, h, w, k, stride, pad):
+    rs = np.random.RandomState(n + ci + co + h + k + stride)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(gy.double())
+    xd, wd, bd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = gf['gf'].conv2d(xd, wd, bd, stride=stride, padding=pad)
+    assert rel_err(c(y), c(yr)) < 2e-5
+    y.backward(gy.to(DEV))
+    assert rel_err(c(xd.grad), c(xr.grad)) < 2e-5
+    assert rel_err(c(wd.grad), c(wr.grad)) < 2e-5
+    assert rel_err(c(bd.grad), c(br.grad)) < 2e-5
+    # deterministic: the K slices are summed in a fixed order
+    assert torch.equal(gf['kernels'].conv2d_wgrad(x.to(DEV), gy.to(DEV), k, k, stride, pad), wd.grad)
+    # no_weight_gradients() (conv2d_gradfix.py:25-31)
+    xd2, wd2 = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    with gf['gf'].no_weight_gradients():
+        gf['gf'].conv2d(xd2, wd2, None, stride=stride, padding=pad).backward(gy.to(DEV))
+    assert wd2.grad is None and torch.equal(xd2.grad, xd.grad)
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,pad', [(2, 16, 8, 8, 8, 0), (1, 37, 70, 16, 20, 0), (2, 64, 32, 32, 32, 1), (1, 24, 24, 33, 65, 1)])
+def test_conv_transpose2d_backward_vs_torch_autograd(gf, n, ci, co, h, w, pad):
+    rs = np.random.RandomState(n + ci + co + h + pad)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((ci, co, 3, 3)) / np.sqrt(ci * 9)).astype(np.float32))
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    yr = F.conv_transpose2d(xr, wr, stride=2, padding=pad)
+    gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(gy.double())
+    xd, wd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    y = gf['gf'].conv_transpose2d(xd, wd, stride=2, padding=pad)
+    assert rel_err(c(y), c(yr)) < 2e-5
+    y.backward(gy.to(DEV))
+    assert rel_err(c(xd.grad), c(xr.grad)) < 2e-5
+    assert rel_err(c(wd.grad), c(wr.grad)) < 2e-5
+
+
+def test_wgrad_rejects_bad_geometry(gf):
+    from shgan_amd import _lib
+    kk = gf['kernels']
+    x, g = torch.zeros(1, 4, 8, 8, device=DEV), torch.zeros(1, 4, 8, 8, device=DEV)
+    with pytest.raises(_lib.ShgError):
+        kk.conv2d_wgrad(x, g, 3, 3, 1, 0)          # an 8x8 output needs padding 1
+    with pytest.raises(_lib.ShgError):
+        kk.conv2d_wgrad(x, g, 5, 5, 1, 2)
+    with pytest.raises(_lib.ShgError):
+        kk.conv2d_wgrad(x.cpu(), g, 3, 3, 1, 1)
