@@ -49,6 +49,10 @@ int shg_upfirdn2d_epilogue_f32(const float* x, const float* f, float* y, int N, 
 int shg_bias_act_f32(const float* x, float* y, const float* scale, const float* bias, const float* noise, int noise_mode,
                      float noise_strength, const float* residual, int N, int C, int HW, int act, float alpha, float gain,
                      float clamp, void* stream);
+/* Backward of shg_bias_act_f32 without scale / noise / residual (the training path's bias + lrelu_agc): dx = g * slope(y), with
+ * the forward OUTPUT y.  The bias gradient is the per-channel sum of dx. */
+int shg_bias_act_backward_f32(const float* g, const float* y, float* dx, long total, int act, float alpha, float gain, float clamp,
+                              void* stream);
 /* stylegan_utils/fma.py:15 -- y = a*b + c, elementwise on `total` floats. */
 int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long total, void* stream);
 /* stylegan.py:173 -- y[nc,:] = x[nc,:] * s[nc]. */

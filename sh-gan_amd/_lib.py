@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -61,6 +61,7 @@ _SIGS = {
     'shg_dense_grouped_f32': [ctypes.POINTER(DenseGroup), c_i, c_i, c_fp],
     'shg_modconv_style_prep_grouped_f32': [ctypes.POINTER(StyleGroup), c_i, c_i, c_fp],
     'shg_shu_rfft2_shift_f32': [c_fp, c_l, c_fp, c_i, c_i, c_fp],
+    'shg_bias_act_backward_f32': [c_fp, c_fp, c_fp, c_l, c_i, c_f, c_f, c_f, c_fp],
     'shg_conv2d_wgrad_workspace_bytes': [c_i] * 7,
     'shg_conv2d_wgrad_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_shu_spectral_f32': [c_fp] * 6 + [c_i] * 4 + [c_fp],

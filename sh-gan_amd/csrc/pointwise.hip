@@ -48,6 +48,33 @@ extern "C" int shg_bias_act_f32(const float* x, float* y, const float* scale, co
     return SHG_OK;
 }
 
+// Backward of y = lrelu_agc(x + bias) (common/utils.py:135-143 under autograd: leaky_relu -> *gain -> clamp): with the
+// OUTPUT y at hand, dx = g * (|y| < clamp ? (y > 0 ? gain : alpha*gain) : 0) -- gain, alpha > 0 keep the sign, and a clamped
+// value has zero slope.  The bias gradient is the per-channel sum of dx (a reduction left to the caller).
+__global__ __launch_bounds__(256) void bias_act_backward_kernel(const float* g, const float* y, float* dx, long total, int act,
+                                                                 float alpha, float gain, float clamp) {
+    const long stride = (long)gridDim.x * 256;
+    const float gp = gain, gn = act ? alpha * gain : gain;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const float v = y[e];
+        const float slope = (act && clamp >= 0.f && fabsf(v) >= clamp) ? 0.f : (v > 0.f ? gp : gn);
+        dx[e] = g[e] * slope;
+    }
+}
+
+// dx = dL/dx of y = act(x + bias) given g = dL/dy and the forward OUTPUT y (same act / alpha / gain / clamp as the forward call)
+extern "C" int shg_bias_act_backward_f32(const float* g, const float* y, float* dx, long total, int act, float alpha, float gain,
+                                         float clamp, void* stream) {
+    SHG_CHECK_ARG(g && y && dx, "bias_act_backward: null pointer");
+    SHG_CHECK_ARG(total >= 0, "bias_act_backward: bad size");
+    if (total == 0) return SHG_OK;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(bias_act_backward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, y, dx, total, act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // c = a*b + c' with NCHW broadcasting of b:[N,C,1,1] and c':[N,1,H,W] or [H,W]  (stylegan.py:176)
 // handled by bias_act (scale = b, noise = c').  Plain elementwise fma for the generic op:

@@ -229,6 +229,19 @@ def bias_act(x, bias=None, scale=None, noise=None, noise_strength=1.0, residual=
     return y
 
 
+def bias_act_backward(g, y, act=True, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0):
+    """dL/dx of y = bias_act(x, bias, act, gain, alpha, act_gain, clamp) from g = dL/dy and the forward output y."""
+    L = _Launch()
+    g, y = L.req(g, 'g'), L.req(y, 'y')
+    if g.shape != y.shape:
+        raise _lib.ShgError('bias_act_backward: g and y differ in shape')
+    a, al, gn, cl = _act_args(act, gain, alpha, act_gain, clamp)
+    dx = torch.empty_like(g)
+    with L:
+        check(_lib.get_lib().shg_bias_act_backward_f32(_ptr(g), _ptr(y), _ptr(dx), g.numel(), a, al, gn, cl, L.stream()), 'bias_act_backward')
+    return dx
+
+
 def fma(a, b, c):
     L = _Launch()
     a, b, c = torch.broadcast_tensors(L.req(a, 'a'), L.req(b, 'b'), L.req(c, 'c'))

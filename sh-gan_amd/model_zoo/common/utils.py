@@ -5,6 +5,7 @@ plain callable ``act(x, gain=1)``; on a HIP tensor it runs the fused bias_act ke
 import functools
 import math
 
+import torch
 import torch.nn as nn
 
 from ... import kernels
@@ -107,6 +108,9 @@ class lrelu_agc(object):
         self.repr = 'lrelu_agc(alpha={}, gain={}, clamp={})'.format(alpha, gain, clamp)
 
     def __call__(self, x, gain=1):
+        if torch.is_grad_enabled() and x.requires_grad:
+            from ..stylegan_utils import grad_ops
+            return grad_ops.bias_act(x, None, act=True, gain=gain, alpha=self.alpha, act_gain=self.gain, clamp=self.clamp)
         shape = x.shape
         x4 = x.reshape(shape[0], -1, 1, 1) if x.ndim != 4 else x
         y = kernels.bias_act(x4, act=True, gain=gain, alpha=self.alpha, act_gain=self.gain, clamp=self.clamp)

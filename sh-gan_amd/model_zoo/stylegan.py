@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import kernels
 from .common import utils
 from .common.get_model import get_model, register
-from .stylegan_utils import conv2d_resample, fma, misc, upfirdn2d  # noqa: F401
+from .stylegan_utils import grad_ops, conv2d_resample, fma, misc, upfirdn2d  # noqa: F401
 
 version = '0'
 symbol = 'stylegan'
@@ -43,6 +43,13 @@ def _act_kwargs(act_obj, gain=1.0):
     if isinstance(act_obj, utils.lrelu_agc):
         return dict(act=True, gain=gain, alpha=act_obj.alpha, act_gain=act_obj.gain, clamp=act_obj.clamp)
     return None
+
+
+def _add(a, b):
+    """a + b: one fused kernel on the inference path, a differentiable tensor op on the training path."""
+    if grad_ops.wants_grad(a, b):
+        return a + b
+    return kernels.bias_act(a, residual=b, act=False)
 
 
 class _ParamCache:
@@ -119,6 +126,14 @@ class dense(nn.Module):
         self.repr = 'dense({}, {}, bias={}, act={}, lr_multi={})'.format(in_features, out_features, bias, activation, lr_multi)
 
     def forward(self, x, out=None):
+        if grad_ops.wants_grad(x, self.weight, self.bias):
+            # training rows: a plain library GEMM (torch.addmm -> rocBLAS, as stylegan.py:87-98) + the autograd bias/activation op
+            y = x.matmul((self.weight * self.weight_gain).t())
+            ak = _act_kwargs(self.activation)
+            b = None if self.bias is None else self.bias * self.bias_gain
+            if ak is None:
+                return self.activation(y if b is None else y + b)
+            return grad_ops.bias_act(y, b, **ak)
         ak = _act_kwargs(self.activation)
         b = self.bias.detach() if self.bias is not None else None
         if ak is None:   # non-fusable activation object
@@ -204,7 +219,20 @@ class conv2d_layer(nn.Module):
         return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
             self.weight.detach(), gain=self.weight_gain))
 
+    def _forward_train(self, x, gain=1):
+        """Differentiable composition (training rows): convolution / FIR / bias + activation through their autograd forms."""
+        ak = _act_kwargs(self.activation, gain)
+        y = conv2d_resample.conv2d_resample(x=x, w=self.weight * self.weight_gain, f=self.resample_filter, up=self.up,
+                                            down=self.down, padding=self.padding, flip_weight=(self.up == 1))
+        if ak is None:
+            if self.bias is not None:
+                y = y + self.bias.view(1, -1, 1, 1)
+            return self.activation(y, gain=gain)
+        return grad_ops.bias_act(y, self.bias, **ak)
+
     def forward(self, x, gain=1):
+        if grad_ops.wants_grad(x, self.weight, self.bias):
+            return self._forward_train(x, gain)
         ak = _act_kwargs(self.activation, gain)
         b = self.bias.detach() if self.bias is not None else None
         k = self.weight.shape[2]
@@ -501,12 +529,12 @@ class discrim_block(nn.Module):
     def forward(self, x, img):
         if self.fromrgb is not None:
             y = self.fromrgb(img.to(torch.float32))
-            x = kernels.bias_act(x, residual=y, act=False) if x is not None else y
+            x = _add(x, y) if x is not None else y
         img = None
         if self.reslink:
             y = self.skip(x, gain=np.sqrt(0.5))
             x = self.conv1(self.conv0(x), gain=np.sqrt(0.5))
-            x = kernels.bias_act(x, residual=y, act=False)
+            x = _add(x, y)
         else:
             x = self.conv1(self.conv0(x))
         return x, img
@@ -521,6 +549,15 @@ class minibatch_std_layer(nn.Module):
         self.num_channels = num_channels
 
     def forward(self, x):
+        if grad_ops.wants_grad(x):
+            # training rows: the statistic is a handful of reductions over a 4x4 map -- composed from differentiable tensor ops
+            n, c, h, w = x.shape
+            g = n if self.group_size is None else min(int(self.group_size), n)
+            f = self.num_channels
+            y = x.reshape(g, -1, f, c // f, h, w)
+            y = (y - y.mean(dim=0)).square().mean(dim=0)
+            y = (y + 1e-8).sqrt().mean(dim=[2, 3, 4]).reshape(-1, f, 1, 1).repeat(g, 1, h, w)
+            return torch.cat([x, y], dim=1)
         return kernels.minibatch_std(x, self.group_size, self.num_channels)
 
 
@@ -542,7 +579,7 @@ class discrim_epilogue(nn.Module):
 
     def forward(self, x, img=None, cmap=None):
         if self.fromrgb is not None:
-            x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+            x = _add(x, self.fromrgb(img.to(torch.float32)))
         if self.mbstd is not None:
             x = self.mbstd(x)
         x = self.conv(x)

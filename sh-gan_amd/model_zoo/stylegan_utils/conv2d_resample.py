@@ -3,7 +3,7 @@ padding arithmetic as lib/model_zoo/stylegan_utils/conv2d_resample.py:57-154."""
 import torch
 
 from ... import kernels
-from . import upfirdn2d
+from . import conv2d_gradfix, upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
@@ -21,6 +21,15 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
         if padding[0] != padding[1]:
             raise NotImplementedError('asymmetric conv padding')
         padding = padding[0]
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        # training path (conv2d_resample.py:26-51 verbatim in structure): flip for a true convolution, the transposed form takes
+        # the weight as [Cin, Cout, kh, kw]
+        if groups != 1:
+            raise NotImplementedError('grouped convolutions are forward only')
+        wg = w if flip_weight else w.flip([2, 3])
+        if transpose:
+            return conv2d_gradfix.conv_transpose2d(x, wg.transpose(0, 1), stride=stride, padding=padding)
+        return conv2d_gradfix.conv2d(x, wg, stride=stride, padding=padding)
     xs = x.reshape(n * groups, c // groups, h, wd)
     if transpose:
         if stride != 2:

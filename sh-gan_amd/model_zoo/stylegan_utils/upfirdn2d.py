@@ -3,7 +3,8 @@ lib/model_zoo/stylegan_utils/upfirdn2d.py (``setup_filter`` :66, ``upfirdn2d`` :
 ``filter2d`` :245, ``upsample2d`` :279, ``downsample2d`` :316).
 
 Differences by design: the native library is prebuilt and mandatory (no `_upfirdn2d_ref`
-fallback, upfirdn2d.py:237-239); forward only (inference path)."""
+fallback, upfirdn2d.py:237-239).  Differentiable in ``x`` (first order): the backward is the same operator with up and
+down exchanged (upfirdn2d.py:174-192)."""
 import numpy as np
 import torch
 
@@ -97,12 +98,34 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     if not (isinstance(f, torch.Tensor) and f.ndim in (1, 2) and f.dtype == torch.float32):
         raise AssertionError('f must be a float32 tensor of rank 1 or 2')
     f = f.to(x.device)
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _UpfirdnFn.apply(x, f, (upx, upy), (downx, downy), (px0, px1, py0, py1), bool(flip_filter), float(gain))
     if f.ndim == 2:
         return _plugin.upfirdn2d(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain)
     # separable: one horizontal and one vertical pass, sqrt(gain) each (upfirdn2d.py:164-168)
     g = float(np.sqrt(gain))
     y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
     return _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
+
+
+class _UpfirdnFn(torch.autograd.Function):
+    """upfirdn2d under autograd (the reference's Upfirdn2dCuda, upfirdn2d.py:141-192)."""
+
+    @staticmethod
+    def forward(ctx, x, f, up, down, padding, flip_filter, gain):
+        ctx.save_for_backward(f)
+        ctx.cfg = (tuple(x.shape), up, down, padding, flip_filter, gain)
+        with torch.no_grad():
+            return upfirdn2d(x.detach(), f, up=list(up), down=list(down), padding=list(padding), flip_filter=flip_filter, gain=gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        x_shape, up, down, padding, flip_filter, gain = ctx.cfg
+        with torch.no_grad():
+            dx = upfirdn2d_backward(dy.contiguous(), f, x_shape, up=list(up), down=list(down), padding=list(padding),
+                                    flip_filter=flip_filter, gain=gain)
+        return dx, None, None, None, None, None, None
 
 
 def upfirdn2d_backward(dy, f, x_shape, up=1, down=1, padding=0, flip_filter=False, gain=1):

@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _inference_by_default():
+    """Tests run like the reference's evaluation code (shgan_default.py: `torch.no_grad()` around the generator): gradients
+    are off unless a test switches them on (`torch.enable_grad()`), which is what selects the modules' training path."""
+    import torch
+    with torch.no_grad():
+        yield
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=True)
 

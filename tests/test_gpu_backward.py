@@ -39,13 +39,14 @@ def test_conv2d_backward_vs_torch_autograd(gf, n, ci, co, h, w, k, stride, pad):
     wt = torch.from_numpy((rs.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)).astype(np.float32))
     b = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
     xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
-    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
-    gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
-    yr.backward(gy.double())
     xd, wd, bd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
-    y = gf['gf'].conv2d(xd, wd, bd, stride=stride, padding=pad)
+    with torch.enable_grad():
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+        gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+        yr.backward(gy.double())
+        y = gf['gf'].conv2d(xd, wd, bd, stride=stride, padding=pad)
+        y.backward(gy.to(DEV))
     assert rel_err(c(y), c(yr)) < 2e-5
-    y.backward(gy.to(DEV))
     assert rel_err(c(xd.grad), c(xr.grad)) < 2e-5
     assert rel_err(c(wd.grad), c(wr.grad)) < 2e-5
     assert rel_err(c(bd.grad), c(br.grad)) < 2e-5
@@ -53,7 +54,7 @@ def test_conv2d_backward_vs_torch_autograd(gf, n, ci, co, h, w, k, stride, pad):
     assert torch.equal(gf['kernels'].conv2d_wgrad(x.to(DEV), gy.to(DEV), k, k, stride, pad), wd.grad)
     # no_weight_gradients() (conv2d_gradfix.py:25-31)
     xd2, wd2 = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
-    with gf['gf'].no_weight_gradients():
+    with torch.enable_grad(), gf['gf'].no_weight_gradients():
         gf['gf'].conv2d(xd2, wd2, None, stride=stride, padding=pad).backward(gy.to(DEV))
     assert wd2.grad is None and torch.equal(xd2.grad, xd.grad)
 
@@ -64,13 +65,14 @@ def test_conv_transpose2d_backward_vs_torch_autograd(gf, n, ci, co, h, w, pad):
     x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
     wt = torch.from_numpy((rs.standard_normal((ci, co, 3, 3)) / np.sqrt(ci * 9)).astype(np.float32))
     xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
-    yr = F.conv_transpose2d(xr, wr, stride=2, padding=pad)
-    gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
-    yr.backward(gy.double())
     xd, wd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
-    y = gf['gf'].conv_transpose2d(xd, wd, stride=2, padding=pad)
+    with torch.enable_grad():
+        yr = F.conv_transpose2d(xr, wr, stride=2, padding=pad)
+        gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+        yr.backward(gy.double())
+        y = gf['gf'].conv_transpose2d(xd, wd, stride=2, padding=pad)
+        y.backward(gy.to(DEV))
     assert rel_err(c(y), c(yr)) < 2e-5
-    y.backward(gy.to(DEV))
     assert rel_err(c(xd.grad), c(xr.grad)) < 2e-5
     assert rel_err(c(wd.grad), c(wr.grad)) < 2e-5
 
@@ -85,3 +87,35 @@ def test_wgrad_rejects_bad_geometry(gf):
         kk.conv2d_wgrad(x, g, 5, 5, 1, 2)
     with pytest.raises(_lib.ShgError):
         kk.conv2d_wgrad(x.cpu(), g, 3, 3, 1, 1)
+
+
+def test_discriminator_loss_gradients_vs_reference_golden(gf):
+    """One discriminator loss evaluation (stylegan_default_loss.py:96-117, Dmain) through the module tree on the HIP kernels --
+    convolutions, FIR filters and bias + lrelu_agc forward AND backward in HIP, the two dense layers as library GEMMs -- against
+    logits, loss and every parameter gradient produced by the reference's modules under torch autograd
+    (tests/golden/discriminator_grads.npz, tools/gen_golden.py)."""
+    from conftest import load_golden
+    from shgan_amd.model_zoo import stylegan
+    g = load_golden('discriminator_grads')
+    D = stylegan.Discriminator(resolution=32, ic_n=4, ch_base=256, ch_max=16, use_fp16_before_res=None, mbstd_group_size=4, mbstd_c_n=1)
+    D.load_state_dict({k[len('sd__'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd__')}, strict=True)
+    D = D.to(DEV).train().requires_grad_(True)
+    fake = torch.from_numpy(g['fake']).to(DEV).requires_grad_(True)
+    real = torch.from_numpy(g['real']).to(DEV)
+    with torch.enable_grad():
+        lf, lr = D(fake, None), D(real, None)
+        loss = F.softplus(lf).mean() + F.softplus(-lr).mean()
+        loss.backward()
+    assert rel_err(c(lf), g['logits_fake']) < 1e-4 and rel_err(c(lr), g['logits_real']) < 1e-4
+    assert abs(float(loss) - float(g['loss'])) < 1e-5 * abs(float(g['loss']))
+    assert rel_err(c(fake.grad), g['grad__fake']) < 2e-4
+    worst = 0.0
+    for name, p in D.named_parameters():
+        assert p.grad is not None, name
+        e = rel_err(c(p.grad), g['grad__' + name])
+        worst = max(worst, e)
+        assert e < 2e-4, (name, e)
+    print('worst parameter-gradient error', worst)
+    # the inference path is untouched by the same modules when no gradient is requested
+    with torch.no_grad():
+        assert rel_err(c(D(fake.detach(), None)), g['logits_fake']) < 1e-4

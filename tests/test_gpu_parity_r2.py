@@ -364,9 +364,10 @@ def test_upfirdn2d_backward_is_the_swapped_operator(mods, up, down, pad, fshape,
     rs = np.random.RandomState(19)
     x = rnd(rs, *shape).requires_grad_(True)
     f = rnd(rs, *fshape)
-    y = orc.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=1.7)
-    dy = rnd(rs, *y.shape)
-    (ref,) = torch.autograd.grad(y, x, dy)
+    with torch.enable_grad():
+        y = orc.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=1.7)
+        dy = rnd(rs, *y.shape)
+        (ref,) = torch.autograd.grad(y, x, dy)
     dx = ufd.upfirdn2d_backward(dy.to(DEV), f.to(DEV), tuple(shape), up=up, down=down, padding=pad, gain=1.7)
     assert tuple(dx.shape) == tuple(shape)
     assert rel_err(c(dx), ref.numpy()) < 1e-5

@@ -468,11 +468,38 @@ def gen_discriminator():
     save('discriminator', **out)
 
 
+def gen_discriminator_grads():
+    """Training row N3: one discriminator loss evaluation of stylegan_default_loss.py:96-117 (Dmain: softplus(D(fake)) and
+    softplus(-D(real)), means, gain 1) through the reference's own modules under autograd -- logits, loss, the gradient of
+    every parameter and of the fake image (what the generator step receives)."""
+    torch.manual_seed(2027)
+    with torch.enable_grad():
+        D = stylegan.Discriminator(resolution=32, ic_n=4, ch_base=256, ch_max=16, use_fp16_before_res=None,
+                                   resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=4, mbstd_c_n=1,
+                                   c_dim=None, cmap_dim=None).train().requires_grad_(True)
+        with torch.no_grad():
+            for n_, p_ in D.named_parameters():
+                if n_.endswith('.bias'):
+                    p_.copy_(torch.randn_like(p_) * 0.1)
+        out = _sd_arrays(D)
+        fake = torch.randn(8, 4, 32, 32).requires_grad_(True)
+        real = torch.randn(8, 4, 32, 32)
+        lf, lr = D(fake, None), D(real, None)
+        loss = torch.nn.functional.softplus(lf).mean() + torch.nn.functional.softplus(-lr).mean()
+        loss.backward()
+    out['fake'], out['real'] = fake.detach().numpy(), real.numpy()
+    out['logits_fake'], out['logits_real'], out['loss'] = lf.detach().numpy(), lr.detach().numpy(), np.float64(loss.item())
+    out['grad__fake'] = fake.grad.numpy()
+    for n_, p_ in D.named_parameters():
+        out['grad__' + n_] = p_.grad.numpy()
+    save('discriminator_grads', **out)
+
+
 GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modconv=gen_modconv,
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
-            discriminator=gen_discriminator)
+            discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
