@@ -1,0 +1,99 @@
+"""Gradient synchronisation for the data-parallel training rows: bucketed all-reduce over RCCL.
+
+The reference trains under ``DistributedDataParallel`` (``lib/experiments/stylegan_default.py:178-187`` wraps every trainable
+module, ``broadcast_buffers=False``) and sanitises each gradient before the optimiser step (``nan_to_num(nan=0, posinf=1e5,
+neginf=-1e5)``, ``:160-164``).  On MI355X the xGMI fabric is point to point
+(7 links x ~153 GB/s per GPU), so a ring all-reduce is bound per link and wants few, large messages -- but one message per phase
+cannot overlap with the backward pass.  ``BucketedAllReduce`` therefore
+  * lays every parameter's gradient out as a view into a few contiguous fp32 buckets (default 64 MiB: a 58 M-parameter
+    discriminator is 4 buckets, the 79 M-parameter generator 5), filled in REVERSE registration order -- the order in which
+    backward produces gradients;
+  * launches ``all_reduce(bucket, async_op=True)`` from a post-accumulate hook as soon as the last gradient of a bucket has
+    been written, i.e. while the rest of backward is still running (RCCL runs on its own stream);
+  * ``finish()`` waits for the outstanding handles, divides by the world size and applies the StyleGAN2 sanitisation
+    (``nan_to_num(nan=0, posinf=1e5, neginf=-1e5)``) in one pass per bucket.
+One process per GPU, backend ``nccl`` (= RCCL on ROCm); the CPU tests drive the same code over ``gloo``."""
+import torch
+import torch.distributed as dist
+
+
+class BucketedAllReduce:
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, sanitize=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.sanitize = sanitize
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []          # flat fp32 tensors
+        self._slot = {}            # id(param) -> (bucket index, offset, numel)
+        self._pending = []         # per bucket: gradients still missing in this backward pass
+        self._handles = []
+        self._hooks = []
+        cap = max(int(bucket_bytes) // 4, 1)
+        cur, cur_n = [], 0
+        groups = []
+        for p in reversed(self.params):                      # backward order
+            if cur and (cur_n + p.numel() > cap or p.device != cur[0].device):
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
+            off = 0
+            for p in grp:
+                if p.dtype != torch.float32:
+                    raise TypeError('BucketedAllReduce: fp32 parameters only')
+                p.grad = flat[off:off + p.numel()].view_as(p)          # gradients accumulate straight into the bucket
+                self._slot[id(p)] = (bi, off, p.numel())
+                off += p.numel()
+            self.buckets.append(flat)
+            self._pending.append(len(grp))
+        self._sizes = list(self._pending)
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- hooks ---------------------------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        bi, off, n = self._slot[id(p)]
+        flat = self.buckets[bi]
+        if p.grad.data_ptr() != flat[off:off + n].data_ptr():            # autograd replaced the view (first accumulation)
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+            p.grad = flat[off:off + n].view_as(p)
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and self.world > 1:
+            self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
+    # -- per step ------------------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        """Zero the buckets and (re-)attach every parameter's ``.grad`` view -- an optimiser's ``zero_grad(set_to_none=True)`` drops them."""
+        for flat in self.buckets:
+            flat.zero_()
+        for p in self.params:
+            bi, off, n = self._slot[id(p)]
+            if p.grad is None or p.grad.data_ptr() != self.buckets[bi][off:off + n].data_ptr():
+                p.grad = self.buckets[bi][off:off + n].view_as(p)
+        self._pending = list(self._sizes)
+        self._handles = []
+
+    def finish(self):
+        """Wait for the reductions of this backward pass; average, sanitise.  Buckets whose parameters did not all receive a
+        gradient (unused branches) are reduced here, synchronously."""
+        launched = {bi for bi, _ in self._handles}
+        for bi, h in self._handles:
+            h.wait()
+        for bi, flat in enumerate(self.buckets):
+            if self.world > 1 and bi not in launched:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                flat.div_(self.world)
+            if self.sanitize:
+                torch.nan_to_num(flat, nan=0.0, posinf=1e5, neginf=-1e5, out=flat)
+        self._handles = []
+        self._pending = list(self._sizes)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

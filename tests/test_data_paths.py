@@ -113,3 +113,66 @@ print("rank", r, "ok")
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_gloo_world2_bucketed_gradient_all_reduce():
+    """Training row N3 on CPU: ``grad_sync.BucketedAllReduce`` over two gloo ranks -- gradients live in contiguous buckets,
+    reductions are launched from the backward hooks, ``finish()`` averages and sanitises; the result must equal the
+    gradient of the mean loss over both ranks' data, with several buckets, an unused parameter, a NaN to be sanitised and a
+    second step after ``zero_grad()`` (and after an optimiser that drops the gradients)."""
+    script = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd.grad_sync import BucketedAllReduce
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 48), torch.nn.ReLU(), torch.nn.Linear(48, 1))
+unused = torch.nn.Parameter(torch.ones(5))
+params = list(net.parameters()) + [unused]
+sync = BucketedAllReduce(params, bucket_bytes=8192)          # 2048 floats per bucket -> several buckets
+assert len(sync.buckets) >= 3
+data = [torch.randn(16, 32, generator=torch.Generator().manual_seed(10 + k)) for k in range(2)]
+def ref_grads(scale):
+    gs = []
+    for k in range(2):
+        net2 = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 48), torch.nn.ReLU(), torch.nn.Linear(48, 1))
+        net2.load_state_dict(net.state_dict())
+        (net2(data[k]).square().mean() * scale).backward()
+        gs.append([p.grad.clone() for p in net2.parameters()])
+    return [(a + b) / 2 for a, b in zip(*gs)]
+for step, scale in enumerate((1.0, 3.0)):
+    want = ref_grads(scale)
+    if step == 0:
+        sync.zero_grad()
+    else:
+        for p in params:                 # what optimizer.zero_grad(set_to_none=True) does
+            p.grad = None
+        sync.zero_grad()
+    (net(data[r]).square().mean() * scale).backward()
+    if step == 0 and r == 1:
+        sync.buckets[0][0] = float("nan")            # a non-finite value on one rank must not survive
+    sync.finish()
+    for p, w in zip(net.parameters(), want):
+        if step == 0 and p.grad.data_ptr() == sync.buckets[0].data_ptr():
+            assert torch.isfinite(p.grad).all()
+            assert torch.allclose(p.grad.reshape(-1)[1:], w.reshape(-1)[1:], rtol=1e-5, atol=1e-7)
+        else:
+            assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7), (step, p.shape)
+    assert unused.grad is not None and float(unused.grad.abs().max()) == 0.0
+    # gradients are views into the buckets (one fused optimiser / sanitiser pass per bucket)
+    assert all(any(p.grad.data_ptr() >= b.data_ptr() and p.grad.data_ptr() < b.data_ptr() + 4 * b.numel() for b in sync.buckets) for p in params)
+sync.remove()
+dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+    port = str(33500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
