@@ -11,9 +11,9 @@ from .. import kernels
 from .common.get_model import get_model, register
 from .stylegan import Generator as Generator_StyleGan
 from .stylegan import Mapping as Mapping_StyleGan
-from .stylegan import dense, discrim_block, discrim_epilogue, synthesis_layer, torgb_layer
+from .stylegan import _add, dense, discrim_block, discrim_epilogue, synthesis_layer, torgb_layer
 from .stylegan import synthesis_block as stylegan_synthesis_block
-from .stylegan_utils import upfirdn2d
+from .stylegan_utils import grad_ops, upfirdn2d
 
 version = '0'
 symbol = 'comodgan'
@@ -32,11 +32,11 @@ class encoder_block(discrim_block):
     def forward(self, x, img):
         if self.fromrgb is not None:
             y = self.fromrgb(img.to(torch.float32))
-            x = kernels.bias_act(x, residual=y, act=False) if x is not None else y
+            x = _add(x, y) if x is not None else y
         if self.reslink:
             y = self.skip(x, gain=np.sqrt(0.5))
             feat = self.conv0(x)
-            x = kernels.bias_act(self.conv1(feat, gain=np.sqrt(0.5)), residual=y, act=False)
+            x = _add(self.conv1(feat, gain=np.sqrt(0.5)), y)
         else:
             feat = self.conv0(x)
             x = self.conv1(feat)
@@ -56,7 +56,7 @@ class encoder_epilogue(discrim_epilogue):
 
     def forward(self, x, img=None, cmap=None):
         if self.fromrgb is not None:
-            x = kernels.bias_act(x, residual=self.fromrgb(img.to(torch.float32)), act=False)
+            x = _add(x, self.fromrgb(img.to(torch.float32)))
         if self.mbstd is not None:
             x = self.mbstd(x)
         feat = self.conv(x)
@@ -64,7 +64,9 @@ class encoder_epilogue(discrim_epilogue):
         if self.out is not None:
             x = self.out(x)
         if self.dropout is not None and self.training:
-            raise NotImplementedError('the HIP path is inference-only: call .eval() (dropout is identity in eval)')
+            if not grad_ops.wants_grad(x):
+                raise NotImplementedError('dropout is active in train() mode: the inference path wants .eval() (identity)')
+            x = self.dropout(x)                                                            # comodgan.py:109-110
         if self.cmap_dim is not None:
             raise NotImplementedError('conditional projection is not on the generator path')
         return x, feat
@@ -139,7 +141,7 @@ class synthesis_block_first(nn.Module):
     def forward(self, x, x0, ws, fused_modconv=None, noise_mode='random', style_cache=None):
         w0 = x.to(torch.float32)
         x = self.fc(w0).view(w0.size(0), -1, self.resolution, self.resolution)
-        x = kernels.bias_act(x, residual=x0, act=False)
+        x = _add(x, x0)
         w_iter = iter(ws.unbind(dim=1))
         x = self.conv(x, _style_in(style_cache, self.conv, w_iter, w0), noise_mode=noise_mode, styles_sd=_style_of(style_cache, self.conv))
         img = None
@@ -214,7 +216,8 @@ class Synthesis(nn.Module):
             block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
             w_idx += block.num_conv
         w0 = x
-        cache = self._all_styles(ws, w0.to(torch.float32))
+        # (training rows: every layer derives its own styles under autograd; the grouped style kernels are an inference-path fusion)
+        cache = None if grad_ops.wants_grad(x, ws, *self.parameters()) else self._all_styles(ws, w0.to(torch.float32))
         x, img = self.b4(x, feats[4], block_ws[0], noise_mode=noise_mode, style_cache=cache)
         for res, cur_ws in zip(self.block_res[1:], block_ws[1:]):
             x, img = getattr(self, f'b{res}')(x, feats[res], img, cur_ws, w0, noise_mode=noise_mode, style_cache=cache)

@@ -16,6 +16,7 @@ from .. import kernels
 from .comodgan import Encoder as Encoder_base
 from .common.get_model import register
 from .stylegan import _cache_of
+from .stylegan_utils import grad_ops
 
 version = '0'
 symbol = 'shgan'
@@ -115,6 +116,12 @@ class heterogeneous_filter(nn.Module):
         """Standalone form (shgan.py:143-160): y = sum_k conv1x1(x, W)[:, :, k] * cw[k].  SHU.forward does not come through
         here -- it fuses this band sum with the Gaussian split and the inverse FFTs in one kernel."""
         n, c, h, w = x.shape
+        if grad_ops.wants_grad(x, self.weight):
+            # training rows (shgan.py:143-160 verbatim in structure): 1x1 convolution to O*B channels on the HIP conv (forward
+            # and backward), view [O, B], weighted sum over the bands
+            from .stylegan_utils import conv2d_gradfix
+            y = conv2d_gradfix.conv2d(x, self.weight.t().reshape(-1, c, 1, 1)).view(n, self.out_channels, -1, h, w)
+            return (y * self.cweight(h, w, x.device)[None, None]).sum(2)
         y = self.band_conv(x).view(n, self.out_channels, -1, h, w)
         cw = self.cweight(h, w, x.device)
         out = None
@@ -227,7 +234,26 @@ class SHU(nn.Module):
         t = self.conv0(t, relu=True)                   # 1x1 conv + bias + ReLU on the MFMA kernel
         return self.df1.band_conv(t), self._cw         # [N,2C*6,64,33]
 
+    def _forward_train(self, x):
+        """Training rows: shgan.py:312-336 on differentiable operators -- library FFTs (torch.fft -> rocFFT), the two 1x1
+        convolutions on the HIP conv kernels (forward / backward), everything else elementwise."""
+        sp = torch.fft.rfftn(x, dim=(2, 3), norm='forward')
+        hh = sp.shape[2]
+        sp = torch.cat([sp[:, :, hh // 2 + 1:], sp[:, :, :hh // 2 + 1]], dim=2)
+        t = self.conv0(torch.cat([sp.real, sp.imag], dim=1).contiguous(), relu=True)
+        t = self.df1(t)
+        sp = torch.complex(t[:, :self.out_channels], t[:, self.out_channels:])
+        out = {}
+        for r in self.reslist:
+            s_ = sp[:, :, self.input_res // 2 - r // 2: self.input_res // 2 + r // 2, 0: r // 2 + 1]
+            s_ = s_ * getattr(self, f'_gauss{r}')[None, None]
+            s_ = torch.cat([s_[:, :, r - r // 2 - 1:], s_[:, :, :r - r // 2 - 1]], dim=2)
+            out[r] = torch.fft.irfftn(s_, dim=(2, 3), norm='forward')
+        return out
+
     def forward(self, x):
+        if grad_ops.wants_grad(x, *self.parameters()):
+            return self._forward_train(x)
         y, cw = self._spectral(x)
         n, c = x.shape[0], self.out_channels
         outs = [torch.empty((n, c, r, r), device=x.device, dtype=torch.float32) for r in self.reslist]
@@ -264,5 +290,12 @@ class Encoder(Encoder_base):
     def forward(self, img, c=None):
         x, feats = super().forward(img, c)
         src = feats[self.shu_input_res]
-        self.shu.forward_accumulate(src[:, src.shape[1] - self.shu_channels:], feats)
+        ch = self.shu_channels
+        if grad_ops.wants_grad(src, *self.shu.parameters()):
+            # training rows (shgan.py:374-382): out-of-place split / add / cat so that autograd sees the hints
+            for r, v in self.shu(src[:, src.shape[1] - ch:]).items():
+                fa, fb = torch.split(feats[r], [feats[r].size(1) - ch, ch], dim=1)
+                feats[r] = torch.cat([fa, fb + v], dim=1)
+            return x, feats
+        self.shu.forward_accumulate(src[:, src.shape[1] - ch:], feats)
         return x, feats

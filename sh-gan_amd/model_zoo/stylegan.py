@@ -107,6 +107,11 @@ class conv2d(nn.Conv2d):
         if self.padding_mode != 'zeros' or self.groups != 1 or tuple(self.dilation) != (1, 1):
             raise NotImplementedError('conv2d: only zero padding, groups=1, dilation=1 run on the HIP path')
         stride, pad = self.stride[0], self.padding[0]
+        if grad_ops.wants_grad(x, self.weight, self.bias):
+            from .stylegan_utils import conv2d_gradfix
+            y = conv2d_gradfix.conv2d(x, self.weight * self.weight_gain, None if self.bias is None else self.bias * self.bias_gain,
+                                      stride=stride, padding=pad)
+            return torch.relu(y) if relu else y
         mode = kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2
         b = self.bias.detach() if self.bias is not None else None
         return kernels.conv2d(x, self.prepped(), mode=mode, pad=pad, bias=b, act=relu, alpha=0.0, act_gain=1.0, clamp=None)
@@ -159,6 +164,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
     misc.assert_shape(x, [batch_size, in_channels, None, None])
     misc.assert_shape(styles, [batch_size, in_channels])
+    if grad_ops.wants_grad(x, weight, styles, noise):
+        if _epilogue:
+            raise NotImplementedError('modulated_conv2d: the fused epilogue is an inference-path extension')
+        return _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight)
     ep = dict(_epilogue or {})
     if noise is not None and noise.ndim == 4 and noise.shape[0] == 1:
         noise = noise[0, 0]
@@ -192,6 +201,26 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                                         padding=padding, flip_weight=flip_weight)
     return kernels.bias_act(y, scale=d.reshape(-1) if d is not None else None, noise=noise, bias=ep.get('bias'),
                             residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
+
+
+def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight):
+    """Training rows: the non-fused form of stylegan.py:172-181 (what the reference runs while training) on differentiable
+    operators -- activations scaled by the styles, ONE shared-weight convolution (HIP forward / backward), demodulation
+    coefficient and noise applied afterwards.  The coefficient d[n,o] = rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + 1e-8) is evaluated
+    as rsqrt(s^2 @ (sum_k W^2)^T + 1e-8): the [N,O,I,k,k] tensor of stylegan.py:150-155 is never materialised."""
+    n = x.shape[0]
+    dcoefs = None
+    if demodulate:
+        weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
+        styles = styles * styles.square().mean().rsqrt()                                   # :147
+        dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
+    x = x * styles.reshape(n, -1, 1, 1)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight, f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    if demodulate and noise is not None:
+        return torch.addcmul(noise, x, dcoefs.reshape(n, -1, 1, 1))                        # fma.py:15
+    if demodulate:
+        return x * dcoefs.reshape(n, -1, 1, 1)
+    return x if noise is None else x + noise
 
 
 class conv2d_layer(nn.Module):
@@ -308,6 +337,13 @@ class synthesis_layer(conv2d_layer):
         ak = _act_kwargs(self.activation, gain)
         if ak is None or self.up not in (1, 2) or self.weight.shape[2] != 3:
             raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
+        if grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight):
+            # training rows (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
+            # non-fused modulated convolution, bias + activation; the skip tensor (extension) is added last
+            y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w), noise=None if noise is None else noise * self.noise_strength,
+                                 up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
+            y = grad_ops.bias_act(y, self.bias, **ak)
+            return y if residual is None else y + residual
         ns = self._noise_strength_host() if noise is not None else 0.0
         pw = self.prepped()
         if styles_sd is not None:
@@ -335,6 +371,11 @@ class torgb_layer(conv2d_layer):
     def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None, styles_sd=None):
         if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
             raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
+        if grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, base_img):
+            # training rows (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338)
+            y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w) * self.weight_gain, demodulate=False)
+            y = y + self.bias.view(1, -1, 1, 1)
+            return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
         if styles_sd is not None:
             s = styles_sd[0]
         else:
@@ -348,6 +389,8 @@ class torgb_layer(conv2d_layer):
 # ------------------------------------------------------------------------------------------------
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    if grad_ops.wants_grad(x):
+        return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()                 # stylegan.py:343-344
     if dim != 1 or x.ndim != 2:
         raise NotImplementedError('normalize_2nd_moment: HIP path handles [N,K] along dim 1')
     return kernels.normalize_2nd_moment(x, eps)

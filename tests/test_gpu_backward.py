@@ -119,3 +119,48 @@ def test_discriminator_loss_gradients_vs_reference_golden(gf):
     # the inference path is untouched by the same modules when no gradient is requested
     with torch.no_grad():
         assert rel_err(c(D(fake.detach(), None)), g['logits_fake']) < 1e-4
+
+
+def test_generator_parameter_gradients_vs_reference_golden(gf):
+    """Training row N3: d/dtheta of sum(G(x, z) * r) / N for EVERY generator parameter and for z, through this package's module
+    tree with gradients enabled (non-fused modulated convolutions on the HIP conv kernels forward AND backward, FIR up /
+    down-sampling and bias + lrelu_agc with their HIP backward, SHU through library FFTs) against the reference's own modules
+    under torch autograd (tests/golden/generator_grads.npz).  R = 256, reduced width, noise_mode='const', eval() (no dropout)."""
+    from conftest import load_golden
+    from shgan_amd import configs, eval_harness
+    from oracle import shgan_oracle as orc
+    g = load_golden('generator_grads')
+    res, ch_base, ch_max, w_dim, z_dim, w0_dim = [int(v) for v in g['cfg']]
+    sd = orc.init_state_dict(res, seed=int(g['seed']), ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim,
+                             noise_strength=0.1, bias_std=0.1)
+    G = configs.build_generator(res, ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim)
+    G.load_state_dict(sd, strict=True)
+    G = G.to(DEV).eval().requires_grad_(True)
+    real = torch.from_numpy(g['real_u8'].astype(np.float32)) / 127.5 - 1.0
+    n = real.shape[0]
+    mask = torch.from_numpy(np.unpackbits(g['mask_bits'])[: n * res * res].reshape(n, 1, res, res).astype(np.float32))
+    x = eval_harness.assemble_input(real, mask).to(DEV)
+    r = torch.from_numpy(np.random.RandomState(int(g['r_seed'])).standard_normal((n, 3, res, res)).astype(np.float32)).to(DEV)
+    z = torch.from_numpy(g['z']).to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        img = G(x=x, z=z, c=torch.zeros(n, 0, device=DEV), noise_mode='const')
+        loss = (img * r).sum() / n
+        loss.backward()
+    assert rel_err(c(img)[:, :, ::4, ::4], g['img_ds']) < 1e-3
+    assert abs(float(loss) - float(g['loss'])) < 1e-3 * max(abs(float(g['loss'])), 1.0)
+    assert rel_err(c(z.grad), g['grad__z']) < 1e-3
+    errs = {}
+    for name, p in G.named_parameters():
+        assert p.grad is not None, name
+        gn = p.grad.reshape(-1)
+        got = c(gn) if gn.numel() <= 4096 else np.concatenate([c(gn[:2048]), c(gn[-2048:])])
+        ref, (rsum, rnorm) = g['grad__' + name], g['gsum__' + name]
+        if float(np.abs(ref).max()) > 0:
+            errs[name] = rel_err(got, ref)
+        if gn.numel() > 1:
+            assert abs(float(gn.double().norm()) - rnorm) <= 2e-3 * max(rnorm, 1e-12) + 1e-12, name
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print('largest parameter-gradient errors:', [(k, float('%.2e' % v)) for k, v in top])
+    for name, e in errs.items():
+        # the noise strengths are single numbers = a sum of ~1e5 signed products: cancellation costs them a digit more
+        assert e < (2e-2 if name.endswith('noise_strength') else 2e-3), (name, e)

@@ -468,6 +468,36 @@ def gen_discriminator():
     save('discriminator', **out)
 
 
+def gen_generator_grads():
+    """Training row N3: gradients of a scalar functional of the generator output (sum(img * r) / N, noise_mode='const', dropout
+    off) with respect to EVERY generator parameter and to z, through the reference's own modules under autograd at reduced width
+    (R=256, <=32 ch).  Parameters larger than 4096 elements are stored as their first 2048 + last 2048 entries plus sum and
+    L2 norm."""
+    cfg = dict(resolution=256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = build_reference_generator(**cfg)
+    sd = orc.init_state_dict(256, seed=41, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    G = G.eval().requires_grad_(True)
+    real_u8, mask, z = synth_inputs(2, 256, 64, seed=42)
+    x = assemble_x(real_u8, mask)
+    rs = np.random.RandomState(43)
+    r = rs.standard_normal((2, 3, 256, 256)).astype(np.float32)
+    with torch.enable_grad():
+        zt = torch.from_numpy(z).requires_grad_(True)
+        img = G(x=x, z=zt, c=torch.zeros(2, 0), noise_mode='const')
+        loss = (img * torch.from_numpy(r)).sum() / 2
+        loss.backward()
+    out = dict(real_u8=real_u8, mask_bits=np.packbits(mask), z=z, r_seed=np.int64(43), seed=np.int64(41),
+               cfg=np.array([256, 2048, 32, 64, 64, 128], dtype=np.int64), loss=np.float64(loss.item()),
+               img_ds=img.detach()[:, :, ::4, ::4].numpy(), grad__z=zt.grad.numpy())
+    for n_, p_ in G.named_parameters():
+        g = p_.grad.reshape(-1).double()
+        out['gsum__' + n_] = np.array([g.sum().item(), g.norm().item()])
+        gn = p_.grad.reshape(-1).numpy()
+        out['grad__' + n_] = gn if gn.size <= 4096 else np.concatenate([gn[:2048], gn[-2048:]])
+    save('generator_grads', **out)
+
+
 def gen_discriminator_grads():
     """Training row N3: one discriminator loss evaluation of stylegan_default_loss.py:96-117 (Dmain: softplus(D(fake)) and
     softplus(-D(real)), means, gain 1) through the reference's own modules under autograd -- logits, loss, the gradient of
@@ -499,7 +529,7 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
-            discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads)
+            discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
