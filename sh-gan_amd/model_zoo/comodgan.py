@@ -64,9 +64,7 @@ class encoder_epilogue(discrim_epilogue):
         if self.out is not None:
             x = self.out(x)
         if self.dropout is not None and self.training:
-            if not grad_ops.wants_grad(x):
-                raise NotImplementedError('dropout is active in train() mode: the inference path wants .eval() (identity)')
-            x = self.dropout(x)                                                            # comodgan.py:109-110
+            x = self.dropout(x)                                  # comodgan.py:109-110 (identity in eval(); [N, oc_n] -- a tensor op)
         if self.cmap_dim is not None:
             raise NotImplementedError('conditional projection is not on the generator path')
         return x, feat
