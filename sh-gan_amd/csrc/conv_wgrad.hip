@@ -8,11 +8,12 @@
 //
 // GEMM view: M = 64 output channels, N = 64 input channels (x kh*kw taps), K = all output pixels of the batch.  One workgroup owns a
 // 64 x 64 x taps tile of dw for one slice of K; its four waves own the 2 x 2 sub-tiles of 32 x 32 with all taps in registers
-// (9 accumulator tiles for a 3x3 kernel) -- no cross-wave reduction.  K is walked in chunks of 64 (stride 1) or 32 (stride 2)
-// pixels of one output row: the 64-channel piece of g and the kh x 66-column window of x are staged in LDS pixel-major
+// (9 accumulator tiles for a 3x3 kernel) -- no cross-wave reduction.  K is walked in chunks of 64 (stride 1) or 32 (stride 2) pixels of one output row:
+// the 64-channel piece of g and the kh x (64 s + kw - 1)-column window of x are staged in LDS pixel-major
 // ([pixel][channel], pitch 65: coalesced global reads along a row become conflict-free LDS writes, and the operand reads of 32
-// consecutive channels are conflict-free too); one A operand feeds the nine taps' MFMAs.  68 KB of LDS and <= 256 registers: two
-// workgroups per CU cover each other's staging.  K slices are summed by a second tiny kernel in slice order, so the result is
+// consecutive channels are conflict-free too); one A operand feeds the nine taps' MFMAs.  Staging is software-pipelined through
+// registers (one workgroup per CU, 68 KB of LDS, the staged values live in the 512-register budget beside the 144
+// accumulators).  K slices are summed by a second tiny kernel in slice order, so the result is
 // deterministic (no atomics).
 #include "shg_common.h"
 
@@ -29,9 +30,9 @@ struct WgradParams {
 };
 
 template <int KH, int KW, int S>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, XW = PX * S + KW - 1, CP = 65;    // CP: channel pitch (odd)
-    constexpr int XE = XW > 64 ? XW - 64 : 0, XC = XW < 64 ? XW : 64;
+    constexpr int NXE = 64 * KH * XW, NX = (NXE + 255) / 256;   // elements of the x window, per thread
     __shared__ float Gs[PX * CP];                                // [pixel][o]
     __shared__ float Xs[KH * XW * CP];                           // [row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -45,38 +46,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const long gplane = (long)p.OH * p.OW, xplane = (long)p.H * p.W;
-    for (int c = c_begin; c < c_end; ++c) {
+    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before the MFMAs of chunk c and
+    // written to LDS after them, so their latency is covered by ~20 k cycles of matrix work instead of standing in front of it.
+    constexpr int NG = PX * 64 / 256;                            // g elements per thread
+    float rg[NG], rx[NX];
+    const int gpx = tid % PX, gog = tid / PX;                    // g: pixel, first channel
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int cx = c % p.chunks_x, oy = (c / p.chunks_x) % p.OH, n = c / (p.chunks_x * p.OH);
         const int ox0 = cx * PX;
+        {
+            const bool pok = ox0 + gpx < p.OW;
+            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0 + gpx;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int o = gog + j * (256 / PX);
+                rg[j] = (pok && o0 + o < p.O) ? gp[(long)o * gplane] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {                           // element e = (channel * KH + row) * XW + column: lanes walk along rows
+            const int e = tid + 256 * j;
+            const int q = e / XW, col = e - q * XW, i = q / KH, r = q - i * KH;
+            const int iy = oy * S - p.pad + r, ix = ox0 * S - p.pad + col;
+            const bool ok = e < NXE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + i < p.I;
+            rx[j] = ok ? p.x[((long)n * p.I + i0 + i) * xplane + (long)iy * p.W + ix] : 0.f;
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) Gs[gpx * CP + gog + j * (256 / PX)] = rg[j];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int e = tid + 256 * j;
+            const int q = e / XW, col = e - q * XW, i = q / KH, r = q - i * KH;
+            if (e < NXE) Xs[(r * XW + col) * CP + i] = rx[j];
+        }
+    };
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
         __syncthreads();                                         // previous chunk fully consumed
-        {   // g piece: 64 channels x PX pixels of output row oy; a wave reads whole row pieces
-            const int px = tid % PX, og = tid / PX;
-            const bool pok = ox0 + px < p.OW;
-            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0 + px;
-#pragma unroll 4
-            for (int o = og; o < 64; o += 256 / PX)
-                Gs[px * CP + o] = (pok && o0 + o < p.O) ? gp[(long)o * gplane] : 0.f;
-        }
-        {   // x window: 64 channels x KH rows x XW columns starting at (oy*S - pad, ox0*S - pad)
-            const int col = tid & 63, rg = tid >> 6;
-            const int ix = ox0 * S - p.pad + col;
-            const bool cok = col < XC && ix >= 0 && ix < p.W;
-            for (int q = rg; q < 64 * KH; q += 4) {              // (channel, row) pairs, four per pass
-                const int i = q / KH, r = q - i * KH;
-                const int iy = oy * S - p.pad + r;
-                const bool ok = cok && iy >= 0 && iy < p.H && i0 + i < p.I;
-                const float v = ok ? p.x[((long)n * p.I + i0 + i) * xplane + (long)iy * p.W + ix] : 0.f;
-                if (col < XC) Xs[(r * XW + col) * CP + i] = v;
-            }
-            for (int e = tid; e < 64 * KH * XE; e += 256) {      // the remaining XW - 64 columns
-                const int q = e / (XE > 0 ? XE : 1), cc = 64 + e % (XE > 0 ? XE : 1);
-                const int i = q / KH, r = q - i * KH;
-                const int iy = oy * S - p.pad + r, ix2 = ox0 * S - p.pad + cc;
-                const bool ok = iy >= 0 && iy < p.H && ix2 >= 0 && ix2 < p.W && i0 + i < p.I;
-                Xs[(r * XW + cc) * CP + i] = ok ? p.x[((long)n * p.I + i0 + i) * xplane + (long)iy * p.W + ix2] : 0.f;
-            }
-        }
+        store_chunk();
         __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);
 #pragma unroll 2
         for (int ks = 0; ks < PX / 2; ++ks) {
             const int k = 2 * ks + half;                         // pixel of this lane's operand row
