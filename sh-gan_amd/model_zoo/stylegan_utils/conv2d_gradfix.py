@@ -8,8 +8,9 @@ lib/model_zoo/stylegan_utils/conv2d_gradfix.py:35-43, forward AND first-order ba
 * weight gradient: ``shg_conv2d_wgrad_f32`` (replaces the cuDNN backward-weight call of :140-146), bias gradient: a sum.
 
 Supported geometry is what the generator / discriminator need: 3x3 / 1x1 kernels, stride 1 or 2, dilation 1, symmetric
-padding, groups = 1 under autograd (grouped forward only), and the stride-2 3x3 transposed form.  Second-order gradients
-(``Conv2dGradWeight.backward``, needed by the R1 / path-length regularisers) are not built."""
+padding, groups = 1 under autograd (grouped forward only), and the stride-2 3x3 transposed form.  The backward passes are
+themselves written with these operators (and ``_WgradFn`` has the derivatives of ``Conv2dGradWeight.backward``,
+conv2d_gradfix.py:148-163), so gradients of gradients work: the R1 and path-length regularisers differentiate twice."""
 import torch
 
 from ... import kernels
@@ -74,6 +75,41 @@ def _convt_fwd(x, weight, bias, padding, groups):
     return y
 
 
+def _conv_input_grad(g, weight, x_shape, stride, padding):
+    """dL/dx of y = conv2d(x, weight, stride, padding) from g = dL/dy, through the public (differentiable) operators: a stride-1
+    convolution with the flipped, channel-transposed weights, or the stride-2 transposed convolution cropped / zero-extended to
+    the input extent (the output_padding rule of conv2d_gradfix.py:96-105)."""
+    k = weight.shape[2]
+    if stride == 1:
+        return conv2d(g, weight.transpose(0, 1).flip(2, 3), stride=1, padding=k - 1 - padding)
+    if k != 3:
+        raise NotImplementedError('conv2d backward: 1x1 stride-2 convolutions (the forward decimates with upfirdn2d first)')
+    return _fit(conv_transpose2d(g, weight, stride=2, padding=0), x_shape[2], x_shape[3], padding)
+
+
+class _WgradFn(torch.autograd.Function):
+    """dw[o,i,ky,kx] = sum g[n,o,oy,ox] * x[n,i,oy*s-p+ky,ox*s-p+kx] -- bilinear in (g, x); its own derivatives are again a
+    convolution and an input gradient (Conv2dGradWeight.backward, conv2d_gradfix.py:148-163), which makes the convolution
+    twice differentiable (R1 / path-length regularisers)."""
+
+    @staticmethod
+    def forward(ctx, g, x, k, stride, padding):
+        ctx.save_for_backward(g, x)
+        ctx.geom = (k, stride, padding)
+        return kernels.conv2d_wgrad(x.detach().contiguous(), g.detach().contiguous(), k, k, stride, padding)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        g, x = ctx.saved_tensors
+        k, stride, padding = ctx.geom
+        gg = gx = None
+        if ctx.needs_input_grad[0]:
+            gg = conv2d(x, ggw, stride=stride, padding=padding)
+        if ctx.needs_input_grad[1]:
+            gx = _conv_input_grad(g, ggw, x.shape, stride, padding)
+        return gg, gx, None, None, None
+
+
 class _Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w, b, stride, padding), groups = 1."""
 
@@ -87,20 +123,12 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         stride, padding, has_bias = ctx.geom
-        k = weight.shape[2]
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if stride == 1:
-                wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
-                gx = _conv_fwd(g, wt, None, 1, k - 1 - padding, 1)
-            elif k == 3:
-                full = _convt_fwd(g, weight.detach(), None, 0, 1)                 # [.., 2*OH+1, 2*OW+1]
-                gx = _fit(full, x.shape[2], x.shape[3], padding)
-            else:
-                raise NotImplementedError('conv2d backward: 1x1 stride-2 convolutions (the forward decimates with upfirdn2d first)')
+            gx = _conv_input_grad(g, weight, x.shape, stride, padding)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            gw = kernels.conv2d_wgrad(x.detach(), g, k, k, stride, padding)
+            gw = _WgradFn.apply(g, x, weight.shape[2], stride, padding)
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum([0, 2, 3])
         return gx, gw, gb, None, None
@@ -122,10 +150,10 @@ class _ConvTranspose2dFn(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _conv_fwd(g, weight.detach(), None, 2, padding, 1)              # conv2d_gradfix.py:124-127, transpose flipped
+            gx = conv2d(g, weight, stride=2, padding=padding)                     # conv2d_gradfix.py:124-127, transpose flipped
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             # dw[ci,co,ky,kx] = sum x[n,ci,y,x] * g[n,co,2y-p+ky,2x-p+kx]: the conv weight gradient with the tensors exchanged
-            gw = kernels.conv2d_wgrad(g, x.detach(), 3, 3, 2, padding)
+            gw = _WgradFn.apply(x, g, 3, 2, padding)
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum([0, 2, 3])
         return gx, gw, gb, None

@@ -5,7 +5,8 @@ never comes here: the modules switch to these only when gradients are requested 
   ``shg_bias_act_backward_f32`` from the saved OUTPUT (sign and clamp state are readable from it), bias gradient = channel sum;
 * FIR resampling has its backward in ``upfirdn2d.py`` (``upfirdn2d`` is its own gradient with up / down exchanged,
   upfirdn2d.py:174-192); convolutions in ``conv2d_gradfix.py``.
-First order only: the R1 / path-length regularisers (stylegan_default_loss.py:76-91, 118-124) need second derivatives."""
+Every backward is written with differentiable operators again, so second derivatives (the R1 / path-length regularisers,
+stylegan_default_loss.py:76-91, 118-124) work."""
 import torch
 
 from ... import kernels
@@ -13,6 +14,22 @@ from ... import kernels
 
 def wants_grad(*ts):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+class _BiasActBwdFn(torch.autograd.Function):
+    """dx = g * slope(y): linear in g, piecewise constant in y -- its derivative with respect to g is the same operator."""
+
+    @staticmethod
+    def forward(ctx, g, y, cfg):
+        ctx.save_for_backward(y)
+        ctx.cfg = cfg
+        act, gain, alpha, act_gain, clamp = cfg
+        return kernels.bias_act_backward(g.detach().contiguous(), y, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return _BiasActBwdFn.apply(gg, y, ctx.cfg), None, None
 
 
 class _BiasActFn(torch.autograd.Function):
@@ -28,7 +45,7 @@ class _BiasActFn(torch.autograd.Function):
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         act, gain, alpha, act_gain, clamp, has_bias = ctx.cfg
-        dx = kernels.bias_act_backward(g.contiguous(), y, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        dx = _BiasActBwdFn.apply(g, y, (act, gain, alpha, act_gain, clamp))
         db = dx.sum([0] + list(range(2, dx.ndim))) if has_bias and ctx.needs_input_grad[1] else None
         return dx, db, None, None, None, None, None
 

@@ -3,7 +3,7 @@ lib/model_zoo/stylegan_utils/upfirdn2d.py (``setup_filter`` :66, ``upfirdn2d`` :
 ``filter2d`` :245, ``upsample2d`` :279, ``downsample2d`` :316).
 
 Differences by design: the native library is prebuilt and mandatory (no `_upfirdn2d_ref`
-fallback, upfirdn2d.py:237-239).  Differentiable in ``x`` (first order): the backward is the same operator with up and
+fallback, upfirdn2d.py:237-239).  Differentiable in ``x`` to any order: the backward is the same operator with up and
 down exchanged (upfirdn2d.py:174-192)."""
 import numpy as np
 import torch
@@ -122,9 +122,9 @@ class _UpfirdnFn(torch.autograd.Function):
     def backward(ctx, dy):
         (f,) = ctx.saved_tensors
         x_shape, up, down, padding, flip_filter, gain = ctx.cfg
-        with torch.no_grad():
-            dx = upfirdn2d_backward(dy.contiguous(), f, x_shape, up=list(up), down=list(down), padding=list(padding),
-                                    flip_filter=flip_filter, gain=gain)
+        # (the public operator again: differentiable when dy carries a graph -- second derivatives)
+        dx = upfirdn2d_backward(dy.contiguous(), f, x_shape, up=list(up), down=list(down), padding=list(padding),
+                                flip_filter=flip_filter, gain=gain)
         return dx, None, None, None, None, None, None
 
 

@@ -164,3 +164,77 @@ def test_generator_parameter_gradients_vs_reference_golden(gf):
     for name, e in errs.items():
         # the noise strengths are single numbers = a sum of ~1e5 signed products: cancellation costs them a digit more
         assert e < (2e-2 if name.endswith('noise_strength') else 2e-3), (name, e)
+
+
+def test_discriminator_r1_regulariser_second_order_vs_reference_golden(gf):
+    """Dreal + Dr1 of stylegan_default_loss.py:104-127: the R1 penalty |d logits / d image|^2 (first derivative with
+    create_graph, weight gradients switched off as in the reference) differentiated again with respect to every parameter --
+    convolution, FIR and activation backward passes are themselves differentiable HIP operators."""
+    from conftest import load_golden
+    from shgan_amd.model_zoo import stylegan
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    g = load_golden('discriminator_grads')
+    D = stylegan.Discriminator(resolution=32, ic_n=4, ch_base=256, ch_max=16, use_fp16_before_res=None, mbstd_group_size=4, mbstd_c_n=1)
+    D.load_state_dict({k[len('sd__'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd__')}, strict=True)
+    D = D.to(DEV).train().requires_grad_(True)
+    with torch.enable_grad():
+        real = torch.from_numpy(g['real']).to(DEV).requires_grad_(True)
+        logits = D(real, None)
+        with conv2d_gradfix.no_weight_gradients():
+            (r1_grads,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[real], create_graph=True, only_inputs=True)
+        r1 = r1_grads.square().sum([1, 2, 3])
+        (logits * 0 + F.softplus(-logits) + r1.reshape(-1, 1) * (10.0 / 2)).mean().backward()
+    assert rel_err(c(r1), g['r1_penalty']) < 1e-4
+    errs = {name: rel_err(c(p.grad), g['r1grad__' + name]) for name, p in D.named_parameters()}
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print('largest R1 parameter-gradient errors:', [(k, float('%.2e' % v)) for k, v in top])
+    assert max(errs.values()) < 5e-4, top
+
+
+def test_generator_path_length_regulariser_second_order_vs_reference_golden(gf):
+    """Gpl of stylegan_default_loss.py:76-91: |d (img . noise) / d ws| (create_graph) -> penalty -> gradients of every generator
+    parameter that the penalty reaches, against the reference's autograd; a second-order path through the modulated
+    convolutions (HIP forward / input-gradient / weight-gradient kernels), the FIR up-sampling and the activations."""
+    from conftest import load_golden
+    from shgan_amd import configs, eval_harness
+    from oracle import shgan_oracle as orc
+    g = load_golden('generator_grads')
+    res, ch_base, ch_max, w_dim, z_dim, w0_dim = [int(v) for v in g['cfg']]
+    sd = orc.init_state_dict(res, seed=int(g['seed']), ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim,
+                             noise_strength=0.1, bias_std=0.1)
+    G = configs.build_generator(res, ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim)
+    G.load_state_dict(sd, strict=True)
+    G = G.to(DEV).eval().requires_grad_(True)
+    real = torch.from_numpy(g['real_u8'].astype(np.float32)) / 127.5 - 1.0
+    n = real.shape[0]
+    mask = torch.from_numpy(np.unpackbits(g['mask_bits'])[: n * res * res].reshape(n, 1, res, res).astype(np.float32))
+    x = eval_harness.assemble_input(real, mask).to(DEV)
+    rs = np.random.RandomState(int(g['r_seed']))
+    rs.standard_normal((n, 3, res, res))                                   # (the first draw was `r` of the first-order golden)
+    pl_noise = torch.from_numpy(rs.standard_normal((n, 3, res, res)).astype(np.float32) / np.sqrt(res * res)).to(DEV)
+    z = torch.from_numpy(g['z']).to(DEV)
+    with torch.enable_grad():
+        ws = G.mapping(z, torch.zeros(n, 0, device=DEV))
+        xg, feats = G.encoder(x)
+        img = G.synthesis(xg, feats, ws, noise_mode='const')
+        (pl_grads,) = torch.autograd.grad(outputs=[(img * pl_noise).sum()], inputs=[ws], create_graph=True, only_inputs=True)
+        pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+        (img[:, 0, 0, 0] * 0 + pl_lengths.square() * 2.0).mean().backward()
+    assert rel_err(c(pl_lengths), g['pl_lengths']) < 1e-3
+    errs, missing = {}, []
+    for name, p in G.named_parameters():
+        key = 'plgrad__' + name
+        if key not in g.files:
+            continue
+        if p.grad is None:
+            missing.append(name)
+            continue
+        gn = p.grad.reshape(-1)
+        got = c(gn) if gn.numel() <= 4096 else np.concatenate([c(gn[:2048]), c(gn[-2048:])])
+        if float(np.abs(g[key]).max()) > 0:
+            errs[name] = rel_err(got, g[key])
+    assert not missing, missing
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print('largest path-length parameter-gradient errors:', [(k, float('%.2e' % v)) for k, v in top])
+    for name, e in errs.items():
+        assert e < (5e-2 if name.endswith('noise_strength') else 5e-3), (name, e)

@@ -495,6 +495,24 @@ def gen_generator_grads():
         out['gsum__' + n_] = np.array([g.sum().item(), g.norm().item()])
         gn = p_.grad.reshape(-1).numpy()
         out['grad__' + n_] = gn if gn.size <= 4096 else np.concatenate([gn[:2048], gn[-2048:]])
+    # Gpl (stylegan_default_loss.py:76-91): path-length penalty = second-order path through mapping output -> synthesis
+    G.zero_grad()
+    pl_noise = rs.standard_normal((2, 3, 256, 256)).astype(np.float32) / np.sqrt(256 * 256)
+    with torch.enable_grad():
+        ws = G.mapping(torch.from_numpy(z), torch.zeros(2, 0))
+        xg, feats = G.encoder(x)
+        img = G.synthesis(xg, feats, ws, noise_mode='const')
+        pl_grads = torch.autograd.grad(outputs=[(img * torch.from_numpy(pl_noise)).sum()], inputs=[ws], create_graph=True, only_inputs=True)[0]
+        pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+        ((img[:, 0, 0, 0] * 0 + pl_lengths.square() * 2.0).mean()).backward()
+    out['pl_lengths'] = pl_lengths.detach().numpy()
+    for n_, p_ in G.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.reshape(-1).double()
+        out['plsum__' + n_] = np.array([g.sum().item(), g.norm().item()])
+        gn = p_.grad.reshape(-1).numpy()
+        out['plgrad__' + n_] = gn if gn.size <= 4096 else np.concatenate([gn[:2048], gn[-2048:]])
     save('generator_grads', **out)
 
 
@@ -522,6 +540,18 @@ def gen_discriminator_grads():
     out['grad__fake'] = fake.grad.numpy()
     for n_, p_ in D.named_parameters():
         out['grad__' + n_] = p_.grad.numpy()
+    # Dreal + Dr1 (stylegan_default_loss.py:104-127): the R1 penalty differentiates the logits with respect to the real images
+    # and is then differentiated with respect to the parameters -- a second-order path through every operator
+    D.zero_grad()
+    with torch.enable_grad():
+        real_tmp = real.detach().requires_grad_(True)
+        real_logits = D(real_tmp, None)
+        r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_tmp], create_graph=True, only_inputs=True)[0]
+        r1_penalty = r1_grads.square().sum([1, 2, 3])
+        (real_logits * 0 + torch.nn.functional.softplus(-real_logits) + r1_penalty.reshape(-1, 1) * (10.0 / 2)).mean().backward()
+    out['r1_penalty'] = r1_penalty.detach().numpy()
+    for n_, p_ in D.named_parameters():
+        out['r1grad__' + n_] = p_.grad.numpy()
     save('discriminator_grads', **out)
 
 
