@@ -61,6 +61,8 @@ __device__ __forceinline__ float ufd_epilogue(const UfdParams& p, float v, int n
 // (16+FH-1) x (64+FW-1) input window is staged in LDS with coalesced row loads (1.2 loads per output instead
 // of FH*FW), then every lane produces 4 vertically adjacent outputs from a register window.
 // Per-plane part of the epilogue, evaluated once per (n,c) plane instead of once per output.
+__device__ __attribute__((aligned(16))) float shg_ufd_zeros[64];   // stand-in for an absent noise operand (unconditional loads)
+
 struct UfdPlane { float sc, bs; const float* nz; const float* res; };
 __device__ __forceinline__ UfdPlane ufd_plane(const UfdParams& p, int nc) {
     UfdPlane q;
@@ -321,8 +323,19 @@ __global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p
         }
         __syncthreads();
         const int u = u0 + tu0, v = v0 + tv;
-        // next plane's window: in flight while this one is filtered
-        if (nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);
+        // vmcnt retires in order and counts stores: a noise row requested behind the window prefetch (or behind a store) can only
+        // be waited for by draining both.  The noise rows are therefore requested unconditionally (an absent operand reads
+        // zeros), two rows ahead, and the next plane's window only after the last of them (after output row 1).
+        const bool vecp = VEC && v + 1 < p.W;
+        const float* nzb = (p.has_epilogue && plq.nz) ? plq.nz : shg_ufd_zeros;
+        const bool nzp = vecp && p.has_epilogue && plq.nz;
+        auto nz_row = [&](int dy) __attribute__((always_inline)) {
+            const int yy = 2 * u + dy < p.OH ? 2 * u + dy : p.OH - 1;
+            return *reinterpret_cast<const float4*>(nzb + (nzp ? yy * p.OW + 2 * v : 0));
+        };
+        float4 nzq[2];
+        if (VEC) { nzq[0] = nz_row(0); nzq[1] = nz_row(1); }
+        else if (nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);
         // neighbourhood of the lane's 2 x 2 low-res pixels: rows Y = 2u-1 .. 2u+5, cols X = 2v-1 .. 2v+5; element (r,c)
         // lives in plane (ra,cb) = ((r+1)&1, (c+1)&1)
         float m[7][7];
@@ -337,11 +350,10 @@ __global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p
                 m[r][c] = tile[ra * 2 + cb][ur * PITCH + vc];
             }
         }
-        if (v < p.W) {
 #pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-                __builtin_amdgcn_sched_barrier(0);     // one output row at a time: keeps the live set small
-                if (2 * u + dy >= p.OH) continue;
+        for (int dy = 0; dy < 4; ++dy) {
+            __builtin_amdgcn_sched_barrier(0);     // one output row at a time: keeps the live set small
+            if (v < p.W && 2 * u + dy < p.OH) {
                 float o4[4];
 #pragma unroll
                 for (int dx = 0; dx < 4; ++dx) {
@@ -354,10 +366,9 @@ __global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p
                 }
                 const int pix = (2 * u + dy) * p.OW + 2 * v;
                 float* yp = p.y + (long)nc * p.OH * p.OW + pix;
-                if (VEC && v + 1 < p.W) {
+                if (vecp) {
                     // 16-byte path: scale / noise / bias / activation / skip on four outputs at once
-                    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.has_epilogue && plq.nz) nz = *reinterpret_cast<const float4*>(plq.nz + pix);
+                    const float4 nz = nzq[dy & 1];
                     const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
                     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.has_epilogue && plq.res) rs = *reinterpret_cast<const float4*>(plq.res + pix);
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p
                         }
                         o[dx] = t;
                     }
+                    if (dy < 2) nzq[dy & 1] = nz_row(dy + 2);                    // ahead of this row's store
                     if (!(p.dbg & 4) || o[0] == 12345.f) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
 #pragma unroll
@@ -380,6 +392,8 @@ __global__ __launch_bounds__(256, 4) void fir_up_planar_kernel(const UfdParams p
                         if (2 * v + dx < p.OW) yp[dx] = ufd_finish(p, plq, o4[dx], pix + dx);
                 }
             }
+            // next plane's window: every thread stages its part -- outside the per-lane conditions, behind the last noise request
+            if (VEC && dy == 1 && nc + (int)gridDim.z < p.NC) load_tile(nc + gridDim.z);
         }
         __syncthreads();
     }
