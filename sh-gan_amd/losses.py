@@ -1,0 +1,111 @@
+"""The StyleGAN2 training loss on the HIP training path -- same class name, constructor and ``accumulate_gradients`` contract as
+``lib/experiments/stylegan_default_loss.py:16-128`` (non-saturating logistic loss, lazy R1 on the discriminator, lazy
+path-length regularisation on the generator, style mixing), so that the reference's training loop
+(``stylegan_default.py:150-166``: one call per phase and round, then ``nan_to_num`` + optimiser step) can drive it unchanged.
+
+What differs: gradients flow through this package's differentiable operators (``model_zoo/stylegan_utils/conv2d_gradfix.py``,
+``grad_ops.py``, ``upfirdn2d.py`` -- convolution, FIR and activation forward and backward in HIP, twice differentiable);
+``sync`` is accepted and ignored (gradient reduction is ``grad_sync.BucketedAllReduce``, not DDP's implicit hooks, so there is
+nothing to suppress between accumulation rounds); an ADA ``augment_pipe`` is not supported; the statistics reporting of the
+reference (``training_stats.report``) is replaced by ``self.stats``, a plain dict of the last values."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .model_zoo.stylegan_utils import conv2d_gradfix
+
+PHASES = ('Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth')
+
+
+class Loss:
+    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
+        raise NotImplementedError()
+
+
+class StyleGAN2Loss(Loss):
+    def __init__(self, device, G_mapping, G_synthesis, D, augment_pipe=None, style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2,
+                 pl_decay=0.01, pl_weight=2):
+        super().__init__()
+        if augment_pipe is not None:
+            raise NotImplementedError('ADA augmentation is not part of the HIP path')
+        self.device = device
+        self.G_mapping, self.G_synthesis, self.D = G_mapping, G_synthesis, D
+        self.style_mixing_prob = style_mixing_prob
+        self.r1_gamma, self.pl_batch_shrink, self.pl_decay, self.pl_weight = r1_gamma, pl_batch_shrink, pl_decay, pl_weight
+        self.pl_mean = torch.zeros([], device=device)
+        self.randn_like = torch.randn_like          # (tests substitute a fixed draw for the path-length noise)
+        self.stats = {}
+
+    # -- forward helpers (stylegan_default_loss.py:31-51) ----------------------------------------------------------------
+    def run_G(self, z, c, sync=True):
+        ws = self.G_mapping(z, c)
+        if self.style_mixing_prob > 0:
+            # with probability p the rows from a random cutoff on come from a second latent
+            cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
+            cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
+            cut = int(cutoff)
+            if cut < ws.shape[1]:
+                ws2 = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
+                ws = torch.cat([ws[:, :cut], ws2[:, cut:]], dim=1)
+        return self.G_synthesis(ws), ws
+
+    def run_D(self, img, c, sync=True):
+        return self.D(img, c)
+
+    # -- one phase (stylegan_default_loss.py:53-128) -----------------------------------------------------------------------
+    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync=True, gain=1):
+        if phase not in PHASES:
+            raise AssertionError(f'unknown phase {phase!r}')
+        do_Gmain = phase in ('Gmain', 'Gboth')
+        do_Dmain = phase in ('Dmain', 'Dboth')
+        do_Gpl = phase in ('Greg', 'Gboth') and self.pl_weight != 0
+        do_Dr1 = phase in ('Dreg', 'Dboth') and self.r1_gamma != 0
+        with torch.enable_grad():
+            if do_Gmain:                                             # maximise the logits of generated images
+                gen_img, _ = self.run_G(gen_z, gen_c)
+                gen_logits = self.run_D(gen_img, gen_c)
+                loss_Gmain = F.softplus(-gen_logits)                 # -log(sigmoid(logits))
+                self.stats.update({'Loss/scores/fake': gen_logits.detach(), 'Loss/G/loss': loss_Gmain.detach()})
+                loss_Gmain.mean().mul(gain).backward()
+
+            if do_Gpl:                                               # path-length regularisation on a shrunk batch
+                n = gen_z.shape[0] // self.pl_batch_shrink
+                gen_img, gen_ws = self.run_G(gen_z[:n], gen_c[:n])
+                pl_noise = self.randn_like(gen_img) / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
+                with conv2d_gradfix.no_weight_gradients():
+                    (pl_grads,) = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[gen_ws], create_graph=True,
+                                                      only_inputs=True)
+                pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+                pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
+                self.pl_mean.copy_(pl_mean.detach())
+                pl_penalty = (pl_lengths - pl_mean).square()
+                loss_Gpl = pl_penalty * self.pl_weight
+                self.stats.update({'Loss/pl_penalty': pl_penalty.detach(), 'Loss/G/reg': loss_Gpl.detach()})
+                (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
+
+            loss_Dgen = 0
+            if do_Dmain:                                             # minimise the logits of generated images
+                with torch.no_grad():
+                    gen_img, _ = self.run_G(gen_z, gen_c)
+                gen_logits = self.run_D(gen_img, gen_c)
+                loss_Dgen = F.softplus(gen_logits)                   # -log(1 - sigmoid(logits))
+                self.stats['Loss/scores/fake'] = gen_logits.detach()
+                loss_Dgen.mean().mul(gain).backward()
+
+            if do_Dmain or do_Dr1:                                   # maximise the logits of real images; R1 on the same pass
+                real_tmp = real_img.detach().requires_grad_(do_Dr1)
+                real_logits = self.run_D(real_tmp, real_c)
+                self.stats['Loss/scores/real'] = real_logits.detach()
+                loss_Dreal = 0
+                if do_Dmain:
+                    loss_Dreal = F.softplus(-real_logits)
+                    self.stats['Loss/D/loss'] = (loss_Dgen + loss_Dreal).detach()
+                loss_Dr1 = 0
+                if do_Dr1:
+                    with conv2d_gradfix.no_weight_gradients():
+                        (r1_grads,) = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_tmp], create_graph=True,
+                                                          only_inputs=True)
+                    r1_penalty = r1_grads.square().sum([1, 2, 3])
+                    loss_Dr1 = (r1_penalty * (self.r1_gamma / 2)).reshape(-1, 1)
+                    self.stats.update({'Loss/r1_penalty': r1_penalty.detach(), 'Loss/D/reg': loss_Dr1.detach()})
+                (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()

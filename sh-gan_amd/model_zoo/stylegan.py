@@ -476,7 +476,7 @@ class synthesis_block(nn.Module):
 
     def forward(self, x, img, ws, fused_modconv=None, noise_mode='random'):
         if self.const is not None:
-            x = self.const.detach().unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = (self.const if grad_ops.wants_grad(self.const) else self.const.detach()).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
         w_iter = iter(ws.unbind(dim=1))

@@ -238,3 +238,86 @@ def test_generator_path_length_regulariser_second_order_vs_reference_golden(gf):
     print('largest path-length parameter-gradient errors:', [(k, float('%.2e' % v)) for k, v in top])
     for name, e in errs.items():
         assert e < (5e-2 if name.endswith('noise_strength') else 5e-3), (name, e)
+
+
+
+def test_stylegan2_loss_phases_match_hand_written_autograd(gf):
+    """``losses.StyleGAN2Loss`` (the contract of stylegan_default_loss.py:16-128) on the plain StyleGAN2 generator / discriminator at
+    reduced width: every phase accumulates exactly the gradients of the formula it stands for -- Gmain = softplus(-D(G(z))),
+    Dmain = softplus(D(G(z))) + softplus(-D(x)), Dreg = r1_gamma/2 |dD/dx|^2, Greg = pl_weight (|J^T y| - pl_mean)^2 -- on the network
+    being trained, scaled by ``gain``; the operators behind them are pinned on the reference in the tests above."""
+    from shgan_amd import losses
+    from shgan_amd.model_zoo import stylegan as sg
+    torch.manual_seed(3)
+    mp = sg.Mapping(z_dim=32, c_dim=0, w_dim=32, num_ws=8, num_layers=3, lr_multiplier=0.01, w_avg_beta=0.995)
+    syn = sg.Synthesis(w_dim=32, resolution=32, rgb_n=3, ch_base=256, ch_max=16, use_fp16_after_res=32)
+    G = sg.Generator(mp, syn).to(DEV).train()
+    D = sg.Discriminator(resolution=32, ic_n=3, ch_base=256, ch_max=16, use_fp16_before_res=None, mbstd_group_size=4, mbstd_c_n=1).to(DEV).train()
+    noise_fix = torch.randn(2, 3, 32, 32, device=DEV)
+    L = losses.StyleGAN2Loss(DEV, G.mapping, G.synthesis, D, style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+    L.randn_like = lambda t: noise_fix[:t.shape[0]]
+    z, real, cnd = torch.randn(4, 32, device=DEV), torch.randn(4, 3, 32, 32, device=DEV), torch.zeros(4, 0, device=DEV)
+
+    def grads(mod):
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in mod.named_parameters()}
+
+    def zero():
+        G.zero_grad(set_to_none=True); D.zero_grad(set_to_none=True)
+
+    def synth(zz):                        # the generator as the loss calls it; the noise inputs are random per call -> use 'const'
+        return G.synthesis(G.mapping(zz, cnd[:zz.shape[0]]), noise_mode='const')
+    L.G_synthesis = lambda ws: G.synthesis(ws, noise_mode='const')
+
+    # ---- Gmain
+    zero(); G.requires_grad_(True); D.requires_grad_(False)
+    L.accumulate_gradients('Gmain', real, cnd, z, cnd, sync=True, gain=2)
+    got = grads(G)
+    zero()
+    with torch.enable_grad():
+        (F.softplus(-D(synth(z), cnd)).mean() * 2).backward()
+    want = grads(G)
+    assert all(p.grad is None for p in D.parameters())
+    for n in want:
+        assert torch.allclose(got[n], want[n], rtol=1e-4, atol=1e-7), n
+    # ---- Dboth = Dmain + Dreg in one pass over the real images
+    zero(); G.requires_grad_(False); D.requires_grad_(True)
+    L.accumulate_gradients('Dboth', real, cnd, z, cnd, sync=True, gain=1)
+    got = grads(D)
+    zero()
+    with torch.enable_grad():
+        with torch.no_grad():
+            fake = synth(z)
+        F.softplus(D(fake, cnd)).mean().backward()
+        rt = real.detach().requires_grad_(True)
+        lr = D(rt, cnd)
+        (r1g,) = torch.autograd.grad([lr.sum()], [rt], create_graph=True)
+        (F.softplus(-lr) + (r1g.square().sum([1, 2, 3]) * 5.0).reshape(-1, 1)).mean().backward()
+    want = grads(D)
+    for n in want:
+        assert torch.allclose(got[n], want[n], rtol=2e-4, atol=1e-6), n
+    assert all(p.grad is None for p in G.parameters())
+    assert 'Loss/r1_penalty' in L.stats and L.stats['Loss/D/loss'].shape == (4, 1)
+    # ---- Greg: path length on the shrunk batch, pl_mean updated with the EMA of the lengths
+    zero(); G.requires_grad_(True); D.requires_grad_(False)
+    assert float(L.pl_mean) == 0.0
+    L.accumulate_gradients('Greg', real, cnd, z, cnd, sync=True, gain=4)
+    got = grads(G)
+    zero()
+    with torch.enable_grad():
+        ws = G.mapping(z[:2], cnd[:2])
+        img = G.synthesis(ws, noise_mode='const')
+        (plg,) = torch.autograd.grad([(img * (noise_fix / 32.0)).sum()], [ws], create_graph=True)
+        pll = plg.square().sum(2).mean(1).sqrt()
+        plm = torch.zeros([], device=DEV).lerp(pll.mean(), 0.01)
+        ((img[:, 0, 0, 0] * 0 + (pll - plm).square() * 2).mean() * 4).backward()
+    want = grads(G)
+    assert abs(float(L.pl_mean) - float(plm)) <= 1e-5 * abs(float(plm))
+    for n in want:
+        if want[n] is None:
+            assert got[n] is None or float(got[n].abs().max()) == 0.0, n
+        else:
+            assert torch.allclose(got[n], want[n], rtol=5e-4, atol=1e-6), n
+    with pytest.raises(AssertionError):
+        L.accumulate_gradients('Gall', real, cnd, z, cnd)
+    with pytest.raises(NotImplementedError):
+        losses.StyleGAN2Loss(DEV, G.mapping, G.synthesis, D, augment_pipe=object())
