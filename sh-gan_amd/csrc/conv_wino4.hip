@@ -12,10 +12,13 @@
 // blocks = 16 x 32 pixels) = 72 accumulator tiles of 32x32 on 8 waves: waves 0-3 own four positions (8 tiles) each, waves
 // 4-7 five positions (10 tiles) each -- one wave of either kind per SIMD.  K is consumed in chunks of 8 input channels:
 //   * U (pre-transformed weights, [O/64][chunk][k-step][unit][lane]) goes straight into registers: a ring of one chunk
-//     (4 k-steps x 8 or 10 operands), every slot re-loaded for the next chunk right after its MFMAs were issued;
-//   * the raw 18 x 40 window of a channel arrives by 16-byte LDS-DMA (waves 4-7, two channels each);
-//   * waves 0-3 transform two channels each (B^T d B on the 6x6 patch, styles applied) into V [36][8][32] in LDS;
-//   * V and the raw windows are double buffered, one barrier per chunk.
+//     (4 k-steps x 8 or 10 operands), every slot re-loaded for the next chunk two MFMAs after the MFMA that read it;
+//   * the raw 18 x 40 window of a channel arrives by 16-byte LDS-DMA (waves 4-7, two channels each, issued as inline
+//     assembly so that the compiler does not drain the weight prefetch behind it);
+//   * waves 0-3 transform two channels each (B^T d B on the 6x6 patch read as conflict-free b128, styles applied) into
+//     V [36][8][32] in LDS, stage by stage between their own MFMAs;
+//   * V and the raw windows are double buffered, one raw s_barrier per chunk, the MFMA stream skewed one k-step across it.
+// DESIGN.md section 5 ("What bounds an fp32-MFMA kernel") has the measurements behind these choices.
 // Epilogue: the 36 M_xi of an (o, t) pair live in different waves -> exchanged through LDS in four passes of 16 channels x
 // 32 blocks; each thread applies A^T . A, the fused layer tail (demodulation coefficient, noise, bias, lrelu_agc, skip) and
 // stores its 4x4 pixels as four 16-byte rows.
@@ -25,7 +28,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) float shg_wino4_zeros[64];
 
