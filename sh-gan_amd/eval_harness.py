@@ -99,8 +99,8 @@ def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, ga
         x, z, _, _ = synthetic_items(ids[b0:b0 + batch_size], resolution, z_dim, seed=seed, device=device)
         outs.append(step_fn(x, z))
     local = torch.cat(outs)
-    if not gather or world == 1:
-        return ids, local
+    if not gather or (world == 1 and not (dist.is_available() and dist.is_initialized())):
+        return ids, local          # (a 1-rank process group still goes through the collective: same code path as N ranks)
     # concatenated-along-dim-0 form: the one layout both RCCL and gloo accept for all_gather_into_tensor
     full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(full, local.contiguous())

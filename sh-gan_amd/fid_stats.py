@@ -57,7 +57,7 @@ class FidStats:
     def all_reduce(self):
         """Sum the moments over all ranks (one collective per evaluation)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():     # (a 1-rank group goes through the collective too: same path as N ranks)
             dist.all_reduce(self.S, op=dist.ReduceOp.SUM)
         return self
 

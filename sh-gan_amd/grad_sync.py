@@ -18,11 +18,12 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, sanitize=True):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, sanitize=True, always_reduce=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.sanitize = sanitize
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reduce = self.world > 1 or (always_reduce and dist.is_initialized())    # (always_reduce: run the collective in a 1-rank group too)
         self.buckets = []          # flat fp32 tensors
         self._slot = {}            # id(param) -> (bucket index, offset, numel)
         self._pending = []         # per bucket: gradients still missing in this backward pass
@@ -62,7 +63,7 @@ class BucketedAllReduce:
             flat[off:off + n].copy_(p.grad.reshape(-1))
             p.grad = flat[off:off + n].view_as(p)
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.world > 1:
+        if self._pending[bi] == 0 and self.reduce:
             self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     # -- per step ------------------------------------------------------------------------------------------------------
@@ -84,7 +85,7 @@ class BucketedAllReduce:
         for bi, h in self._handles:
             h.wait()
         for bi, flat in enumerate(self.buckets):
-            if self.world > 1 and bi not in launched:
+            if self.reduce and bi not in launched:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
                 flat.div_(self.world)

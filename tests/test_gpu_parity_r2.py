@@ -402,3 +402,47 @@ def test_shu_fused_spectral_kernel_vs_two_convolutions(mods):
         shu.conv0.weight.mul_(0.5)
     a2 = shu(x)
     assert rel_err(c(a2[64]), c(a[64])) > 1e-3
+
+
+def test_rccl_collectives_on_the_gpu_single_rank_group():
+    """The collectives of the multi-GPU rows through RCCL itself (backend 'nccl') on the one GPU of this box: a 1-rank group
+    still runs `all_gather_into_tensor` (sharded_eval's gather), `all_reduce` (FID moments, gradient buckets) as RCCL kernels on
+    device buffers -- what the gloo world-2 CPU tests cannot show."""
+    import os, subprocess, sys
+    script = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd import configs, eval_harness as hz
+from shgan_amd.fid_stats import FidStats
+from shgan_amd.grad_sync import BucketedAllReduce
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"], rank=0, world_size=1, device_id=torch.device("cuda:0"))
+kw = dict(ch_base=2048, ch_max=32, w_dim=64, z_dim=48, w0_dim=96)
+G = configs.seeded_init_(configs.build_generator(256, **kw), seed=5).eval().requires_grad_(False).to("cuda:0")
+with torch.no_grad():
+    order, merged = hz.sharded_eval(G, n_items=5, batch_size=2, resolution=256, seed=3, device="cuda:0", rank=0, world=1, gather=True, z_dim=48)
+    ids, local = hz.sharded_eval(G, n_items=5, batch_size=2, resolution=256, seed=3, device="cuda:0", rank=0, world=1, gather=False, z_dim=48)
+assert order == ids == list(range(5)) and isinstance(merged, np.ndarray) and np.array_equal(merged, local.cpu().numpy())
+st = FidStats(16, device="cuda:0")
+f = torch.randn(40, 16, device="cuda:0", dtype=torch.float64)
+st.add(f); st.all_reduce()
+cnt, mu, cov = st.mean_cov()
+fc = f.cpu().numpy()
+assert cnt == 40 and np.allclose(mu, fc.mean(0)) and np.allclose(cov, np.cov(fc.T, bias=True), atol=1e-10)
+net = torch.nn.Linear(64, 64).to("cuda:0")
+sync = BucketedAllReduce(net.parameters(), bucket_bytes=4096, always_reduce=True)
+sync.zero_grad()
+x = torch.randn(8, 64, device="cuda:0")
+net(x).square().mean().backward()
+sync.finish()
+ref = torch.nn.Linear(64, 64).to("cuda:0"); ref.load_state_dict(net.state_dict())
+ref(x).square().mean().backward()
+assert torch.allclose(net.weight.grad, ref.weight.grad) and torch.allclose(net.bias.grad, ref.bias.grad)
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    env = dict(os.environ, SHG_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), SHG_PORT=str(35500 + os.getpid() % 2000),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b'rccl ok' in p.stdout, p.stdout.decode()[-3000:]

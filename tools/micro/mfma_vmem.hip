@@ -3,6 +3,9 @@
 //  mode 2: + 8 loads with SGPR base + 32-bit VGPR offset         mode 3: + 2 global_load_dwordx4 (same bytes)
 //  mode 4: + 8 ds_read_b32                                       mode 5: loads refill the A operand of the MFMA issued 2 earlier (ring)
 //  mode 6: like 5, refill right behind the reader               mode 7: mode 1 with ONE wave per SIMD (256 threads)
+//  mode 8: mode 1 with the accumulators in AGPRs (inline asm)   mode 9: mode 0 with the accumulators in AGPRs   mode 10: mode 4 + AGPR
+//  mode 11: the 8 loads of an iteration in one burst ahead of its 8 MFMAs   mode 12: 8 MFMAs + 8 loads whose results are never used as
+//  MFMA operands but land in registers (mode 1) vs. loads into ONE register (same destination, write-after-write)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,19 +28,25 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ src, float
         const int o = (it & 7) * 512;
         float ld[8];
         f32x4 l4[2];
+        if (MODE == 11) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ld[j] = pl[o + j * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc[j], 0, 0, 0);
-            if (MODE == 1 || MODE == 7) ld[j] = pl[o + j * 64];
+            if (MODE >= 8 && MODE <= 10) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a[j]), "v"(b));
+            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc[j], 0, 0, 0);
+            if (MODE == 1 || MODE == 7 || MODE == 8) ld[j] = pl[o + j * 64];
             if (MODE == 2) ld[j] = pu[o + j * 64 + lane];
             if (MODE == 3 && (j & 3) == 0) l4[j >> 2] = *reinterpret_cast<const f32x4*>(pu + o + (j >> 2) * 256 + lane * 4);
-            if (MODE == 4) ld[j] = lds[(lane + j * 64 + o) & 4095];
+            if (MODE == 4 || MODE == 10) ld[j] = lds[(lane + j * 64 + o) & 4095];
             if (MODE == 5 && j >= 2) a[j - 2] = pl[o + j * 64];
             if (MODE == 6) a[j] = pl[o + j * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 5) { a[6] = pl[o + 6 * 64 + 1]; a[7] = pl[o + 7 * 64 + 1]; }
-        if (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7) for (int j = 0; j < 8; ++j) sink += ld[j];
+        if (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7 || MODE == 8 || MODE == 10 || MODE == 11) for (int j = 0; j < 8; ++j) sink += ld[j];
         if (MODE == 3) sink += l4[0][0] + l4[1][3];
     }
     float s = sink;
@@ -65,5 +74,6 @@ int main() {
     const int iters = 50000;
     run<0>(src, out, iters); run<1>(src, out, iters); run<2>(src, out, iters); run<3>(src, out, iters);
     run<4>(src, out, iters); run<5>(src, out, iters); run<6>(src, out, iters); run<7>(src, out, iters);
+    run<8>(src, out, iters); run<9>(src, out, iters); run<10>(src, out, iters); run<11>(src, out, iters);
     return 0;
 }
