@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libshgan_hip.so'
 SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-inline-asm']
 
 
 def _hipcc():

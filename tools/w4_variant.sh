@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../sh-gan_amd"
 TAG=$1; shift
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -Wno-inline-asm"
 mkdir -p lib/objcache
 for f in csrc/*.hip; do
   b=$(basename $f .hip); [ $b = conv_wino4 ] && continue
