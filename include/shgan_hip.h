@@ -121,6 +121,12 @@ int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, c
  * computes y [NB,O,OH,OW] = act(conv3x3_stride2 + bias)*gain + residual (OH = H/2, OW = W/2; OH, OW >= 16, OW % 4 == 0). */
 int shg_fir_down_planar_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int PP, int flip, float gain,
                             void* stream);
+/* Row-marching form of the same pre-filter for a SEPARABLE filter f[ky][kx] = fy[ky]*fx[kx] (every filter upfirdn2d.setup_filter
+ * builds from a 1-D kernel, upfirdn2d.py:61-95): taps_host = {fx[0..3], fy[0..3]} in HOST memory.  PP == 0: y [N,C,H+1,W+1]
+ * (= upfirdn2d(x, f, padding=2)); PP > 0: the polyphase planes above with pitch PP.  W in {8,16,32,64,128,256,512}. */
+int shg_fir_pad2_sep_supported(int H, int W, int PP);
+int shg_fir_pad2_sep_f32(const float* x, const float* taps_host, float* y, int N, int C, int H, int W, int PP, int flip, float gain,
+                         void* stream);
 int shg_conv_weight_prep_down_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP, int flip,
                                        void* stream);
 int shg_conv2d_down_poly_supported(int NB, int I, int O, int OH, int OW);

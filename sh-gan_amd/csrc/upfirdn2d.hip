@@ -15,6 +15,7 @@
 //    comodgan.py:326-327) a single pass over HBM.
 //  * upfirdn_generic_kernel: any up/down/padding/filter (RGB skip upsample, D's down path, tests).
 #include "shg_common.h"
+#include "fir_march.h"
 #include <stdlib.h>
 
 struct UfdParams {
@@ -487,6 +488,56 @@ extern "C" int shg_fir_down_planar_f32(const float* x, const float* f, float* y,
     SHG_CHECK_ARG(4L * N * C * (H / 2 + 1) * PP <= 2147483647L, "fir_down_planar: output is too large");
     p.pl_ph2 = H / 2 + 1; p.pl_pp = PP;
     return ufd_launch(p, (hipStream_t)stream);
+}
+
+// Row-marching form of the same pad-2 4x4 pre-filter (fir_march.h) for a SEPARABLE filter f[ky][kx] = fy[ky] * fx[kx] -- every
+// filter upfirdn2d.setup_filter builds from a 1-D kernel (upfirdn2d.py:61-95).  taps_host = {fx[0..3], fy[0..3]} in HOST memory
+// (they travel as kernel arguments).  PP == 0: y [N,C,H+1,W+1]; PP > 0: the polyphase planes of shg_fir_down_planar_f32 with
+// pitch PP (a multiple of 32 floats makes every store a whole 128-byte line for W >= 256).
+extern "C" int shg_fir_pad2_sep_supported(int H, int W, int PP) {
+    if (H < 2 || W < 8 || W > 512 || !(W % 64 == 0 ? (W == 64 || W == 128 || W == 256 || W == 512) : 64 % W == 0)) return 0;
+    if (PP > 0 && (H % 2 || W % 2 || PP % 4 || PP < W / 2 + 1)) return 0;
+    return 1;
+}
+
+extern "C" int shg_fir_pad2_sep_f32(const float* x, const float* taps_host, float* y, int N, int C, int H, int W, int PP, int flip,
+                                    float gain, void* stream) {
+    SHG_CHECK_ARG(x && taps_host && y, "fir_pad2_sep: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1, "fir_pad2_sep: bad shape");
+    SHG_CHECK_ARG(shg_fir_pad2_sep_supported(H, W, PP), "fir_pad2_sep: unsupported geometry (shg_fir_pad2_sep_supported)");
+    SHG_CHECK_ARG((long)N * C * (H + 1) * (W + 1) <= 2147483647L && (PP == 0 || 4L * N * C * (H / 2 + 1) * PP <= 2147483647L),
+                  "fir_pad2_sep: tensor too large");
+    FirMarchParams p{};
+    p.x = x; p.y = y; p.NC = N * C; p.H = H; p.W = W;
+    p.mode = PP > 0; p.pitch = PP > 0 ? PP : W + 1; p.ph2 = H / 2 + 1;
+    for (int k = 0; k < 4; ++k) {
+        p.a[k] = taps_host[flip ? k : 3 - k];
+        p.b[k] = taps_host[4 + (flip ? k : 3 - k)] * gain;
+    }
+    const int OH = H + 1;
+    const bool wide = p.mode && W % 256 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
+                      PP % 2 == 0;
+    p.LPG = wide ? 64 : (W < 64 ? W : 64);
+    p.G = wide ? 1 : 64 / p.LPG;
+    const int npg = shg_cdiv(p.NC, p.G);
+    int nseg = shg_cdiv(8192, npg);                              // ~8k waves; at least 16 rows each (3 halo rows are re-read per segment)
+    if (nseg > OH / 16) nseg = OH / 16;
+    if (nseg < 1) nseg = 1;
+    p.R = shg_cdiv(OH, nseg); p.nseg = shg_cdiv(OH, p.R); p.nitem = npg * p.nseg;
+    const dim3 grid(shg_cdiv(p.nitem, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (wide) {
+        if (W == 256) hipLaunchKernelGGL((fir_down_march4_kernel<1, 8>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fir_down_march4_kernel<2, 8>), grid, dim3(256), 0, s, p);
+    } else {
+        const int K = shg_cdiv(W, 64);
+        if (K == 1) hipLaunchKernelGGL((fir_down_march_kernel<1, 8>), grid, dim3(256), 0, s, p);
+        else if (K == 2) hipLaunchKernelGGL((fir_down_march_kernel<2, 8>), grid, dim3(256), 0, s, p);
+        else if (K == 4) hipLaunchKernelGGL((fir_down_march_kernel<4, 8>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fir_down_march_kernel<8, 4>), grid, dim3(256), 0, s, p);
+    }
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
 }
 
 // Second half of the up-sampling synthesis layer: 4x4 FIR (pad 1, `gain`) over the four phase planes written by

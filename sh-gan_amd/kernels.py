@@ -166,6 +166,34 @@ def upfirdn2d_out_size(h, w, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0
     return oh.value, ow.value
 
 
+FIR_MARCH = True        # separable 4x4 filters take the row-marching FIR kernels (csrc/fir_march.h)
+
+
+def sep_taps(f):
+    """Host taps {fx[0..3], fy[0..3]} (ctypes float[8]) when the 4x4 filter ``f`` is an outer product fy (x) fx -- every filter
+    ``upfirdn2d.setup_filter`` builds from a 1-D kernel (upfirdn2d.py:61-95) -- else None.  One device read per filter tensor
+    and version, cached on the tensor."""
+    if not FIR_MARCH or f is None or tuple(f.shape) != (4, 4):
+        return None
+    key = (f.data_ptr(), f._version)
+    hit = getattr(f, '_shg_sep', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    import numpy as np
+    fh = f.detach().to('cpu', torch.float64).numpy()
+    tot = fh.sum()
+    taps = None
+    if np.isfinite(fh).all() and abs(tot) > 1e-30:
+        fy, fx = fh.sum(1), fh.sum(0) / tot
+        if np.abs(np.outer(fy, fx) - fh).max() <= 1e-7 * np.abs(fh).max():
+            taps = (ctypes.c_float * 8)(*[float(v) for v in fx], *[float(v) for v in fy])
+    try:
+        f._shg_sep = (key, taps)
+    except Exception:
+        pass
+    return taps
+
+
 def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0,
               epilogue=None):
     """Mirror of ``upfirdn2d_plugin.upfirdn2d`` (upfirdn2d.cpp:16).  ``epilogue`` (dict) fuses
@@ -186,7 +214,14 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
     lib = _lib.get_lib()
     work = 4.0 * (x.numel() + y.numel())                       # algorithmic bytes: input once, output once
     if epilogue is None:
+        taps = None
+        if (upx, upy, downx, downy) == (1, 1, 1, 1) and (padx0, padx1, pady0, pady1) == (2, 2, 2, 2) and (fh, fw) == (4, 4) \
+                and lib.shg_fir_pad2_sep_supported(h, w, 0):
+            taps = sep_taps(f)
         with _timed(L, 'upfirdn2d', work):
+            if taps is not None:
+                check(lib.shg_fir_pad2_sep_f32(_ptr(x), taps, _ptr(y), n, c, h, w, 0, int(bool(flip)), float(gain), L.stream()), 'fir_pad2_sep')
+                return y
             check(lib.shg_upfirdn2d_f32(_ptr(x), _ptr(f), _ptr(y), n, c, h, w, fh, fw, upx, upy, downx, downy, padx0, padx1,
                                         pady0, pady1, int(bool(flip)), float(gain), L.stream()), 'upfirdn2d')
         return y
@@ -495,7 +530,10 @@ def fir_conv_down2(x, f, pw, bias=None, act=False, gain=1.0, alpha=0.2, act_gain
         raise _lib.ShgError('fir_conv_down2: f must be 4x4')
     n, i, h, w = x.shape
     oh, ow = h // 2, w // 2
-    pp = (ow + 1 + 3) // 4 * 4
+    lib = _lib.get_lib()
+    taps = sep_taps(f) if lib.shg_fir_pad2_sep_supported(h, w, 4) else None
+    # plane pitch: whole 128-byte lines per row for the wide planes of the marching FIR (its stores want that), else 16 bytes
+    pp = (ow + 1 + 31) // 32 * 32 if (taps is not None and w % 256 == 0) else (ow + 1 + 3) // 4 * 4
     wa, wb = pw.down_poly()
     L.view(wa, 'weights')
     xp = L.new((4, n, i, oh + 1, pp))
@@ -504,10 +542,12 @@ def fir_conv_down2(x, f, pw, bias=None, act=False, gain=1.0, alpha=0.2, act_gain
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.ShgError('fir_conv_down2: residual shape mismatch')
     a, al, g, cl = _act_args(act, gain, alpha, act_gain, clamp)
-    lib = _lib.get_lib()
     with _timed(L, 'upfirdn2d', 4.0 * (x.numel() + n * i * (h + 1) * (w + 1))):
-        check(lib.shg_fir_down_planar_f32(_ptr(x), _ptr(f), _ptr(xp), n, i, h, w, pp, int(bool(flip_filter)), 1.0, L.stream()),
-              'fir_down_planar')
+        if taps is not None:
+            check(lib.shg_fir_pad2_sep_f32(_ptr(x), taps, _ptr(xp), n, i, h, w, pp, int(bool(flip_filter)), 1.0, L.stream()), 'fir_pad2_sep')
+        else:
+            check(lib.shg_fir_down_planar_f32(_ptr(x), _ptr(f), _ptr(xp), n, i, h, w, pp, int(bool(flip_filter)), 1.0, L.stream()),
+                  'fir_down_planar')
     nba, nbb = ((oh + 2) // 3) * ((ow + 2) // 3), (oh // 2) * (ow // 2)
     with _timed(L, 'conv_poly_down', 2.0 * n * pw.o * i * 9 * oh * ow, 2.0 * n * pw.o * i * 16.0 * (nba + nbb)):
         check(lib.shg_conv2d_down_poly_f32(_ptr(xp), _ptr(wa), _ptr(wb), _ptr(y), n, i, pw.o, pw.op, oh, ow, pp, None, _ptr(bias),

@@ -79,6 +79,53 @@ def test_fir_fast_path_vs_oracle(mods, shape, pad, gain):
         assert rel_err(c(y), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 512, 512), (1, 5, 256, 256), (3, 2, 128, 128), (2, 7, 64, 64), (5, 3, 32, 32), (3, 5, 16, 16),
+                                   (1, 9, 8, 8), (2, 3, 64, 128)])
+def test_fir_march_pad2_vs_oracle_and_tiled_kernel(mods, shape):
+    """Row-marching pad-2 FIR (csrc/fir_march.h, separable filters): plain rows and polyphase planes, against the oracle
+    (upfirdn2d.py:98-138 semantics) and against the tiled kernel it replaces; asymmetric separable taps catch flips; a filter
+    that is not an outer product must keep the general kernel."""
+    orc, ufd, K = mods['orc'], mods['ufd'], mods['kernels']
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+    n, ch, h, w = shape
+    lib = K._lib.get_lib()
+    assert lib.shg_fir_pad2_sep_supported(h, w, 0) == 1
+    fa = torch.from_numpy(np.outer([0.5, 1.5, -0.7, 0.2], [0.3, 1.0, 2.0, -0.4]).astype(np.float32))
+    for f in (orc.setup_filter([1, 3, 3, 1]), fa):
+        assert K.sep_taps(f.to(DEV)) is not None
+        for flip in (False, True):
+            ref = orc.upfirdn2d(x, f, padding=[2, 2, 2, 2], gain=1.5, flip_filter=flip).numpy()
+            fd = f.to(DEV)
+            y = c(ufd.upfirdn2d(x.to(DEV), fd, padding=[2, 2, 2, 2], gain=1.5, flip_filter=flip))
+            assert rel_err(y, ref) < 1e-5
+            K.FIR_MARCH = False
+            try:
+                y_old = c(ufd.upfirdn2d(x.to(DEV), f.to(DEV), padding=[2, 2, 2, 2], gain=1.5, flip_filter=flip))
+            finally:
+                K.FIR_MARCH = True
+            assert rel_err(y, y_old) < 1e-6
+            if lib.shg_fir_pad2_sep_supported(h, w, 4):
+                for pp in ((w // 2 + 1 + 3) // 4 * 4, (w // 2 + 1 + 31) // 32 * 32):
+                    xp = torch.full((4, n, ch, h // 2 + 1, pp), float('nan'), device=DEV)
+                    K.check(lib.shg_fir_pad2_sep_f32(K._ptr(x.to(DEV)), K.sep_taps(fd), K._ptr(xp), n, ch, h, w, pp, int(flip), 1.5,
+                                                     None), 'fir_pad2_sep')
+                    full = np.zeros((n, ch, 2 * (h // 2 + 1), 2 * pp), np.float32)
+                    full[:, :, :h + 1, :w + 1] = ref
+                    got = c(xp)
+                    for a in range(2):
+                        for b in range(2):
+                            assert np.array_equal(np.isnan(got[a * 2 + b]), np.zeros_like(got[a * 2 + b], bool))
+                            assert np.abs(got[a * 2 + b] - full[:, :, a::2, b::2]).max() < 1e-5 * max(1.0, np.abs(ref).max())
+                            pad = full[:, :, a::2, b::2] == 0
+                            edge = np.zeros_like(pad); edge[:, :, :, (w + 1 - b + 1) // 2:] = True; edge[:, :, (h + 1 - a + 1) // 2:, :] = True
+                            assert (got[a * 2 + b][edge] == 0).all()           # beyond the filtered image: exact zeros
+    fn = torch.from_numpy(rs.standard_normal((4, 4)).astype(np.float32))
+    assert K.sep_taps(fn.to(DEV)) is None
+    ref = orc.upfirdn2d(x, fn, padding=[2, 2, 2, 2]).numpy()
+    assert rel_err(c(ufd.upfirdn2d(x.to(DEV), fn.to(DEV), padding=[2, 2, 2, 2])), ref) < 1e-5
+
+
 def test_fir_fused_epilogue_vs_oracle(mods):
     orc, k = mods['orc'], mods['kernels']
     rs = np.random.RandomState(2)
