@@ -104,6 +104,12 @@ int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int 
 int shg_upfir_planar_f32(const float* mid, const float* f, float* y, int N, int C, int H, int W, int flip, float gain,
                          const float* scale, const float* bias, const float* noise, int noise_mode, float noise_strength,
                          int act, float alpha, float act_gain, float clamp, const float* residual, void* stream);
+/* The same for a SEPARABLE filter (row-marching kernel): taps_host = {fx[0..3], fy[0..3]} in HOST memory; W even, W/2 a divisor of
+ * 64 or W in {128, 256}; y / noise / residual 16-byte aligned. */
+int shg_upfir_planar_sep_supported(int H, int W);
+int shg_upfir_planar_sep_f32(const float* mid, const float* taps_host, float* y, int N, int C, int H, int W, int flip, float gain,
+                             const float* scale, const float* bias, const float* noise, int noise_mode, float noise_strength,
+                             int act, float alpha, float act_gain, float clamp, const float* residual, void* stream);
 /* Polyphase-Winograd form of mode 2 / out_mode 1 (conv_wino_poly.hip): the `ee` phase as F(3x3,2x2), `eo`/`oe`/`oo` of
  * every 2x2 block of low-resolution pixels with 16 multiplies, one-pixel strips by single-tap contractions -- 5.8 instead of
  * 9 multiplies per low-resolution pixel, same result up to fp32 round-off.  y [4][NB,O,H+1,W+1] raw phase planes (no

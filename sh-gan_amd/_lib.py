@@ -53,6 +53,8 @@ _SIGS = {
     'shg_conv2d_wino4_supported': [c_i] * 5,
     'shg_conv2d_wino4_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_upfir_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_upfir_planar_sep_supported': [c_i, c_i],
+    'shg_upfir_planar_sep_f32': [c_fp, ctypes.POINTER(c_f), c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_conv1x1_thin_in_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_torgb_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],

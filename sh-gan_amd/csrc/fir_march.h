@@ -244,3 +244,150 @@ __global__ __launch_bounds__(256) void fir_down_march4_kernel(const FirMarchPara
             for (int c = lane; c < p.pitch; c += 64) pz[c] = 0.f;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pad-1 4x4 FIR after the transposed convolution (conv2d_resample.py:133-138), fused with the synthesis-layer tail
+// (stylegan.py:295-304, comodgan.py:326-327).  Input: the four phase planes mid[(a*2+b)][nc][u][v] = full[2u+a][2v+b] of the
+// (2H+1) x (2W+1) transposed-conv result, each (H+1) x (W+1) with pitch W+1; output y [NC, 2H, 2W]:
+//     y[Y][X] = act((sum_{ky,kx} b[ky] a[kx] full[Y+ky-1][X+kx-1]) * scale[nc] + noise * strength + bias[c]) + residual.
+// A lane owns 4 output columns = 2 low-resolution columns (v0 = 2c, v1 = v0+1) and marches down the low-resolution rows: per step it
+// loads row r of the four planes (dword loads: the pitch is odd), filters it horizontally into er (full row 2r) and or (row 2r+1)
+// with three DPP neighbour values each, and emits output rows 2(r-1), 2(r-1)+1 from (or[r-2], er[r-1], or[r-1], er[r], or[r]) --
+// 16-byte stores and 16-byte noise / skip loads on 128-byte aligned rows.
+struct FirUpParams {
+    const float* mid; float* y;
+    const float* scale; const float* bias; const float* noise; const float* residual;
+    int NC, C, H, W;          // low-resolution extent
+    int noise_mode;           // 0 none, 1 [2H,2W], 2 [N,2H,2W]
+    float noise_strength;
+    int act; float alpha, act_gain, clamp;
+    int R, nseg, LPG, G, nitem;
+    float a[4], b[4];
+};
+
+__device__ __forceinline__ float fm_act(float v, int act, float alpha, float gain, float clamp) {
+    if (!act) return v;
+    v = (v < 0.f ? v * alpha : v) * gain;
+    return clamp >= 0.f ? fminf(fmaxf(v, -clamp), clamp) : v;
+}
+
+template <int K, int B>
+__global__ __launch_bounds__(256) void fir_up_march_kernel(const FirUpParams p) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.nitem) return;
+    const int seg = item % p.nseg, pg = item / p.nseg;           // (handing a workgroup the same segment of four planes instead -- shared
+    const int g = lane / p.LPG, li = lane - g * p.LPG;           //  noise rows -- measures the same)
+    const int u0 = seg * p.R, u1 = min(u0 + p.R, p.H);
+    const int plane_raw = pg * p.G + g;
+    const bool lane_on = plane_raw < p.NC;
+    const int plane = lane_on ? plane_raw : 0;
+    const bool grp = K == 1 && p.LPG < 64;
+    const bool gfirst = grp && li == 0, glast = grp && li == p.LPG - 1;
+    const int PW = p.W + 1, OW = 2 * p.W, OH = 2 * p.H;
+    const long P = (long)(p.H + 1) * PW;
+    const float* mb = p.mid + (long)plane * P + 2 * li;                    // plane q adds q * NC * P
+    const long qs = (long)p.NC * P;
+    const int n = plane / p.C, ch = plane - n * p.C;
+    const float sc = p.scale ? p.scale[plane] : 1.f, bs = p.bias ? p.bias[ch] : 0.f;
+    const float* nzb = p.noise_mode == 0 ? nullptr : (p.noise_mode == 1 ? p.noise : p.noise + (long)n * OH * OW);
+    const float* rsb = p.residual ? p.residual + (long)plane * OH * OW : nullptr;
+    float* yb = p.y + (long)plane * OH * OW;
+    const float a0 = p.a[0], a1 = p.a[1], a2 = p.a[2], a3 = p.a[3];
+    const float b0 = p.b[0], b1 = p.b[1], b2 = p.b[2], b3 = p.b[3];
+
+    struct Row { float e0[2][K], e1[2][K], o0[2][K], o1[2][K], ew[2]; float4 nz[2][K], rs[2][K]; };   // [a] = row parity
+    Row in[B];
+    float4 orA[K], erB[K], orB[K];                                         // or[r-2], er[r-1], or[r-1]
+#pragma unroll
+    for (int k = 0; k < K; ++k) orA[k] = erB[k] = orB[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_step = [&](Row& d, int r) __attribute__((always_inline)) {
+        const int rc = min(max(r, 0), p.H);
+        const float* src = mb + (long)rc * PW;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float* se = src + (2 * a) * qs;
+            const float* so = se + qs;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                d.e0[a][k] = se[128 * k]; d.e1[a][k] = se[128 * k + 1];      // (an 8-byte load from the 4-byte aligned address is slower)
+                d.o0[a][k] = so[128 * k]; d.o1[a][k] = so[128 * k + 1];
+            }
+            d.ew[a] = se[p.W - 2 * li];                                   // E[W], the column past the last lane
+        }
+        // noise / skip rows of the outputs this step completes: Y = 2(r-1), 2(r-1)+1
+        const int yc = min(max(2 * (r - 1), 0), OH - 2);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const long off = (long)(yc + dy) * OW + 4 * (li + 64 * k);
+                d.nz[dy][k] = nzb ? *reinterpret_cast<const float4*>(nzb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d.rs[dy][k] = rsb ? *reinterpret_cast<const float4*>(rsb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    auto hfilt = [&](const Row& d, int a, bool ok, float4 (&h)[K]) __attribute__((always_inline)) {
+        float e0[K], e1[K], o0[K], o1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            e0[k] = ok ? d.e0[a][k] : 0.f; e1[k] = ok ? d.e1[a][k] : 0.f;
+            o0[k] = ok ? d.o0[a][k] : 0.f; o1[k] = ok ? d.o1[a][k] : 0.f;
+        }
+        const float ew = ok ? d.ew[a] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float fo = k > 0 ? fm_lane(o1[k - 1], 63) : 0.f;
+            float om1 = fm_shr1(o1[k], fo);
+            float e2 = k + 1 < K ? fm_shl1(e0[k], fm_lane(e0[k + 1], 0)) : fm_shl1(e0[k], ew);
+            float o2 = fm_shl1(o0[k], k + 1 < K ? fm_lane(o0[k + 1], 0) : 0.f);
+            om1 = gfirst ? 0.f : om1; e2 = glast ? ew : e2; o2 = glast ? 0.f : o2;
+            h[k].x = a0 * om1 + a1 * e0[k] + a2 * o0[k] + a3 * e1[k];
+            h[k].y = a0 * e0[k] + a1 * o0[k] + a2 * e1[k] + a3 * o1[k];
+            h[k].z = a0 * o0[k] + a1 * e1[k] + a2 * o1[k] + a3 * e2;
+            h[k].w = a0 * e1[k] + a1 * o1[k] + a2 * e2 + a3 * o2;
+        }
+    };
+    auto finish = [&](float v, float nz, float rs) __attribute__((always_inline)) {
+        return fm_act(v * sc + nz * p.noise_strength + bs, p.act, p.alpha, p.act_gain, p.clamp) + rs;
+    };
+    auto step = [&](const Row& d, int t) __attribute__((always_inline)) {
+        const int r = u0 - 1 + t;
+        float4 ern[K], orn[K];
+        hfilt(d, 0, r >= 0 && r <= p.H, ern);
+        hfilt(d, 1, r >= 0 && r <= p.H - 1, orn);
+        const int u = r - 1;
+        if (t >= 2 && u < u1) {                                            // uniform
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float4 y0, y1;
+                y0.x = b0 * orA[k].x + b1 * erB[k].x + b2 * orB[k].x + b3 * ern[k].x;
+                y0.y = b0 * orA[k].y + b1 * erB[k].y + b2 * orB[k].y + b3 * ern[k].y;
+                y0.z = b0 * orA[k].z + b1 * erB[k].z + b2 * orB[k].z + b3 * ern[k].z;
+                y0.w = b0 * orA[k].w + b1 * erB[k].w + b2 * orB[k].w + b3 * ern[k].w;
+                y1.x = b0 * erB[k].x + b1 * orB[k].x + b2 * ern[k].x + b3 * orn[k].x;
+                y1.y = b0 * erB[k].y + b1 * orB[k].y + b2 * ern[k].y + b3 * orn[k].y;
+                y1.z = b0 * erB[k].z + b1 * orB[k].z + b2 * ern[k].z + b3 * orn[k].z;
+                y1.w = b0 * erB[k].w + b1 * orB[k].w + b2 * ern[k].w + b3 * orn[k].w;
+                y0.x = finish(y0.x, d.nz[0][k].x, d.rs[0][k].x); y0.y = finish(y0.y, d.nz[0][k].y, d.rs[0][k].y);
+                y0.z = finish(y0.z, d.nz[0][k].z, d.rs[0][k].z); y0.w = finish(y0.w, d.nz[0][k].w, d.rs[0][k].w);
+                y1.x = finish(y1.x, d.nz[1][k].x, d.rs[1][k].x); y1.y = finish(y1.y, d.nz[1][k].y, d.rs[1][k].y);
+                y1.z = finish(y1.z, d.nz[1][k].z, d.rs[1][k].z); y1.w = finish(y1.w, d.nz[1][k].w, d.rs[1][k].w);
+                if (lane_on) {
+                    float* yr = yb + (long)(2 * u) * OW + 4 * (li + 64 * k);
+                    *reinterpret_cast<float4*>(yr) = y0;
+                    *reinterpret_cast<float4*>(yr + OW) = y1;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { orA[k] = orB[k]; erB[k] = ern[k]; orB[k] = orn[k]; }
+    };
+    const int nt = u1 - u0 + 2;
+    for (int t = 0; t < nt; t += B) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) load_step(in[j], u0 - 1 + t + j);
+#pragma unroll
+        for (int j = 0; j < B; ++j) step(in[j], t + j);
+    }
+}

@@ -575,3 +575,42 @@ extern "C" int shg_upfir_planar_f32(const float* mid, const float* f, float* y, 
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
+
+// Row-marching form of shg_upfir_planar_f32 (fir_march.h) for a SEPARABLE filter; taps_host = {fx[0..3], fy[0..3]} in HOST memory.
+extern "C" int shg_upfir_planar_sep_supported(int H, int W) {
+    if (H < 1 || W < 4 || W > 256 || W % 2) return 0;
+    return (W >= 128 ? W % 128 == 0 : 64 % (W / 2) == 0) ? 1 : 0;
+}
+
+extern "C" int shg_upfir_planar_sep_f32(const float* mid, const float* taps_host, float* y, int N, int C, int H, int W, int flip,
+                                        float gain, const float* scale, const float* bias, const float* noise, int noise_mode,
+                                        float noise_strength, int act, float alpha, float act_gain, float clamp,
+                                        const float* residual, void* stream) {
+    SHG_CHECK_ARG(mid && taps_host && y, "upfir_planar_sep: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1, "upfir_planar_sep: bad shape");
+    SHG_CHECK_ARG(shg_upfir_planar_sep_supported(H, W), "upfir_planar_sep: unsupported geometry (shg_upfir_planar_sep_supported)");
+    SHG_CHECK_ARG(4L * N * C * (H + 1) * (W + 1) <= 2147483647L && 4L * N * C * H * W <= 2147483647L, "upfir_planar_sep: tensor too large");
+    SHG_CHECK_ARG(noise_mode >= 0 && noise_mode <= 2, "upfir_planar_sep: bad noise_mode");
+    SHG_CHECK_ARG((((uintptr_t)y | (uintptr_t)residual | (uintptr_t)noise) & 15) == 0, "upfir_planar_sep: y / residual / noise must be 16-byte aligned");
+    FirUpParams p{};
+    p.mid = mid; p.y = y; p.scale = scale; p.bias = bias; p.noise = noise; p.residual = residual;
+    p.NC = N * C; p.C = C; p.H = H; p.W = W;
+    p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
+    p.act = act; p.alpha = alpha; p.act_gain = act_gain; p.clamp = clamp;
+    for (int k = 0; k < 4; ++k) {
+        p.a[k] = taps_host[flip ? k : 3 - k];
+        p.b[k] = taps_host[4 + (flip ? k : 3 - k)] * gain;
+    }
+    p.LPG = W / 2 < 64 ? W / 2 : 64; p.G = 64 / p.LPG;
+    const int npg = shg_cdiv(p.NC, p.G);
+    int nseg = shg_cdiv(8192, npg);                              // ~8k waves, at least 8 low-resolution rows each
+    if (nseg > H / 8) nseg = H / 8;
+    if (nseg < 1) nseg = 1;
+    p.R = shg_cdiv(H, nseg); p.nseg = shg_cdiv(H, p.R); p.nitem = npg * p.nseg;
+    const dim3 grid(shg_cdiv(p.nitem, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (W <= 128) hipLaunchKernelGGL((fir_up_march_kernel<1, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((fir_up_march_kernel<2, 1>), grid, dim3(256), 0, s, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

@@ -573,9 +573,16 @@ def upfir_planar(mid, f, scale=None, bias=None, noise=None, noise_strength=1.0, 
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.ShgError('upfir_planar: residual shape mismatch')
     with _timed(L, 'fir_up_planar', 4.0 * (mid.numel() + y.numel() * (2 if residual is not None else 1))):
-        check(_lib.get_lib().shg_upfir_planar_f32(_ptr(mid), _ptr(f), _ptr(y), n, c, h, w, int(bool(flip)), float(fir_gain),
-                                                  _ptr(scale), _ptr(bias), _ptr(noise), nmode, float(noise_strength), a, al, g, cl,
-                                                  _ptr(residual), L.stream()), 'upfir_planar')
+        lib = _lib.get_lib()
+        taps = sep_taps(f) if lib.shg_upfir_planar_sep_supported(h, w) else None
+        if taps is not None and all(t is None or t.data_ptr() % 16 == 0 for t in (y, noise, residual)):
+            check(lib.shg_upfir_planar_sep_f32(_ptr(mid), taps, _ptr(y), n, c, h, w, int(bool(flip)), float(fir_gain),
+                                               _ptr(scale), _ptr(bias), _ptr(noise), nmode, float(noise_strength), a, al, g, cl,
+                                               _ptr(residual), L.stream()), 'upfir_planar_sep')
+        else:
+            check(lib.shg_upfir_planar_f32(_ptr(mid), _ptr(f), _ptr(y), n, c, h, w, int(bool(flip)), float(fir_gain),
+                                           _ptr(scale), _ptr(bias), _ptr(noise), nmode, float(noise_strength), a, al, g, cl,
+                                           _ptr(residual), L.stream()), 'upfir_planar')
     return y
 
 

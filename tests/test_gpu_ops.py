@@ -344,6 +344,60 @@ def test_up_layer_planar_path_vs_oracle(mods):
         assert rel_err(c(y), ref.numpy()) < 2e-5, (n, ci, co, r)
 
 
+@pytest.mark.parametrize('n,co,h,w', [(2, 5, 256, 256), (1, 9, 128, 128), (3, 7, 64, 64), (2, 6, 32, 32), (5, 4, 16, 16), (3, 3, 8, 8),
+                                       (2, 5, 4, 4), (2, 3, 16, 64)])
+def test_upfir_march_vs_tiled_kernel_and_reference_math(mods, n, co, h, w):
+    """Row-marching FIR-from-phase-planes (csrc/fir_march.h): separable filters, every plane-width class, all tail operands and
+    subsets of them, against the tiled kernel (validated against the oracle above) and against a float64 restatement of
+    conv2d_resample.py:133-138 + stylegan.py:295-304 on the interleaved planes."""
+    kk = mods['kernels']
+    rs = np.random.RandomState(33)
+    mid = torch.from_numpy(rs.standard_normal((4, n, co, h + 1, w + 1)).astype(np.float32))
+    scale = torch.from_numpy(rs.rand(n * co).astype(np.float32) + 0.5)
+    bias = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((n, 1, 2 * h, 2 * w)).astype(np.float32))
+    res = torch.from_numpy(rs.standard_normal((n, co, 2 * h, 2 * w)).astype(np.float32))
+    assert kk._lib.get_lib().shg_upfir_planar_sep_supported(h, w) == 1
+    fsep = torch.from_numpy(np.outer([0.5, 1.5, -0.7, 0.2], [0.3, 1.0, 2.0, -0.4]).astype(np.float32))
+    f1331 = mods['orc'].setup_filter([1, 3, 3, 1])
+    # float64 reference from the interleaved (2H+1) x (2W+1) image
+    full = np.zeros((n, co, 2 * h + 4, 2 * w + 4))
+    m = mid.numpy().astype(np.float64)
+    for a in range(2):
+        for b in range(2):
+            full[:, :, 1 + a:1 + a + 2 * (h + 1 - a):2, 1 + b:1 + b + 2 * (w + 1 - b):2] = m[a * 2 + b][:, :, :h + 1 - a, :w + 1 - b]
+    for f, flip, kw in [(f1331, False, dict(scale=scale, bias=bias, noise=noise, residual=res, act=True)),
+                        (fsep, False, dict(scale=scale, bias=bias, noise=noise, residual=res, act=True)),
+                        (fsep, True, dict(scale=scale, noise=noise[0, 0], act=False)),
+                        (fsep, False, dict(bias=bias, residual=res, act=True))]:
+        args = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        y = c(kk.upfir_planar(mid.to(DEV), f.to(DEV), noise_strength=0.4, gain=0.8, flip=flip, **args))
+        kk.FIR_MARCH = False
+        try:
+            y_old = c(kk.upfir_planar(mid.to(DEV), f.to(DEV), noise_strength=0.4, gain=0.8, flip=flip, **args))
+        finally:
+            kk.FIR_MARCH = True
+        assert rel_err(y, y_old) < 2e-6
+        fk = f.numpy().astype(np.float64) * 4.0
+        fk = fk if flip else fk[::-1, ::-1]
+        v = np.zeros((n, co, 2 * h, 2 * w))
+        for ky in range(4):
+            for kx in range(4):
+                v += fk[ky, kx] * full[:, :, ky:ky + 2 * h, kx:kx + 2 * w]
+        if 'scale' in kw:
+            v = v * scale.numpy().astype(np.float64).reshape(n, co, 1, 1)
+        if 'noise' in kw:
+            nz = kw['noise'].numpy().astype(np.float64)
+            v = v + (nz if nz.ndim == 4 else nz[None, None]) * 0.4
+        if 'bias' in kw:
+            v = v + bias.numpy().astype(np.float64).reshape(1, co, 1, 1)
+        if kw['act']:
+            v = np.clip(np.where(v < 0, 0.2 * v, v) * np.sqrt(2) * 0.8, -256 * 0.8, 256 * 0.8)
+        if 'residual' in kw:
+            v = v + res.numpy().astype(np.float64)
+        assert rel_err(y, v) < 2e-6
+
+
 def test_modulated_conv2d_golden(mods):
     gd = load_golden('modulated_conv2d')
     f4 = g(gd['f'])

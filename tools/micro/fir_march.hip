@@ -34,6 +34,89 @@ static void launch_down(FirMarchParams p, hipStream_t s) {
     else { printf("unsupported W\n"); exit(1); }
 }
 
+
+static void launch_up(FirUpParams p, hipStream_t s) {
+    const int K = (p.W + 127) / 128;
+    p.LPG = p.W / 2 < 64 ? p.W / 2 : 64; p.G = 64 / p.LPG;
+    const int npg = (p.NC + p.G - 1) / p.G;
+    int nseg = (8192 + npg - 1) / npg; if (nseg > p.H / 8) nseg = p.H / 8; if (nseg < 1) nseg = 1;
+    if (getenv("NSEG")) nseg = atoi(getenv("NSEG"));
+    p.R = (p.H + nseg - 1) / nseg; p.nseg = (p.H + p.R - 1) / p.R; p.nitem = npg * p.nseg;
+    dim3 grid((p.nitem + 3) / 4);
+    const int bb = getenv("UB") ? atoi(getenv("UB")) : 0;
+    if (K == 1) { if (bb == 1) hipLaunchKernelGGL((fir_up_march_kernel<1, 1>), grid, dim3(256), 0, s, p);
+                  else if (bb == 4) hipLaunchKernelGGL((fir_up_march_kernel<1, 4>), grid, dim3(256), 0, s, p);
+                  else hipLaunchKernelGGL((fir_up_march_kernel<1, 2>), grid, dim3(256), 0, s, p); }
+    else if (K == 2) { if (bb == 1) hipLaunchKernelGGL((fir_up_march_kernel<2, 1>), grid, dim3(256), 0, s, p);
+                  else hipLaunchKernelGGL((fir_up_march_kernel<2, 2>), grid, dim3(256), 0, s, p); }
+    else { printf("unsupported W\n"); exit(1); }
+}
+
+static void up_cases() {
+    const float t[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    struct Case { int N, C, H; } cases[] = {{16, 64, 256}, {16, 128, 128}, {16, 256, 64}, {16, 512, 32}, {16, 512, 16}, {16, 512, 8}, {3, 5, 4}, {2, 3, 64}};
+    for (auto cs : cases) {
+        const int N = cs.N, C = cs.C, NC = N * C, H = cs.H, W = cs.H, OH = 2 * H, OW = 2 * W, PW = W + 1;
+        const size_t nm = (size_t)4 * NC * (H + 1) * PW, ny = (size_t)NC * OH * OW, nn = (size_t)N * OH * OW;
+        std::vector<float> hm(nm), hr(ny), hn(nn), hs(NC), hb(C);
+        unsigned s = 777u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+        for (auto& v : hm) v = rnd();
+        for (auto& v : hr) v = rnd();
+        for (auto& v : hn) v = rnd();
+        for (auto& v : hs) v = 1.f + rnd();
+        for (auto& v : hb) v = rnd();
+        float *dm, *dr, *dn, *ds, *db, *dy;
+        CK(hipMalloc(&dm, nm * 4)); CK(hipMalloc(&dr, ny * 4)); CK(hipMalloc(&dn, nn * 4)); CK(hipMalloc(&ds, NC * 4)); CK(hipMalloc(&db, C * 4));
+        CK(hipMalloc(&dy, ny * 4));
+        CK(hipMemcpy(dm, hm.data(), nm * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dr, hr.data(), ny * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dn, hn.data(), nn * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, hs.data(), NC * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), C * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(dy, 0xff, ny * 4));
+        FirUpParams p{};
+        p.mid = dm; p.y = dy; p.scale = ds; p.bias = db; p.noise = dn; p.residual = dr; p.NC = NC; p.C = C; p.H = H; p.W = W;
+        p.noise_mode = 2; p.noise_strength = 0.3f; p.act = 1; p.alpha = 0.2f; p.act_gain = 1.41421356f; p.clamp = 0.6f;
+        for (int k = 0; k < 4; ++k) { p.a[k] = t[k] * (1.f + 0.1f * k); p.b[k] = t[k] * (1.f - 0.05f * k); }
+        launch_up(p, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<float> hy(ny);
+        CK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));
+        double maxerr = 0; long bad = 0;
+        const int planes[4] = {0, 1, NC / 2, NC - 1};
+        for (int pi = 0; pi < 4; ++pi) {
+            const int nc = planes[pi], n = nc / C, c = nc % C;
+            auto full = [&](int Y, int X) -> double {
+                if (Y < 0 || Y > 2 * H || X < 0 || X > 2 * W) return 0.0;
+                return hm[(((size_t)((Y & 1) * 2 + (X & 1)) * NC + nc) * (H + 1) + (Y >> 1)) * PW + (X >> 1)];
+            };
+            for (int Y = 0; Y < OH; ++Y)
+                for (int X = 0; X < OW; ++X) {
+                    double v = 0;
+                    for (int ky = 0; ky < 4; ++ky)
+                        for (int kx = 0; kx < 4; ++kx) v += (double)p.b[ky] * p.a[kx] * full(Y + ky - 1, X + kx - 1);
+                    v = v * hs[nc] + hn[((size_t)n * OH + Y) * OW + X] * p.noise_strength + hb[c];
+                    v = (v < 0 ? v * p.alpha : v) * p.act_gain;
+                    v = fmin(fmax(v, -(double)p.clamp), (double)p.clamp);
+                    v += hr[((size_t)nc * OH + Y) * OW + X];
+                    const double e = fabs(hy[((size_t)nc * OH + Y) * OW + X] - v);
+                    if (!(e <= 2e-5)) ++bad;
+                    if (e > maxerr || e != e) maxerr = e;
+                }
+        }
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int it = 20;
+        launch_up(p, 0);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < it; ++i) launch_up(p, 0);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000 / it, bytes = 4.0 * ((double)nm + 2.0 * ny);
+        printf("up NC=%5d %3d^2->%3d^2: %8.1f us  %5.2f TB/s  maxerr %.2e bad %ld\n", NC, H, OH, us, bytes / us / 1e6, maxerr, bad);
+        CK(hipFree(dm)); CK(hipFree(dr)); CK(hipFree(dn)); CK(hipFree(ds)); CK(hipFree(db)); CK(hipFree(dy));
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const float4* x, float4* y, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) { float4 v = x[i]; v.x *= 2.f; y[i] = v; }
@@ -54,7 +137,8 @@ __global__ __launch_bounds__(256) void wpat_kernel(char* y, int rows, long pitch
         else *reinterpret_cast<float*>(d) = (float)r;
     }
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'u') { up_cases(); return 0; }
     {
         const long nw = 16384; const int rows = 64;
         char* y; CK(hipMalloc(&y, nw * rows * 1152 + 4096));
