@@ -226,6 +226,102 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* x, const float*
     }
 }
 
+// The same for W % 4 == 0 and 16-byte aligned tensors: one lane per FOUR horizontally adjacent pixels (16-byte loads, 8 channels =
+// 8 KB per wave in flight, 16-byte stores); the modulated weights w[o,i]*styles[n,i] sit at wave-uniform addresses in LDS.
+// S channel slices per pixel group for small images, summed through LDS like above.  O <= 3.
+__global__ __launch_bounds__(256) void torgb4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ styles, const float* __restrict__ bias,
+                                                     const float* __restrict__ base_up, const float* __restrict__ f,
+                                                     float* __restrict__ y, int I, int O, int H, int W, int S) {
+    extern __shared__ float ws[];   // [3][I] + [S-1][256/S][12] partial sums
+    const int n = blockIdx.z;
+    for (int k = threadIdx.x; k < 3 * I; k += 256) {
+        const int i = k % I;
+        ws[k] = k < O * I ? w[k] * (styles ? styles[(long)n * I + i] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    const int HW = H * W, Q = HW >> 2;               // pixel quads per plane
+    const int QPB = 256 / S;
+    const int ql = threadIdx.x % QPB, slice = threadIdx.x / QPB;
+    const int quad = blockIdx.x * QPB + ql;
+    const bool inside = quad < Q;
+    float4 acc[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int per = ((I + S - 1) / S + 7) & ~7;
+    const int i_lo = slice * per, i_hi = min(I, i_lo + per);
+    const float4* xp = reinterpret_cast<const float4*>(x + (long)n * I * HW) + (inside ? quad : 0);
+    int i = i_lo;
+    for (; i + 8 <= i_hi; i += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = xp[(long)(i + k) * Q];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float c = ws[o * I + i + k];
+                acc[o].x += c * v[k].x; acc[o].y += c * v[k].y; acc[o].z += c * v[k].z; acc[o].w += c * v[k].w;
+            }
+    }
+    for (; i < i_hi; ++i) {
+        const float4 v = xp[(long)i * Q];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float c = ws[o * I + i];
+            acc[o].x += c * v.x; acc[o].y += c * v.y; acc[o].z += c * v.z; acc[o].w += c * v.w;
+        }
+    }
+    if (S > 1) {
+        float4* red = reinterpret_cast<float4*>(ws + 3 * I + ((3 * I) & 3 ? 4 - ((3 * I) & 3) : 0));   // [S-1][QPB][3]
+        if (slice > 0) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) red[((slice - 1) * QPB + ql) * 3 + o] = acc[o];
+        }
+        __syncthreads();
+        if (slice > 0) return;
+        for (int sl = 0; sl < S - 1; ++sl)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float4 r = red[(sl * QPB + ql) * 3 + o];
+                acc[o].x += r.x; acc[o].y += r.y; acc[o].z += r.z; acc[o].w += r.w;
+            }
+    }
+    if (!inside) return;
+    const int pix = quad * 4, oy = pix / W, ox = pix - oy * W;
+    for (int o = 0; o < O; ++o) {
+        const float b = bias ? bias[o] : 0.f;
+        float out[4] = {acc[o].x + b, acc[o].y + b, acc[o].z + b, acc[o].w + b};
+        if (base_up) {
+            // upsample2d(up=2, 4x4 filter, pad [2,1,2,1], gain 4): u = oy + ky - 2 must be even, iy = u/2 (same order of the
+            // additions as torgb_kernel)
+            const int h2 = H >> 1, w2 = W >> 1;
+            const float* bp = base_up + ((long)n * O + o) * h2 * w2;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                float u = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const int uy = oy + ky - 2;
+                    if (uy < 0 || (uy & 1)) continue;
+                    const int iy = uy >> 1;
+                    if (iy >= h2) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int ux = ox + dx + kx - 2;
+                        if (ux < 0 || (ux & 1)) continue;
+                        const int ix = ux >> 1;
+                        if (ix >= w2) continue;
+                        u += bp[iy * w2 + ix] * (f[(3 - ky) * 4 + (3 - kx)] * 4.f);
+                    }
+                }
+                out[dx] += u;
+            }
+        }
+        *reinterpret_cast<float4*>(y + ((long)n * O + o) * HW + pix) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 // y[n,o] = sum_i w[o,i]*styles[n,i]*x[n,i] + bias[o] (+ upsample2d(base_up, f)); O <= 4.
 extern "C" int shg_torgb_f32(const float* x, const float* w, const float* styles, const float* bias, const float* base_up,
                              const float* f, float* y, int N, int I, int O, int H, int W, void* stream) {
@@ -235,6 +331,21 @@ extern "C" int shg_torgb_f32(const float* x, const float* w, const float* styles
     SHG_CHECK_ARG(N >= 1 && N <= 65535, "torgb: bad N");
     SHG_CHECK_ARG((size_t)4 * I * 4 + 4096 <= 64 * 1024, "torgb: I too large");
     // channel slices per pixel: enough to put >= ~64k threads on the chip (small images are otherwise one long serial chain)
+    // (measured at N = 16: 512^2 x 64ch 236 vs 257 us, 64^2 x 512ch 38 vs 63 us; in between -- 128^2 x 256ch -- the pixel-per-lane
+    //  kernel's 16 waves per CU win, 59 vs 65 us)
+    const long nquad = (long)N * (H * W / 4);
+    if (O <= 3 && W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (nquad >= 262144 || nquad <= 16384)) {
+        // quad kernel: channel slices until ~256k lanes are busy, at least 8 channels per slice and 16 quads per row piece
+        int S4 = 1;
+        while (S4 < 16 && (long)N * (H * W / 4) * S4 < 262144 && I / (S4 * 2) >= 8) S4 *= 2;
+        const size_t lds = sizeof(float) * (((3 * I + 3) & ~3) + (size_t)(S4 - 1) * (256 / S4) * 12);
+        if (lds <= 64 * 1024) {
+            dim3 g4(shg_cdiv(H * W / 4, 256 / S4), 1, N);
+            hipLaunchKernelGGL(torgb4_kernel, g4, dim3(256), lds, (hipStream_t)stream, x, w, styles, bias, base_up, f, y, I, O, H, W, S4);
+            SHG_CHECK_LAUNCH();
+            return SHG_OK;
+        }
+    }
     int S = 1;
     while (S < 16 && (long)N * H * W * S < 65536 && I / (S * 2) >= 8) S *= 2;
     dim3 grid(shg_cdiv(H * W, 256 / S), 1, N);
