@@ -79,6 +79,7 @@ static void up_cases() {
         for (int k = 0; k < 4; ++k) { p.a[k] = t[k] * (1.f + 0.1f * k); p.b[k] = t[k] * (1.f - 0.05f * k); }
         launch_up(p, 0);
         CK(hipDeviceSynchronize());
+        const int du = getenv("DBGU") ? atoi(getenv("DBGU")) : 0;
         std::vector<float> hy(ny);
         CK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));
         double maxerr = 0; long bad = 0;
@@ -105,6 +106,8 @@ static void up_cases() {
         }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int it = 20;
+        if (du & 1) { p.noise = nullptr; p.noise_mode = 0; }
+        if (du & 2) p.residual = nullptr;
         launch_up(p, 0);
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < it; ++i) launch_up(p, 0);
