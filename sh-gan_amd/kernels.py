@@ -531,9 +531,10 @@ def fir_conv_down2(x, f, pw, bias=None, act=False, gain=1.0, alpha=0.2, act_gain
     n, i, h, w = x.shape
     oh, ow = h // 2, w // 2
     lib = _lib.get_lib()
-    taps = sep_taps(f) if lib.shg_fir_pad2_sep_supported(h, w, 4) else None
     # plane pitch: whole 128-byte lines per row for the wide planes of the marching FIR (its stores want that), else 16 bytes
-    pp = (ow + 1 + 31) // 32 * 32 if (taps is not None and w % 256 == 0) else (ow + 1 + 3) // 4 * 4
+    pp4 = (ow + 1 + 3) // 4 * 4
+    taps = sep_taps(f) if lib.shg_fir_pad2_sep_supported(h, w, pp4) else None
+    pp = (ow + 1 + 31) // 32 * 32 if (taps is not None and w % 256 == 0) else pp4
     wa, wb = pw.down_poly()
     L.view(wa, 'weights')
     xp = L.new((4, n, i, oh + 1, pp))

@@ -105,7 +105,8 @@ def test_fir_march_pad2_vs_oracle_and_tiled_kernel(mods, shape):
             finally:
                 K.FIR_MARCH = True
             assert rel_err(y, y_old) < 1e-6
-            if lib.shg_fir_pad2_sep_supported(h, w, 4):
+            if h % 2 == 0 and w % 2 == 0:
+                assert lib.shg_fir_pad2_sep_supported(h, w, (w // 2 + 1 + 3) // 4 * 4) == 1
                 for pp in ((w // 2 + 1 + 3) // 4 * 4, (w // 2 + 1 + 31) // 32 * 32):
                     xp = torch.full((4, n, ch, h // 2 + 1, pp), float('nan'), device=DEV)
                     K.check(lib.shg_fir_pad2_sep_f32(K._ptr(x.to(DEV)), K.sep_taps(fd), K._ptr(xp), n, ch, h, w, pp, int(flip), 1.5,
