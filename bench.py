@@ -13,6 +13,11 @@ loop) + the uint8 composite.  Weights: the reference's random initialisers, seed
 (shgan_amd.configs.seeded_init_); data: synthetic.  Multi-GPU = batch sharding, one process per GPU, no collective on
 the data path (weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
 
+The K timed steps are K independent batches, as in the evaluation loop of the product (eval_harness.sharded_eval): they are issued
+round-robin on --pipeline-depth HIP streams (default 3; eval_harness.StreamPipeline), so that the few microseconds every one of the
+~150 launch boundaries of a forward pass idles the chip are filled by the next batch's kernels.  ms_per_step = wall time / K;
+the time of one batch alone on one stream is reported as pipeline.ms_per_step_single_stream (--pipeline-depth 1 makes it the headline).
+
 The headline loop runs WITHOUT instrumentation.  A second, untimed pass then brackets every kernel launch with HIP
 events on the launch stream (kernels.KernelTimer) and rank 0 prints ONE JSON line with
   roofline      the dominant kernel (conv_wino4_kernel, Winograd F(4x4,3x3)): flops the matrix cores EXECUTE (36 multiplies per
@@ -93,14 +98,16 @@ def cpu_baseline(resolution, bench_batch, n_images, forwards, noise_mode, seed):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--resolution', type=int, default=512)
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 16 @512, 32 @256)')
     ap.add_argument('--noise-mode', default='random')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--cpu-forwards', type=int, default=3)
+    ap.add_argument('--pipeline-depth', type=int, default=None,
+                    help='HIP streams the consecutive (independent) batches are issued on round-robin; 1 = one stream')
     ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
     return ap.parse_args()
 
@@ -163,13 +170,18 @@ def worker(local_rank, a, spawned_world=None, port=None):
     def step():
         return eval_harness.run_generator(G, x, z, noise_mode=a.noise_mode)
 
+    if a.pipeline_depth is None:
+        a.pipeline_depth = eval_harness.PIPELINE_DEPTH
+    pipe = eval_harness.StreamPipeline(dev, depth=a.pipeline_depth)
     for _ in range(a.warmup):
-        step()
+        pipe.run(step)
+    pipe.join()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
+        out = pipe.run(step)
+    pipe.join()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -178,6 +190,16 @@ def worker(local_rank, a, spawned_world=None, port=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
+    # one batch alone on one stream (latency of a step; not the headline)
+    lat_ms = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        lat_ms = (time.perf_counter() - t1) / 3 * 1e3
+    barrier()
 
     # ---- second pass (not part of the headline): per-kernel-class HIP-event times
     tsum = {}
@@ -255,7 +277,13 @@ def worker(local_rank, a, spawned_world=None, port=None):
                        'resolution': res, 'batch_per_gpu': batch, 'global_batch': batch * world, 'noise_mode': a.noise_mode,
                        'parallelism': f'batch-shard x{world}', 'launcher': 'self-spawn' if spawned_world else
                        ('torch.distributed.run' if 'RANK' in os.environ and spawned_world is None and use_dist else 'single process'),
-                       'collective_backend': backend, 'ranks_share_devices': oversub},
+                       'collective_backend': backend, 'ranks_share_devices': oversub,
+                       'stream_pipeline_depth': a.pipeline_depth},
+            'pipeline': {'depth': a.pipeline_depth, 'ms_per_step_single_stream': round(lat_ms, 3) if lat_ms else None,
+                         'note': 'the K timed steps are independent batches issued round-robin on `depth` HIP streams '
+                                 '(eval_harness.StreamPipeline, the evaluation loop of the product): the launch-boundary gaps of '
+                                 'one batch are filled by the kernels of the next; ms_per_step = wall time / K (throughput), '
+                                 'ms_per_step_single_stream = one batch alone (latency)'},
             'timing': 'headline loop uninstrumented; roofline/hbm from a separate instrumented pass of '
                       f'{psteps} steps (HIP events on the launch stream)',
             'roofline': roof,

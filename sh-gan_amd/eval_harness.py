@@ -76,8 +76,52 @@ def shard_ids(n_items, rank, world):
     return list(iter(DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)))
 
 
+PIPELINE_DEPTH = 3      # streams of the evaluation loop (1 = plain loop); 2: +6.5 %, 3: +8.5 %, 4-6: no further gain at 512x16
+
+
+class StreamPipeline:
+    """Round-robin HIP streams for an evaluation loop.  Consecutive batches are independent, and a forward pass is ~150 kernel
+    launches back to back on one stream: every launch boundary idles the chip for a few microseconds (the last workgroups of a
+    kernel drain, the next kernel's first ones ramp up).  With batch k+1 queued on a second stream the other batch's kernels
+    fill those gaps -- 759 -> 807 (two streams) -> 824 images/s (three) at 512x16 on one MI355X.  ``depth`` = 1 is the plain loop.
+
+        pipe = StreamPipeline(device, depth=2)
+        for x, z in batches: outs.append(pipe.run(step_fn, x, z))
+        pipe.join()                      # before anything reads ``outs`` on the current stream"""
+
+    def __init__(self, device, depth=None):
+        depth = PIPELINE_DEPTH if depth is None else depth
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)] if (depth > 1 and self.device.type == 'cuda') else []
+        self.k = 0
+        self.outs = []
+
+    def run(self, fn, *args):
+        if not self.streams:
+            return fn(*args)
+        s = self.streams[self.k % len(self.streams)]
+        self.k += 1
+        s.wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
+        with torch.cuda.stream(s):
+            out = fn(*args)
+        for t in args:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(s)
+        self.outs.append(out)
+        return out
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device) if self.streams else None
+        for s in self.streams:
+            cur.wait_stream(s)
+        for o in self.outs:
+            if torch.is_tensor(o) and o.is_cuda:
+                o.record_stream(cur)
+        self.outs = []
+
+
 def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, gather=True, device='cuda',
-                 noise_mode='const', step_fn=None, z_dim=None):
+                 noise_mode='const', step_fn=None, z_dim=None, pipeline_depth=None):
     """Batch-sharded evaluation over a synthetic dataset of ``n_items`` images (BASELINE config 4): rank r processes
     the sample ids ``shard_ids`` gives it, in batches of ``batch_size`` built on the device; with ``gather`` the uint8
     outputs are all-gathered (one ``all_gather_into_tensor`` per run: RCCL on GPUs, gloo on CPU tensors) and
@@ -95,9 +139,11 @@ def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, ga
         torch.manual_seed(seed * world + rank)
     ids = shard_ids(n_items, rank, world)
     outs = []
+    pipe = StreamPipeline(device, depth=pipeline_depth)
     for b0 in range(0, len(ids), batch_size):
         x, z, _, _ = synthetic_items(ids[b0:b0 + batch_size], resolution, z_dim, seed=seed, device=device)
-        outs.append(step_fn(x, z))
+        outs.append(pipe.run(step_fn, x, z))
+    pipe.join()
     local = torch.cat(outs)
     if not gather or (world == 1 and not (dist.is_available() and dist.is_initialized())):
         return ids, local          # (a 1-rank process group still goes through the collective: same code path as N ranks)

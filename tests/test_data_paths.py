@@ -176,3 +176,14 @@ print("rank", r, "ok")
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_stream_pipeline_is_a_plain_loop_without_a_gpu():
+    import torch
+    from shgan_amd import eval_harness as hz
+    pipe = hz.StreamPipeline('cpu')
+    assert pipe.streams == []
+    outs = [pipe.run(lambda a, b: a + b, torch.full((3,), float(k)), torch.ones(3)) for k in range(4)]
+    pipe.join()
+    assert [float(o[0]) for o in outs] == [1.0, 2.0, 3.0, 4.0]
+    assert hz.PIPELINE_DEPTH >= 1

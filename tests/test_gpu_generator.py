@@ -158,3 +158,22 @@ def test_sharded_eval_matches_unsharded(env):
     # per-item inputs are identical; batch composition differs -> +-1 LSB at most (batch-global style norm, 8e)
     d = np.abs(merged.astype(np.int32) - c(out1).astype(np.int32))
     assert d.max() <= 1
+
+
+def test_stream_pipeline_matches_plain_loop_bit_exact(env):
+    """The evaluation loop issues consecutive batches round-robin on several HIP streams (eval_harness.StreamPipeline): same
+    bytes as the one-stream loop, for every depth, with the batches' inputs built on the caller's stream in between."""
+    orc, hz = env['orc'], env['harness']
+    sd = orc.init_state_dict(256, seed=52, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = make_G(env, 256, sd, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    ref_ids, ref = hz.sharded_eval(G, 13, 3, 256, seed=4, gather=False, device=DEV, pipeline_depth=1)
+    for depth in (2, 3, 5):
+        ids, out = hz.sharded_eval(G, 13, 3, 256, seed=4, gather=False, device=DEV, pipeline_depth=depth)
+        assert ids == ref_ids
+        assert torch.equal(out, ref), depth
+    # the helper itself: results of every run() are valid after join(), whatever the stream they were computed on
+    pipe = hz.StreamPipeline(DEV, depth=3)
+    xs = [torch.full((1 << 20,), float(k), device=DEV) for k in range(7)]
+    outs = [pipe.run(lambda t: (t * 2 + 1).cumsum(0)[-1:], x) for x in xs]
+    pipe.join()
+    assert [float(o) for o in outs] == [float((2 * k + 1) * (1 << 20)) for k in range(7)]
