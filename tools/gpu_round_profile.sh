@@ -5,14 +5,23 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline > $OUT/prof_stdout.log 2>&1 )
+# (bench runs warmup + steps + 3 single-stream latency steps = 10 forward passes here: the divisor of prof_summary.py)
+# kernel durations: one batch at a time on one stream (what bench.py's roofline block times with HIP events), then the same command
+# with the default three-stream pipeline (kernels of different batches overlap: longer individual durations, shorter wall time)
+for MODE in single pipelined; do
+  D=1; [ $MODE = pipelined ] && D=3
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --no-cpu-baseline > $OUT/prof_stdout_$MODE.log 2>&1 )
+  cd $GRAFT_REPO_ROOT
+  F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+  SUF=""; [ $MODE = pipelined ] && SUF="_pipelined"
+  cp "$F" $OUT/${TAG}_bench512x16${SUF}_kernel_stats.csv
+  python tools/prof_summary.py "$F" 10 > $OUT/${TAG}_summary${SUF}.txt
+  rm -rf $OUT/prof
+  cd /tmp
+done
 cd $GRAFT_REPO_ROOT
-F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
-cp "$F" $OUT/${TAG}_bench512x16_kernel_stats.csv
-python tools/prof_summary.py "$F" 7 > $OUT/${TAG}_summary.txt
-rm -rf $OUT/prof
-python bench.py --steps 20 --warmup 3 ${BENCH_ARGS} > $OUT/${TAG}_bench512x16.json.log 2> $OUT/bench512.err
-python bench.py --steps 20 --warmup 3 --resolution 256 --no-cpu-baseline > $OUT/${TAG}_bench256x32.json.log 2> $OUT/bench256.err
+python bench.py --steps 40 --warmup 6 ${BENCH_ARGS} > $OUT/${TAG}_bench512x16.json.log 2> $OUT/bench512.err
+python bench.py --steps 40 --warmup 6 --resolution 256 --no-cpu-baseline > $OUT/${TAG}_bench256x32.json.log 2> $OUT/bench256.err
 python tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>/dev/null
 python tools/conv_bench_down.py > $OUT/${TAG}_conv_bench_down.txt 2>/dev/null
 python tools/fir_bench.py > $OUT/${TAG}_fir_bench.txt 2>/dev/null
