@@ -30,13 +30,12 @@ struct WgradParams {
 };
 
 template <int KH, int KW, int S>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, XW = PX * S + KW - 1, CP = 65;    // CP: channel pitch (odd)
-    constexpr int NXE = 64 * KH * XW, NX = (NXE + 255) / 256;   // elements of the x window, per thread
     __shared__ float Gs[PX * CP];                                // [pixel][o]
     __shared__ float Xs[KH * XW * CP];                           // [row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int mo = wave >> 1, nt = wave & 1;
+    const int grp = wave >> 2, mo = (wave >> 1) & 1, nt = wave & 1;   // grp: the two k-step groups (two waves per SIMD)
     const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, slice = blockIdx.z;
     const int per = (p.nchunk + p.nslice - 1) / p.nslice;
     const int c_begin = slice * per, c_end = min(p.nchunk, c_begin + per);
@@ -48,38 +47,71 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
     const long gplane = (long)p.OH * p.OW, xplane = (long)p.H * p.W;
     // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before the MFMAs of chunk c and
     // written to LDS after them, so their latency is covered by ~20 k cycles of matrix work instead of standing in front of it.
-    constexpr int NG = PX * 64 / 256;                            // g elements per thread
-    float rg[NG], rx[NX];
-    const int gpx = tid % PX, gog = tid / PX;                    // g: pixel, first channel
+    // The window is staged LINE by line: a line = (channel, window row) = 64 columns, one per lane; wave w takes lines w, w+8, ...
+    // -- the channel / row / image-row arithmetic of a line is wave-uniform (scalar unit) and the vector unit is left with one
+    // address add and one select per element.  The KW-1 halo columns of all lines follow, one lane per element.
+    // (Tried and slower: keeping the loaded values raw and masking them when they are written to LDS, 68 vs 77 TFLOP/s at
+    // 512 channels; an explicit LDS-operand prefetch in the MFMA loop, 64.)
+    constexpr int NLINE = 64 * KH, LPW = NLINE / 8;             // x lines, per wave
+    constexpr int HC = XW - 64;                                  // halo columns of a line (KW - 1)
+    constexpr int NHE = NLINE * HC, NHT = (NHE + 511) / 512;     // halo elements, per thread
+    constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (a 64-lane instruction = 64 / PX lines)
+    static_assert(PX * S == 64, "a window line is 64 columns + halo");
+    float rg[GL], rx[LPW + (NHT ? NHT : 1)];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int cx = c % p.chunks_x, oy = (c / p.chunks_x) % p.OH, n = c / (p.chunks_x * p.OH);
         const int ox0 = cx * PX;
         {
+            const int gpx = lane % PX, gsub = lane / PX;         // pixel, line within the instruction
             const bool pok = ox0 + gpx < p.OW;
-            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0 + gpx;
+            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0 + (pok ? gpx : 0);
 #pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const int o = gog + j * (256 / PX);
-                rg[j] = (pok && o0 + o < p.O) ? gp[(long)o * gplane] : 0.f;
+            for (int j = 0; j < GL; ++j) {
+                const int o = (wv + 8 * j) * (64 / PX) + gsub;
+                const bool ok = pok && o0 + o < p.O;
+                const float v = gp[ok ? (long)o * gplane : 0];
+                rg[j] = ok ? v : 0.f;
             }
         }
+        const int ixl = ox0 * S - p.pad + lane;
+        const bool cok = ixl >= 0 && ixl < p.W;
+        const float* xn = p.x + ((long)n * p.I + i0) * xplane;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {                           // element e = (channel * KH + row) * XW + column: lanes walk along rows
-            const int e = tid + 256 * j;
-            const int q = e / XW, col = e - q * XW, i = q / KH, r = q - i * KH;
-            const int iy = oy * S - p.pad + r, ix = ox0 * S - p.pad + col;
-            const bool ok = e < NXE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + i < p.I;
-            rx[j] = ok ? p.x[((long)n * p.I + i0 + i) * xplane + (long)iy * p.W + ix] : 0.f;
+        for (int j = 0; j < LPW; ++j) {
+            const int L = wv + 8 * j, i = L / KH, r = L - i * KH;        // uniform
+            const int iy = oy * S - p.pad + r;
+            const bool rok = iy >= 0 && iy < p.H && i0 + i < p.I;       // uniform
+            const bool ok = rok && cok;
+            const float v = xn[ok ? (long)i * xplane + (long)iy * p.W + ixl : 0];
+            rx[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NHT; ++t) {
+            const int e = tid + 512 * t;
+            const int L = e / (HC ? HC : 1), hc = 64 + e - L * (HC ? HC : 1), i = L / KH, r = L - i * KH;
+            const int iy = oy * S - p.pad + r, ix = ox0 * S - p.pad + hc;
+            const bool ok = e < NHE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + i < p.I;
+            const float v = xn[ok ? (long)i * xplane + (long)iy * p.W + ix : 0];
+            rx[LPW + t] = ok ? v : 0.f;
         }
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
+        {
+            const int gpx = lane % PX, gsub = lane / PX;
 #pragma unroll
-        for (int j = 0; j < NG; ++j) Gs[gpx * CP + gog + j * (256 / PX)] = rg[j];
+            for (int j = 0; j < GL; ++j) Gs[gpx * CP + (wv + 8 * j) * (64 / PX) + gsub] = rg[j];
+        }
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int e = tid + 256 * j;
-            const int q = e / XW, col = e - q * XW, i = q / KH, r = q - i * KH;
-            if (e < NXE) Xs[(r * XW + col) * CP + i] = rx[j];
+        for (int j = 0; j < LPW; ++j) {
+            const int L = wv + 8 * j, i = L / KH, r = L - i * KH;
+            Xs[(r * XW + lane) * CP + i] = rx[j];
+        }
+#pragma unroll
+        for (int t = 0; t < NHT; ++t) {
+            const int e = tid + 512 * t;
+            const int L = e / (HC ? HC : 1), hc = 64 + e - L * (HC ? HC : 1), i = L / KH, r = L - i * KH;
+            if (e < NHE) Xs[(r * XW + hc) * CP + i] = rx[LPW + t];
         }
     };
     if (c_begin < c_end) load_chunk(c_begin);
@@ -89,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);
 #pragma unroll 2
-        for (int ks = 0; ks < PX / 2; ++ks) {
+        for (int ks = grp; ks < PX / 2; ks += 2) {               // the two wave groups take alternate k-steps
             const int k = 2 * ks + half;                         // pixel of this lane's operand row
             const float a = Gs[k * CP + mo * 32 + l31];
 #pragma unroll
@@ -97,6 +129,28 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[((t / KW) * XW + k * S + (t % KW)) * CP + nt * 32 + l31], acc[t], 0, 0, 0);
         }
     }
+    // the second wave group hands its partial sums to the first through LDS (three taps at a time: 48 KB over the window buffer)
+    float* red = Xs;
+    static_assert(sizeof(Xs) >= sizeof(float) * 4 * (TAPS < 3 ? TAPS : 3) * 1024, "reduction buffer");
+    constexpr int TB = TAPS < 3 ? TAPS : 3;
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TB) {
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane] = acc[t0 + tt][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t0 + tt][r] += red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane];
+        }
+    }
+    if (grp == 1) return;
     float* dst = p.out + (p.nslice > 1 ? (long)slice * p.O * p.I * TAPS : 0);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -153,10 +207,10 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     p.out = p.nslice > 1 ? (float*)workspace : dw;
     const dim3 grid(shg_cdiv(I, 64), shg_cdiv(O, 64), p.nslice);
     hipStream_t s = (hipStream_t)stream;
-    if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(256), 0, s, p);
-    else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(256), 0, s, p);
-    else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2>), grid, dim3(256), 0, s, p);
+    if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
+    else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
+    else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2>), grid, dim3(512), 0, s, p);
     SHG_CHECK_LAUNCH();
     if (p.nslice > 1) {
         const long n = (long)O * I * kh * kw;
