@@ -99,6 +99,13 @@ class StreamPipeline:
     def run(self, fn, *args):
         if not self.streams:
             return fn(*args)
+        if self.k == 0:
+            # the first batch runs on the caller's stream: it builds the per-parameter caches (prepared weight layouts, separable
+            # filter taps, ...) in stream order; every later batch waits for the caller's stream before it starts, i.e. for them
+            self.k = 1
+            out = fn(*args)
+            self.outs.append(out)
+            return out
         s = self.streams[self.k % len(self.streams)]
         self.k += 1
         s.wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
