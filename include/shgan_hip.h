@@ -57,6 +57,11 @@ int shg_bias_act_backward_f32(const float* g, const float* y, float* dx, long to
 int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long total, void* stream);
 /* stylegan.py:173 -- y[nc,:] = x[nc,:] * s[nc]. */
 int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int HW, void* stream);
+/* Phase planes of a stride-2 transposed convolution (shg_conv2d_f32 mode 2 / out_mode 1, shg_conv2d_up_poly_f32) -> image with the
+ * crop / zero-extension conv2d_gradfix.py:96-128 applies: y[n,c,Y,X] = full[Y+lo][X+lo] (+ bias[c]), zero outside the
+ * (2H+1) x (2W+1) result.  N*C <= 65535. */
+int shg_planes_to_image_f32(const float* mid, const float* bias, float* y, int N, int C, int H, int W, int lo, int OH, int OW,
+                            void* stream);
 
 /* ---- A9/A8: convolution on the fp32 MFMA units -- replaces F.conv2d / F.conv_transpose2d reached through
  * conv2d_gradfix.py:35-43,109-116 from conv2d_resample.py:26-51.

@@ -356,6 +356,37 @@ extern "C" int shg_torgb_f32(const float* x, const float* w, const float* styles
 }
 
 // ---------------------------------------------------------------------------------------------
+// Phase planes of the transposed convolution -> image: y[nc][Y][X] = full[Y + lo][X + lo] (+ bias[c]), where
+// full[Yf][Xf] = mid[(Yf&1)*2 + (Xf&1)][nc][Yf>>1][Xf>>1] is the (2H+1) x (2W+1) result of conv_transpose2d(stride 2) and positions
+// outside it read as zero -- the crop / zero-extension `conv2d_gradfix` applies around a transposed convolution
+// (`padding`, and the output_padding rule of conv2d_gradfix.py:96-105), fused with the interleave of the planes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void planes_to_image_kernel(const float* __restrict__ mid, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int NC, int C, int H, int W, int lo, int OH, int OW) {
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, nc = blockIdx.z;
+    if (X >= OW) return;
+    const int Yf = Y + lo, Xf = X + lo;
+    float v = 0.f;
+    if (Yf >= 0 && Yf <= 2 * H && Xf >= 0 && Xf <= 2 * W)
+        v = mid[(((long)((Yf & 1) * 2 + (Xf & 1)) * NC + nc) * (H + 1) + (Yf >> 1)) * (W + 1) + (Xf >> 1)];
+    if (bias) v += bias[nc % C];
+    y[((long)nc * OH + Y) * OW + X] = v;
+}
+
+// mid [4][N*C][H+1][W+1] (shg_conv2d_f32 mode 2 with out_mode 1, or shg_conv2d_up_poly_f32) -> y [N*C, OH, OW]; bias [C] or null
+extern "C" int shg_planes_to_image_f32(const float* mid, const float* bias, float* y, int N, int C, int H, int W, int lo, int OH,
+                                       int OW, void* stream) {
+    SHG_CHECK_ARG(mid && y, "planes_to_image: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1, "planes_to_image: bad shape");
+    SHG_CHECK_ARG((long)N * C <= 65535 * 1L && OH <= 65535, "planes_to_image: too many planes / rows for one launch");
+    SHG_CHECK_ARG(4L * N * C * (H + 1) * (W + 1) <= 2147483647L && (long)N * C * OH * OW <= 2147483647L, "planes_to_image: tensor too large");
+    hipLaunchKernelGGL(planes_to_image_kernel, dim3(shg_cdiv(OW, 256), OH, N * C), dim3(256), 0, (hipStream_t)stream, mid, bias, y,
+                       N * C, C, H, W, lo, OH, OW);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // x[n,i,:] *= s[n,i]   (non-fused modulation, stylegan.py:173)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_channels_kernel(const float* x, const float* s, float* y, int HW, long total) {

@@ -299,6 +299,22 @@ def scale_channels(x, s):
     return y
 
 
+def planes_to_image(mid, lo, out_h, out_w, bias=None):
+    """mid [4,N,C,H+1,W+1] (phase planes of a stride-2 transposed convolution) -> [N,C,out_h,out_w] = rows / columns
+    [lo, lo+out) of the interleaved (2H+1) x (2W+1) result, zero where it ends earlier, + bias[c]."""
+    L = _Launch()
+    mid = L.req(mid, 'mid')
+    bias = L.req(bias, 'bias')
+    _, n, c, hp, wp = mid.shape
+    y = L.new((n, c, out_h, out_w))
+    if n * c > 65535:
+        raise _lib.ShgError('planes_to_image: N*C > 65535')
+    with _timed(L, 'planes_to_image', 4.0 * 2 * y.numel()):
+        check(_lib.get_lib().shg_planes_to_image_f32(_ptr(mid), _ptr(bias), _ptr(y), n, c, hp - 1, wp - 1, int(lo), int(out_h), int(out_w),
+                                                     L.stream()), 'planes_to_image')
+    return y
+
+
 def composite_u8(x4, img):
     L = _Launch()
     x4 = L.req(x4, 'x')

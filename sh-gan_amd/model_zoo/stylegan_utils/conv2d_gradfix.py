@@ -15,6 +15,7 @@ import torch
 
 from ... import kernels
 
+PLANAR_CONVT = True                  # transposed convolutions: phase planes + interleave pass (False: the direct interleaved kernel)
 enabled = True                       # (conv2d_gradfix.py:22) -- the HIP path is the only path; kept for interface compatibility
 weight_gradients_disabled = False    # (conv2d_gradfix.py:23)
 
@@ -60,12 +61,22 @@ def _conv_fwd(x, weight, bias, stride, padding, groups):
     return y
 
 
-def _convt_fwd(x, weight, bias, padding, groups):
+def _convt_fwd(x, weight, bias, padding, groups, out_hw=None):
+    """conv_transpose2d(x, weight [Cin, Cout/g, 3, 3], stride 2) cropped by ``padding`` on every side; with ``out_hw`` = (h, w) the
+    rows / columns [padding, padding + h) x [padding, padding + w) instead, zero where the result ends earlier (``_fit``)."""
     n, c, h, w = x.shape
     ci_g, co_g = weight.shape[0] // groups, weight.shape[1]
     # torch layout [Cin, Cout/g, kh, kw] -> per group [Cout/g, Cin/g, kh, kw]
     wg = weight.reshape(groups, ci_g, co_g, 3, 3).transpose(1, 2).reshape(groups * co_g, ci_g, 3, 3).contiguous()
     pw = kernels.conv_weight_prep(wg, groups=groups)
+    if groups == 1 and PLANAR_CONVT and n * co_g <= 65535:
+        # the four sub-pixel phases as planes (polyphase-Winograd kernel where its geometry allows), then one pass that interleaves,
+        # crops / zero-extends and adds the bias
+        mid = kernels.conv2d(x, pw, mode=kernels.MODE_UP2T, planar=True)
+        oh, ow = out_hw if out_hw is not None else (2 * h + 1 - 2 * padding, 2 * w + 1 - 2 * padding)
+        return kernels.planes_to_image(mid, padding, oh, ow, bias=bias)
+    if out_hw is not None:
+        return _fit(_convt_fwd(x, weight, bias, 0, groups), out_hw[0], out_hw[1], padding)
     y = kernels.conv2d(x.reshape(n * groups, ci_g, h, w), pw, mode=kernels.MODE_UP2T, bias=(bias if groups == 1 else None))
     y = y.reshape(n, -1, *y.shape[2:])
     if padding:
@@ -84,6 +95,8 @@ def _conv_input_grad(g, weight, x_shape, stride, padding):
         return conv2d(g, weight.transpose(0, 1).flip(2, 3), stride=1, padding=k - 1 - padding)
     if k != 3:
         raise NotImplementedError('conv2d backward: 1x1 stride-2 convolutions (the forward decimates with upfirdn2d first)')
+    if not _wants_grad(g, weight):
+        return _convt_fwd(g, weight, None, padding, 1, out_hw=(x_shape[2], x_shape[3]))     # crop / extension fused into the kernel
     return _fit(conv_transpose2d(g, weight, stride=2, padding=0), x_shape[2], x_shape[3], padding)
 
 

@@ -14,7 +14,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--resolution', type=int, default=512)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--direct-convt', action='store_true', help='transposed convolutions on the direct interleaved kernel (A/B)')
 a = ap.parse_args()
+if a.direct_convt:
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix as _gf
+    _gf.PLANAR_CONVT = False
 dev = 'cuda:0'
 G = configs.seeded_init_(configs.build_generator(a.resolution), seed=0).to(dev).train()
 for m in G.modules():                         # dropout of the encoder epilogue stays off: this measures kernels, not RNG
@@ -58,16 +62,18 @@ def d_phase():
     return float(loss)
 
 
+hist = []
 for _ in range(1):
-    g_phase(); d_phase()
+    hist.append((g_phase(), d_phase()))
 torch.cuda.synchronize()
 tg = td = 0.0
 for _ in range(a.steps):
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record(); lg = g_phase(); e[1].record(); ld = d_phase(); e[2].record(); torch.cuda.synchronize()
-    tg += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2])
+    tg += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2]); hist.append((lg, ld))
 print(f'G phase {tg / a.steps:8.1f} ms   D phase {td / a.steps:8.1f} ms   step {(tg + td) / a.steps:8.1f} ms   '
       f'({a.batch / ((tg + td) / a.steps) * 1e3:.1f} images/s, losses {lg:.4f} {ld:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)')
+print('loss history (G, D) per step:', ' '.join(f'({g:.4f} {d:.4f})' for g, d in hist))
 kt = kernels.KernelTimer()
 kernels.set_timer(kt)
 g_phase(); d_phase()
