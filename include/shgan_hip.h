@@ -138,6 +138,11 @@ int shg_fir_down_planar_f32(const float* x, const float* f, float* y, int N, int
 int shg_fir_pad2_sep_supported(int H, int W, int PP);
 int shg_fir_pad2_sep_f32(const float* x, const float* taps_host, float* y, int N, int C, int H, int W, int PP, int flip, float gain,
                          void* stream);
+/* The x2 resampling FIRs of the training rows, separable filter (taps_host as above), row-marching kernels:
+ * up == 1: y [N,C,H/2,W/2] = upfirdn2d(x, f, down=2, padding=1); up == 2: y [N,C,2H,2W] = upfirdn2d(x, f, up=2, padding=[2,1,2,1]). */
+int shg_fir_resample2_sep_supported(int H, int W, int up);
+int shg_fir_resample2_sep_f32(const float* x, const float* taps_host, float* y, int N, int C, int H, int W, int up, int flip, float gain,
+                              void* stream);
 int shg_conv_weight_prep_down_poly_f32(const float* w, const float* wscale, float* wu_a, float* wu_b, int O, int I, int OP, int flip,
                                        void* stream);
 int shg_conv2d_down_poly_supported(int NB, int I, int O, int OH, int OW);

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -76,6 +76,8 @@ _SIGS = {
     'shg_conv2d_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp],
     'shg_fir_down_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_fir_pad2_sep_supported': [c_i, c_i, c_i],
+    'shg_fir_resample2_sep_supported': [c_i, c_i, c_i],
+    'shg_fir_resample2_sep_f32': [c_fp, ctypes.POINTER(c_f), c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_fir_pad2_sep_f32': [c_fp, ctypes.POINTER(c_f), c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_conv_weight_prep_down_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_down_poly_supported': [c_i, c_i, c_i, c_i, c_i],

@@ -391,3 +391,132 @@ __global__ __launch_bounds__(256) void fir_up_march_kernel(const FirUpParams p) 
         for (int j = 0; j < B; ++j) step(in[j], t + j);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two resampling FIRs of the training rows, same marching scheme, separable 4-tap filters:
+//   fir_dn2_march_kernel:  y [NC,H/2,W/2] = upfirdn2d(x, f, down=2, padding=1)   -- the pre-filter of the discriminator's 1x1
+//       stride-2 skip convolutions (conv2d_resample.py:104-108) and the backward of the up-sampling FIR (upfirdn2d.py:174-192);
+//   fir_up2_march_kernel:  y [NC,2h,2w]   = upfirdn2d(g, f, up=2, padding=[2,1,2,1]) -- upsample2d of the running RGB image
+//       (upfirdn2d.py:288-305, gain 4 in the taps) and the backward of the above.
+//     dn2:  y[oy][ox]   = sum b[ky] a[kx] x[2oy+ky-1][2ox+kx-1]
+//     up2:  y[2u][2v]   = (b0 r[u-1] + b2 r[u])[2v],  y[2u+1] = (b1 r[u] + b3 r[u+1]),   r[u][2v] = a0 g[u][v-1] + a2 g[u][v],
+//           r[u][2v+1] = a1 g[u][v] + a3 g[u][v+1]                    (zero insertion: every output sees 2 x 2 inputs)
+struct FirRsParams {
+    const float* x; float* y;
+    int NC, H, W;             // INPUT extent
+    int R, nseg, LPG, G, nitem;
+    float a[4], b[4];
+};
+
+template <int K>   // K float4 per lane per input row (W = 256 K for K > 1)
+__global__ __launch_bounds__(256) void fir_dn2_march_kernel(const FirRsParams p) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.nitem) return;
+    const int seg = item % p.nseg, pg = item / p.nseg;
+    const int g = lane / p.LPG, li = lane - g * p.LPG;
+    const int OH = p.H >> 1, OW = p.W >> 1;
+    const int r0 = seg * p.R, r1 = min(r0 + p.R, OH);           // output rows
+    const int plane_raw = pg * p.G + g;
+    const bool lane_on = plane_raw < p.NC;
+    const int plane = lane_on ? plane_raw : 0;
+    const bool grp = K == 1 && p.LPG < 64;
+    const bool gfirst = grp && li == 0, glast = grp && li == p.LPG - 1;
+    const float* xb = p.x + (long)plane * p.H * p.W + 4 * li;
+    float* yb = p.y + (long)plane * OH * OW + 2 * li;
+    const float a0 = p.a[0], a1 = p.a[1], a2 = p.a[2], a3 = p.a[3];
+    const float b0 = p.b[0], b1 = p.b[1], b2 = p.b[2], b3 = p.b[3];
+    auto hrow = [&](int iy, float2 (&h)[K]) __attribute__((always_inline)) {
+        const bool ok = iy >= 0 && iy < p.H;
+        const float* src = xb + (long)min(max(iy, 0), p.H - 1) * p.W;
+        float4 c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 256 * k);
+            c[k].x = ok ? v.x : 0.f; c[k].y = ok ? v.y : 0.f; c[k].z = ok ? v.z : 0.f; c[k].w = ok ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float pw = fm_shr1(c[k].w, k > 0 ? fm_lane(c[k - 1].w, 63) : 0.f);
+            float nx = fm_shl1(c[k].x, k + 1 < K ? fm_lane(c[k + 1].x, 0) : 0.f);
+            pw = gfirst ? 0.f : pw; nx = glast ? 0.f : nx;
+            h[k].x = a0 * pw + a1 * c[k].x + a2 * c[k].y + a3 * c[k].z;
+            h[k].y = a0 * c[k].y + a1 * c[k].z + a2 * c[k].w + a3 * nx;
+        }
+    };
+    float2 hm1[K], h0[K], h1[K], h2[K];                       // rows 2oy-1, 2oy, 2oy+1, 2oy+2
+    hrow(2 * r0 - 1, hm1);
+    hrow(2 * r0, h0);
+    for (int oy = r0; oy < r1; ++oy) {
+        hrow(2 * oy + 1, h1);
+        hrow(2 * oy + 2, h2);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float2 o;
+            o.x = b0 * hm1[k].x + b1 * h0[k].x + b2 * h1[k].x + b3 * h2[k].x;
+            o.y = b0 * hm1[k].y + b1 * h0[k].y + b2 * h1[k].y + b3 * h2[k].y;
+            if (lane_on) *reinterpret_cast<float2*>(yb + (long)oy * OW + 128 * k) = o;
+            hm1[k] = h1[k]; h0[k] = h2[k];
+        }
+    }
+}
+
+template <int K>   // K float2 per lane per input row (w = 128 K for K > 1)
+__global__ __launch_bounds__(256) void fir_up2_march_kernel(const FirRsParams p) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.nitem) return;
+    const int seg = item % p.nseg, pg = item / p.nseg;
+    const int g = lane / p.LPG, li = lane - g * p.LPG;
+    const int OW = 2 * p.W;
+    const int u0 = seg * p.R, u1 = min(u0 + p.R, p.H);           // input rows
+    const int plane_raw = pg * p.G + g;
+    const bool lane_on = plane_raw < p.NC;
+    const int plane = lane_on ? plane_raw : 0;
+    const bool grp = K == 1 && p.LPG < 64;
+    const bool gfirst = grp && li == 0, glast = grp && li == p.LPG - 1;
+    const float* xb = p.x + (long)plane * p.H * p.W + 2 * li;
+    float* yb = p.y + (long)plane * (2 * p.H) * OW + 4 * li;
+    const float a0 = p.a[0], a1 = p.a[1], a2 = p.a[2], a3 = p.a[3];
+    const float b0 = p.b[0], b1 = p.b[1], b2 = p.b[2], b3 = p.b[3];
+    auto hrow = [&](int u, float4 (&h)[K]) __attribute__((always_inline)) {
+        const bool ok = u >= 0 && u < p.H;
+        const float* src = xb + (long)min(max(u, 0), p.H - 1) * p.W;
+        float2 c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float2 v = *reinterpret_cast<const float2*>(src + 128 * k);
+            c[k].x = ok ? v.x : 0.f; c[k].y = ok ? v.y : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float py = fm_shr1(c[k].y, k > 0 ? fm_lane(c[k - 1].y, 63) : 0.f);
+            float nx = fm_shl1(c[k].x, k + 1 < K ? fm_lane(c[k + 1].x, 0) : 0.f);
+            py = gfirst ? 0.f : py; nx = glast ? 0.f : nx;
+            h[k].x = a0 * py + a2 * c[k].x;          // columns 2v, 2v+1, 2v+2, 2v+3 (v = 2 (li + 64 k))
+            h[k].y = a1 * c[k].x + a3 * c[k].y;
+            h[k].z = a0 * c[k].x + a2 * c[k].y;
+            h[k].w = a1 * c[k].y + a3 * nx;
+        }
+    };
+    float4 rm1[K], r0_[K], rp1[K];
+    hrow(u0 - 1, rm1);
+    hrow(u0, r0_);
+    for (int u = u0; u < u1; ++u) {
+        hrow(u + 1, rp1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float4 e, o;
+            e.x = b0 * rm1[k].x + b2 * r0_[k].x; e.y = b0 * rm1[k].y + b2 * r0_[k].y;
+            e.z = b0 * rm1[k].z + b2 * r0_[k].z; e.w = b0 * rm1[k].w + b2 * r0_[k].w;
+            o.x = b1 * r0_[k].x + b3 * rp1[k].x; o.y = b1 * r0_[k].y + b3 * rp1[k].y;
+            o.z = b1 * r0_[k].z + b3 * rp1[k].z; o.w = b1 * r0_[k].w + b3 * rp1[k].w;
+            if (lane_on) {
+                float* yr = yb + (long)(2 * u) * OW + 256 * k;
+                *reinterpret_cast<float4*>(yr) = e;
+                *reinterpret_cast<float4*>(yr + OW) = o;
+            }
+            rm1[k] = r0_[k]; r0_[k] = rp1[k];
+        }
+    }
+}

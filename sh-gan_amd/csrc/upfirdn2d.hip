@@ -614,3 +614,48 @@ extern "C" int shg_upfir_planar_sep_f32(const float* mid, const float* taps_host
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
+
+// The two x2 resampling FIRs of the training rows as row-marching kernels (fir_march.h), SEPARABLE 4x4 filter, taps_host =
+// {fx[0..3], fy[0..3]} in HOST memory:
+//   up == 1:  y [N,C,H/2,W/2] = upfirdn2d(x, f, down=2, padding=1)          (conv2d_resample.py:104-108; backward of the up FIR)
+//   up == 2:  y [N,C,2H,2W]   = upfirdn2d(x, f, up=2, padding=[2,1,2,1])     (upsample2d, upfirdn2d.py:288-305; backward of the down FIR)
+extern "C" int shg_fir_resample2_sep_supported(int H, int W, int up) {
+    if (up == 1) return (H >= 2 && H % 2 == 0 && W >= 8 && W % 4 == 0 && (W <= 256 ? 64 % (W / 4) == 0 : W == 512)) ? 1 : 0;
+    if (up == 2) return (H >= 1 && W >= 4 && W % 2 == 0 && (W <= 128 ? 64 % (W / 2) == 0 : W == 256)) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int shg_fir_resample2_sep_f32(const float* x, const float* taps_host, float* y, int N, int C, int H, int W, int up, int flip,
+                                         float gain, void* stream) {
+    SHG_CHECK_ARG(x && taps_host && y, "fir_resample2_sep: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 1, "fir_resample2_sep: bad shape");
+    SHG_CHECK_ARG(shg_fir_resample2_sep_supported(H, W, up), "fir_resample2_sep: unsupported geometry (shg_fir_resample2_sep_supported)");
+    SHG_CHECK_ARG((long)N * C * H * W * (up == 2 ? 4 : 1) <= 2147483647L, "fir_resample2_sep: tensor too large");
+    SHG_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "fir_resample2_sep: x / y must be 16-byte aligned");
+    FirRsParams p{};
+    p.x = x; p.y = y; p.NC = N * C; p.H = H; p.W = W;
+    for (int k = 0; k < 4; ++k) {
+        p.a[k] = taps_host[flip ? k : 3 - k];
+        p.b[k] = taps_host[4 + (flip ? k : 3 - k)] * gain;
+    }
+    const int lanes = up == 1 ? W / 4 : W / 2;                   // lanes per row
+    p.LPG = lanes < 64 ? lanes : 64; p.G = 64 / p.LPG;
+    const int K = shg_cdiv(lanes, 64);
+    const int npg = shg_cdiv(p.NC, p.G);
+    const int rows = up == 1 ? H / 2 : H;                        // marched rows (dn2: output rows, up2: input rows)
+    int nseg = shg_cdiv(8192, npg);
+    if (nseg > rows / 8) nseg = rows / 8;
+    if (nseg < 1) nseg = 1;
+    p.R = shg_cdiv(rows, nseg); p.nseg = shg_cdiv(rows, p.R); p.nitem = npg * p.nseg;
+    const dim3 grid(shg_cdiv(p.nitem, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (up == 1) {
+        if (K == 1) hipLaunchKernelGGL((fir_dn2_march_kernel<1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fir_dn2_march_kernel<2>), grid, dim3(256), 0, s, p);
+    } else {
+        if (K == 1) hipLaunchKernelGGL((fir_up2_march_kernel<1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((fir_up2_march_kernel<2>), grid, dim3(256), 0, s, p);
+    }
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

@@ -218,7 +218,21 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
         if (upx, upy, downx, downy) == (1, 1, 1, 1) and (padx0, padx1, pady0, pady1) == (2, 2, 2, 2) and (fh, fw) == (4, 4) \
                 and lib.shg_fir_pad2_sep_supported(h, w, 0):
             taps = sep_taps(f)
+        rs_up = 0
+        if taps is None and (fh, fw) == (4, 4) and x.data_ptr() % 16 == 0:
+            if (upx, upy, downx, downy) == (1, 1, 2, 2) and (padx0, padx1, pady0, pady1) == (1, 1, 1, 1):
+                rs_up = 1
+            elif (upx, upy, downx, downy) == (2, 2, 1, 1) and (padx0, padx1, pady0, pady1) == (2, 1, 2, 1):
+                rs_up = 2
+            if rs_up and lib.shg_fir_resample2_sep_supported(h, w, rs_up):
+                taps = sep_taps(f)
+            if taps is None:
+                rs_up = 0
         with _timed(L, 'upfirdn2d', work):
+            if rs_up:
+                check(lib.shg_fir_resample2_sep_f32(_ptr(x), taps, _ptr(y), n, c, h, w, rs_up, int(bool(flip)), float(gain), L.stream()),
+                      'fir_resample2_sep')
+                return y
             if taps is not None:
                 check(lib.shg_fir_pad2_sep_f32(_ptr(x), taps, _ptr(y), n, c, h, w, 0, int(bool(flip)), float(gain), L.stream()), 'fir_pad2_sep')
                 return y

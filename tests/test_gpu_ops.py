@@ -127,6 +127,36 @@ def test_fir_march_pad2_vs_oracle_and_tiled_kernel(mods, shape):
     assert rel_err(c(ufd.upfirdn2d(x.to(DEV), fn.to(DEV), padding=[2, 2, 2, 2])), ref) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 512, 512), (1, 5, 256, 256), (3, 2, 128, 128), (2, 7, 64, 64), (5, 3, 32, 32), (3, 5, 16, 16),
+                                   (2, 9, 8, 8), (2, 3, 64, 128)])
+def test_fir_march_x2_resampling_vs_oracle_and_generic_kernel(mods, shape):
+    """Row-marching down=2 (padding 1) and up=2 (padding [2,1,2,1]) FIRs of the training rows: oracle (upfirdn2d.py:98-138) and the
+    generic gather kernel, symmetric and asymmetric separable taps, both flips, a gain."""
+    orc, ufd, K = mods['orc'], mods['ufd'], mods['kernels']
+    rs = np.random.RandomState(11)
+    n, ch, h, w = shape
+    lib = K._lib.get_lib()
+    fa = torch.from_numpy(np.outer([0.5, 1.5, -0.7, 0.2], [0.3, 1.0, 2.0, -0.4]).astype(np.float32))
+    for up, xs in ((1, (n, ch, h, w)), (2, (n, ch, h // 2, w // 2))):
+        if not lib.shg_fir_resample2_sep_supported(xs[2], xs[3], up):
+            assert up == 2 and xs[3] < 4
+            continue
+        x = torch.from_numpy(rs.standard_normal(xs).astype(np.float32))
+        kw = dict(down=2, padding=[1, 1, 1, 1]) if up == 1 else dict(up=2, padding=[2, 1, 2, 1])
+        for f in (orc.setup_filter([1, 3, 3, 1]), fa):
+            for flip in (False, True):
+                ref = orc.upfirdn2d(x, f, gain=1.7, flip_filter=flip, **kw).numpy()
+                y = c(ufd.upfirdn2d(x.to(DEV), f.to(DEV), gain=1.7, flip_filter=flip, **kw))
+                assert y.shape == ref.shape
+                assert rel_err(y, ref) < 1e-5
+                K.FIR_MARCH = False
+                try:
+                    y_old = c(ufd.upfirdn2d(x.to(DEV), f.to(DEV), gain=1.7, flip_filter=flip, **kw))
+                finally:
+                    K.FIR_MARCH = True
+                assert rel_err(y, y_old) < 2e-6
+
+
 def test_fir_fused_epilogue_vs_oracle(mods):
     orc, k = mods['orc'], mods['kernels']
     rs = np.random.RandomState(2)
