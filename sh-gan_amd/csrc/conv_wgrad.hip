@@ -161,12 +161,128 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         }
 }
 
+// Small images (OW a power of two below the chunk width: the 4^2 ... 32^2 layers).  A chunk of the kernel above is a piece of ONE
+// output row, so a 4-pixel row would fill 4 of its 64 operand columns.  Here a chunk is PX consecutive pixels of the flattened
+// (image, row, column) space = R = PX / OW whole output rows, each with its own KH-row window in LDS ([row-in-chunk][window row]
+// [column][channel]); the operand address of a pixel is computed from (k / OW, k % OW).  No register pipeline: these layers are
+// small, the staging is element-indexed (shifts: the window pitch is padded to a power of two for the index arithmetic only).
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradParams p) {
+    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, CP = 65;
+    constexpr int XMAX = S == 1 ? 288 : 240;                    // window elements per channel, worst case (OW = 4)
+    __shared__ float Gs[PX * CP];
+    __shared__ float Xs[XMAX * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int grp = wave >> 2, mo = (wave >> 1) & 1, nt = wave & 1;
+    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int per = (p.nchunk + p.nslice - 1) / p.nslice;
+    const int c_begin = slice * per, c_end = min(p.nchunk, c_begin + per);
+    const int lw = 31 - __builtin_clz(p.OW), R = PX >> lw;      // log2 OW, output rows per chunk
+    const int XWs = p.OW * S + KW - 1;                           // window columns
+    const int lxp = 32 - __builtin_clz(XWs - 1);                 // log2 of the padded pitch used for indexing
+    const int WR = R * KH;                                       // window rows per chunk
+    const int NE = (64 * WR) << lxp;                             // indexed elements
+    const int rows_total = p.NB * p.OH;
+    wg_f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const long gplane = (long)p.OH * p.OW, xplane = (long)p.H * p.W;
+    const int gpx = lane % PX, gsub = lane / PX;
+    int tapoff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KW) * XWs + (t % KW)) * CP;
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();
+        {   // g: pixel gpx of the chunk = (row c*R + gpx / OW, column gpx % OW)
+            const int row = c * R + (gpx >> lw), cx = gpx & (p.OW - 1);
+            const int n = row / p.OH, oy = row - n * p.OH;
+            const bool pok = row < rows_total;
+            const float* gp = p.g + ((long)(pok ? n : 0) * p.O + o0) * gplane + (long)(pok ? oy : 0) * p.OW + cx;
+#pragma unroll
+            for (int j = 0; j < 64 * PX / 512; ++j) {
+                const int o = (wave + 8 * j) * (64 / PX) + gsub;
+                const bool ok = pok && o0 + o < p.O;
+                const float v = gp[ok ? (long)o * gplane : 0];
+                Gs[gpx * CP + o] = ok ? v : 0.f;
+            }
+        }
+        for (int e0 = 0; e0 < NE; e0 += 512 * 8) {
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + tid + 512 * j;
+                const int col = e & ((1 << lxp) - 1), t = e >> lxp;
+                const int ch = t / WR, wr = t - ch * WR;
+                const int rr = wr / KH, ty = wr - rr * KH;
+                const int row = c * R + rr;
+                const int n = row / p.OH, oy = row - n * p.OH;
+                const int iy = oy * S - p.pad + ty, ix = col - p.pad;
+                const bool inwin = e < NE && col < XWs;
+                const bool ok = inwin && row < rows_total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + ch < p.I;
+                const float val = p.x[ok ? ((long)n * p.I + i0 + ch) * xplane + (long)iy * p.W + ix : 0];
+                v[j] = ok ? val : 0.f;
+                dst[j] = inwin ? (wr * XWs + col) * CP + ch : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (dst[j] >= 0) Xs[dst[j]] = v[j];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = grp; ks < PX / 2; ks += 2) {
+            const int k = 2 * ks + half;
+            const float a = Gs[k * CP + mo * 32 + l31];
+            const int base = ((k >> lw) * KH * XWs + (k & (p.OW - 1)) * S) * CP + nt * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[base + tapoff[t]], acc[t], 0, 0, 0);
+        }
+    }
+    float* red = Xs;
+    constexpr int TB = TAPS < 3 ? TAPS : 3;
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TB) {
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane] = acc[t0 + tt][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t0 + tt][r] += red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane];
+        }
+    }
+    if (grp == 1) return;
+    float* dst = p.out + (p.nslice > 1 ? (long)slice * p.O * p.I * TAPS : 0);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, i = i0 + nt * 32 + l31;
+            if (o < p.O && i < p.I) dst[((long)o * p.I + i) * TAPS + t] = acc[t][r];
+        }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, long n, int nslice) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     float v = 0.f;
     for (int s = 0; s < nslice; ++s) v += part[(long)s * n + e];
     dw[e] = v;
+}
+
+// small-image form: 3x3, OW a power of two of at most a quarter of a chunk (whole rows per chunk), x rows fully inside the window
+static bool wgrad_packed(int OW, int W, int kh, int stride, int pad) {
+    const int PX = stride == 1 ? 64 : 32;
+    // (rows of half a chunk stay on the row-piece kernel: 990 vs 1039 us at 512 channels, 32^2)
+    return kh == 3 && OW >= 4 && OW <= PX / 4 && (OW & (OW - 1)) == 0 && W <= OW * stride + 2 && pad <= 2;
 }
 
 static int wgrad_slices(int NB, int I, int O, int OH, int OW, int taps) {
@@ -199,15 +315,19 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
                   "conv2d_wgrad: output extent does not match x, stride and padding");
     WgradParams p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
+    const bool packed = wgrad_packed(OW, W, kh, stride, pad);
     p.chunks_x = shg_cdiv(OW, stride == 1 ? 64 : 32);
-    p.nchunk = NB * OH * p.chunks_x;
+    p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : NB * OH * p.chunks_x;
     p.nslice = wgrad_slices(NB, I, O, OH, OW, kh * kw);
+    if (p.nslice > p.nchunk) p.nslice = p.nchunk;
     const size_t need = p.nslice > 1 ? (size_t)p.nslice * O * I * kh * kw * sizeof(float) : 0;
     SHG_CHECK_ARG(need == 0 || (workspace && ws_bytes >= need), "conv2d_wgrad: workspace too small (shg_conv2d_wgrad_workspace_bytes)");
     p.out = p.nslice > 1 ? (float*)workspace : dw;
     const dim3 grid(shg_cdiv(I, 64), shg_cdiv(O, 64), p.nslice);
     hipStream_t s = (hipStream_t)stream;
-    if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
+    if (packed && stride == 1) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
+    else if (packed) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
+    else if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2>), grid, dim3(512), 0, s, p);

@@ -29,6 +29,9 @@ CONV_CASES = [
     (2, 8, 16, 16, 16, 3, 1, 1), (3, 37, 70, 20, 24, 3, 1, 1), (1, 64, 64, 64, 96, 3, 1, 1), (2, 24, 40, 12, 12, 3, 1, 0),
     (2, 16, 32, 33, 33, 3, 2, 0), (1, 40, 24, 65, 129, 3, 2, 0), (2, 12, 20, 16, 16, 3, 2, 1),
     (2, 20, 36, 16, 16, 1, 1, 0), (1, 4, 64, 32, 32, 1, 1, 0),
+    # small images: several output rows per chunk (packed form), incl. a partial last chunk and rows of several images in one chunk
+    (3, 24, 70, 4, 4, 3, 1, 1), (5, 64, 64, 8, 8, 3, 1, 1), (3, 40, 33, 32, 32, 3, 1, 1), (7, 16, 16, 9, 9, 3, 2, 0), (3, 70, 24, 17, 17, 3, 2, 0),
+    (2, 32, 32, 33, 33, 3, 2, 0), (3, 16, 24, 8, 8, 3, 2, 1),
 ]
 
 
