@@ -29,6 +29,7 @@ class BucketedAllReduce:
         self._pending = []         # per bucket: gradients still missing in this backward pass
         self._handles = []
         self._hooks = []
+        self._touched = set()      # id(param) of the parameters that received a gradient since zero_grad()
         cap = max(int(bucket_bytes) // 4, 1)
         cur, cur_n = [], 0
         groups = []
@@ -57,6 +58,7 @@ class BucketedAllReduce:
 
     # -- hooks ---------------------------------------------------------------------------------------------------------
     def _on_grad(self, p):
+        self._touched.add(id(p))
         bi, off, n = self._slot[id(p)]
         flat = self.buckets[bi]
         if p.grad.data_ptr() != flat[off:off + n].data_ptr():            # autograd replaced the view (first accumulation)
@@ -77,6 +79,12 @@ class BucketedAllReduce:
                 p.grad = self.buckets[bi][off:off + n].view_as(p)
         self._pending = list(self._sizes)
         self._handles = []
+        self._touched = set()
+
+    def untouched(self):
+        """Parameters that received no gradient since ``zero_grad()`` -- their bucket slots hold zeros; an optimiser that must skip
+        them (``zero_grad(set_to_none=True)`` semantics: no moment decay, no step) gets ``p.grad = None`` for these."""
+        return [p for p in self.params if id(p) not in self._touched]
 
     def finish(self):
         """Wait for the reductions of this backward pass; average, sanitise.  Buckets whose parameters did not all receive a

@@ -1,0 +1,141 @@
+"""The training stage around the G / D step: phases with lazy regularisation, the per-iteration phase
+loop, gradient sanitisation + all-reduce, the G_ema update.
+
+Mirrors ``lib/experiments/stylegan_default.py``:
+  * ``make_phases``  -- :304-321.  One optimiser per network; with a regularisation interval r the 'main' phase runs every
+    iteration and the 'reg' phase every r-th, and the optimiser's hyper-parameters absorb the skipped steps
+    (``mb_ratio = r / (r + 1)``, ``lr * mb_ratio``, ``beta ** mb_ratio``); without one a single 'both' phase.
+  * ``run_phases``   -- ``train_stage.main`` :108-167: the latents of all phases drawn at once, every phase whose interval divides the
+    iteration index zeroes its gradients, opens ``requires_grad`` on ITS module only, accumulates over the rounds of
+    ``effective_batch_gpu`` samples (``loss.accumulate_gradients(phase, real_img, real_c, gen_z, gen_c, sync, gain=interval)``),
+    sanitises the gradients (``nan_to_num(nan=0, posinf=1e5, neginf=-1e5)``) and steps.
+  * ``update_ema``   -- :383-390: ``ema_beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))`` with the ``ema_rampup`` cap, buffers copied.
+  * ``train``        -- the iteration loop :370-396 without its logging / snapshot / metric maintenance (``training_stats``,
+    ``dnnlib`` and the snapshot pickles are not part of the reference tree; ``on_tick`` is the hook for them).
+The reference wraps the networks in DistributedDataParallel (:172-187); here every phase owns a ``grad_sync.BucketedAllReduce`` over
+its module's parameters (RCCL all-reduce launched from backward hooks, averaged and sanitised per bucket) -- with one rank it only
+sanitises, so the same code runs on one GPU and on N."""
+import torch
+
+from .grad_sync import BucketedAllReduce
+
+
+class Phase:
+    def __init__(self, name, module, opt, interval, sync=None):
+        self.name, self.module, self.opt, self.interval, self.sync = name, module, opt, interval, sync
+        self.start_event = self.end_event = None
+
+    def __repr__(self):
+        return f'Phase({self.name}, interval={self.interval})'
+
+
+def make_phases(G, D, g_opt_kwargs, d_opt_kwargs, g_reg_interval=4, d_reg_interval=16, opt_class=torch.optim.Adam,
+                process_group=None, bucket_bytes=64 << 20, timing=False):
+    """[Gmain, Greg, Dmain, Dreg] (or Gboth / Dboth where the interval is None), stylegan_default.py:304-321."""
+    phases = []
+    for name, module, opt_kwargs, reg_interval in (('G', G, g_opt_kwargs, g_reg_interval), ('D', D, d_opt_kwargs, d_reg_interval)):
+        params = [p for p in module.parameters()]
+        kw = dict(opt_kwargs)
+        sync = BucketedAllReduce(params, bucket_bytes=bucket_bytes, process_group=process_group) if any(p.is_cuda for p in params) or \
+            torch.distributed.is_available() and torch.distributed.is_initialized() else None
+        if reg_interval is None:
+            opt = opt_class(params, **kw)
+            phases.append(Phase(name + 'both', module, opt, 1, sync))
+        else:                                   # lazy regularisation
+            mb_ratio = reg_interval / (reg_interval + 1)
+            kw['lr'] = kw['lr'] * mb_ratio
+            kw['betas'] = tuple(float(beta) ** mb_ratio for beta in kw['betas'])
+            opt = opt_class(params, **kw)
+            phases.append(Phase(name + 'main', module, opt, 1, sync))
+            phases.append(Phase(name + 'reg', module, opt, reg_interval, sync))
+    if timing and torch.cuda.is_available():
+        for ph in phases:
+            ph.start_event, ph.end_event = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    return phases
+
+
+def sanitize_(params):
+    """``misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)`` of stylegan_default.py:160-164."""
+    for p in params:
+        if p.grad is not None:
+            torch.nan_to_num(p.grad, nan=0.0, posinf=1e5, neginf=-1e5, out=p.grad)
+
+
+def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_batch_gpu=None, device=None, real_c=None, gen_c=None):
+    """One iteration = ``train_stage.main`` (stylegan_default.py:108-167).  real_img [batch_gpu, C, H, W]; returns the names of the
+    phases that ran."""
+    device = real_img.device if device is None else torch.device(device)
+    eff = batch_gpu if effective_batch_gpu is None else effective_batch_gpu
+    real_img = real_img.to(device).to(torch.float32)
+    real_c = torch.zeros([batch_gpu, 0], device=device) if real_c is None else real_c.to(device)
+    all_gen_c = torch.zeros([len(phases) * batch_gpu, 0], device=device) if gen_c is None else gen_c.to(device)
+    all_gen_z = torch.randn([len(phases) * batch_gpu, z_dim]).to(device)       # drawn on the host like the reference (:128)
+    real_img_r, real_c_r = real_img.split(eff), real_c.split(eff)
+    all_gen_z = [pz.split(eff) for pz in all_gen_z.split(batch_gpu)]
+    all_gen_c = [pc.split(eff) for pc in all_gen_c.split(batch_gpu)]
+    ran = []
+    for phase, phase_gen_z, phase_gen_c in zip(phases, all_gen_z, all_gen_c):
+        if batch_idx % phase.interval != 0:
+            continue
+        if phase.start_event is not None:
+            phase.start_event.record(torch.cuda.current_stream(device))
+        if phase.sync is not None:
+            phase.sync.zero_grad()                       # gradients live in the all-reduce buckets
+        else:
+            phase.opt.zero_grad(set_to_none=True)
+        phase.module.requires_grad_(True)
+        rounds = batch_gpu // eff
+        for round_idx, (ri, rc, gz, gc) in enumerate(zip(real_img_r, real_c_r, phase_gen_z, phase_gen_c)):
+            loss.accumulate_gradients(phase=phase.name, real_img=ri, real_c=rc, gen_z=gz, gen_c=gc,
+                                      sync=(round_idx == rounds - 1), gain=phase.interval)
+        phase.module.requires_grad_(False)
+        if phase.sync is not None:
+            phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
+            for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them
+                p.grad = None
+        else:
+            sanitize_(phase.module.parameters())
+        phase.opt.step()
+        if phase.end_event is not None:
+            phase.end_event.record(torch.cuda.current_stream(device))
+        ran.append(phase.name)
+    return ran
+
+
+def ema_beta(batch_size, cur_nimg, ema_kimg=10.0, ema_rampup=None):
+    ema_nimg = ema_kimg * 1000
+    if ema_rampup is not None:
+        ema_nimg = min(ema_nimg, cur_nimg * ema_rampup)
+    return 0.5 ** (batch_size / max(ema_nimg, 1e-8))
+
+
+@torch.no_grad()
+def update_ema(G_ema, G, batch_size, cur_nimg, ema_kimg=10.0, ema_rampup=None):
+    """stylegan_default.py:383-390."""
+    beta = ema_beta(batch_size, cur_nimg, ema_kimg, ema_rampup)
+    for p_ema, p in zip(G_ema.parameters(), G.parameters()):
+        p_ema.copy_(p.lerp(p_ema, beta))
+    for b_ema, b in zip(G_ema.buffers(), G.buffers()):
+        b_ema.copy_(b)
+    return beta
+
+
+def train(G, D, G_ema, loss, batches, phases, z_dim, batch_size, batch_gpu, total_kimg, effective_batch_gpu=None, ema_kimg=10.0,
+          ema_rampup=None, kimg_per_tick=4, on_tick=None, device=None):
+    """The iteration loop of stylegan_default.py:370-396: ``batches`` yields real images [batch_gpu, C, H, W] for this rank,
+    ``batch_size`` is the GLOBAL batch (= batch_gpu * world).  Returns (cur_nimg, batch_idx)."""
+    cur_nimg, batch_idx, cur_tick, tick_start = 0, 0, 0, 0
+    for real_img in batches:
+        run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_batch_gpu, device)
+        update_ema(G_ema, G, batch_size, cur_nimg, ema_kimg, ema_rampup)
+        cur_nimg += batch_size
+        batch_idx += 1
+        done = cur_nimg >= total_kimg * 1000
+        if done or cur_tick == 0 or cur_nimg >= tick_start + kimg_per_tick * 1000:
+            if on_tick is not None:
+                on_tick(cur_tick, cur_nimg, batch_idx)
+            cur_tick += 1
+            tick_start = cur_nimg
+        if done:
+            break
+    return cur_nimg, batch_idx
