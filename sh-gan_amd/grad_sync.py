@@ -19,7 +19,9 @@ import torch.distributed as dist
 
 class BucketedAllReduce:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, sanitize=True, always_reduce=False):
-        self.params = [p for p in params if p.requires_grad]
+        # every parameter, whatever its requires_grad flag says NOW: the training stage keeps the networks frozen except inside
+        # their own phase (stylegan_default.py:147,157), so the flag is False when the buckets are laid out
+        self.params = list(params)
         self.group = process_group
         self.sanitize = sanitize
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -54,7 +56,10 @@ class BucketedAllReduce:
             self._pending.append(len(grp))
         self._sizes = list(self._pending)
         for p in self.params:
+            was = p.requires_grad                   # (a hook can only be registered while the flag is set; it stays on the tensor)
+            p.requires_grad_(True)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            p.requires_grad_(was)
 
     # -- hooks ---------------------------------------------------------------------------------------------------------
     def _on_grad(self, p):

@@ -93,6 +93,7 @@ def test_two_training_iterations_on_the_gpu():
     G_ema = copy.deepcopy(G).eval()
     kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8)
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
+    assert len(phases[0].sync.params) == len(list(G.parameters())) and len(phases[2].sync.params) == len(list(D.parameters()))
     loss = losses.StyleGAN2Loss(dev, G.mapping, G.synthesis, D, style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2)
     g0 = [p.detach().clone() for p in G.parameters()]
     d0 = [p.detach().clone() for p in D.parameters()]
@@ -106,3 +107,56 @@ def test_two_training_iterations_on_the_gpu():
     beta = ts.ema_beta(4, 4, ema_kimg=0.004)
     last = list(G.parameters())[0]
     assert torch.isfinite(list(G_ema.parameters())[0]).all() and 0 < beta < 1 and last.shape == list(G_ema.parameters())[0].shape
+
+
+def test_gloo_world2_training_stage_keeps_ranks_identical():
+    """Two gloo ranks, different data per rank, a hand-written least-squares 'GAN': after ``train`` both ranks hold bit-identical
+    parameters, equal to a one-process run on the mean gradient; a parameter the reg phase never touches is not stepped by it."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    script = r'''
+import copy, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd import train_stage as ts
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"], rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+def nets():
+    torch.manual_seed(0)
+    G = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 12)).requires_grad_(False)
+    D = torch.nn.Sequential(torch.nn.Linear(12, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).requires_grad_(False)
+    return G, D
+class Loss:
+    def __init__(self, G, D, world_mean):
+        self.G, self.D, self.wm = G, D, world_mean
+    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
+        with torch.enable_grad():
+            if phase == "Gmain":   l = torch.nn.functional.softplus(-self.D(self.G(gen_z))).mean()
+            elif phase == "Greg":  l = self.G[0](gen_z).square().mean()                      # touches only the first layer
+            elif phase == "Dmain": l = torch.nn.functional.softplus(self.D(self.G(gen_z).detach())).mean() + torch.nn.functional.softplus(-self.D(real_img.flatten(1))).mean()
+            else:                  l = self.D(real_img.flatten(1)).square().mean()
+            (l * gain / self.wm).backward()
+kw = dict(lr=0.01, betas=(0.0, 0.99), eps=1e-8)
+def run(rank_data, world_mean, G, D):
+    torch.manual_seed(123)                       # same latents on every rank / in the reference run
+    phases = ts.make_phases(G, D, kw, kw, g_reg_interval=2, d_reg_interval=3)
+    return ts.train(G, D, copy.deepcopy(G), Loss(G, D, world_mean), iter(rank_data), phases, z_dim=6, batch_size=8, batch_gpu=4, total_kimg=1)
+data = [[torch.randn(4, 3, 2, 2, generator=torch.Generator().manual_seed(100 * k + it)) for it in range(4)] for k in range(2)]
+G, D = nets()
+run(data[r], 1.0, G, D)
+flat = torch.cat([p.reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+both = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1])
+dist.destroy_process_group()
+print("rank", r, "ok", float(flat.abs().sum()))
+'''
+    port = str(35500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f'rank {rank} ok' in o, o
+    assert outs[0].split()[-1] == outs[1].split()[-1]
