@@ -128,6 +128,22 @@ __global__ __launch_bounds__(256) void copy4_kernel(const float* x, float* y, lo
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = 2.f * x[i];
 }
+
+// epilogue-like store pattern: every wave-instruction writes 8 whole 128-byte lines (8 lanes x 16 B each) that lie `rowB` bytes apart
+// (the 4x4-block rows of a convolution tile); NT: nontemporal stores
+template <int NT>
+__global__ __launch_bounds__(512) void wtile_kernel(char* y, int reps, long rowB, long tileB) {
+    const long wg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = 0; r < reps; ++r) {
+        // wave w, instruction r: lines (lane / 8) of "row" r*8*8 + w*8 + lane/8
+        const long line = (long)(r * 64 + wave * 8 + (lane >> 3));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f* d = reinterpret_cast<v4f*>(y + wg * tileB + line * rowB + (lane & 7) * 16);
+        const v4f v = {1.f, 2.f, 3.f, (float)r};
+        if (NT) __builtin_nontemporal_store(v, d); else *d = v;
+    }
+}
 template <int LB>
 __global__ __launch_bounds__(256) void wpat_kernel(char* y, int rows, long pitchB, int order, long nw) {
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -142,6 +158,24 @@ __global__ __launch_bounds__(256) void wpat_kernel(char* y, int rows, long pitch
 }
 int main(int argc, char** argv) {
     if (argc > 1 && argv[1][0] == 'u') { up_cases(); return 0; }
+    if (argc > 1 && argv[1][0] == 't') {
+        // 256 workgroups (one per CU) x 512 threads, each writing a 128 KB "tile" as 16 x 64 lines of 128 B, 2 KB apart
+        const long nwg = 8192, rowB = 2048, tileB = 16 * 64 * rowB;
+        char* y; CK(hipMalloc(&y, nwg * tileB + 4096));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int nt = 0; nt < 2; ++nt) {
+            auto go = [&]() { if (nt) hipLaunchKernelGGL(wtile_kernel<1>, dim3(nwg), dim3(512), 0, 0, y, 16, rowB, tileB);
+                              else hipLaunchKernelGGL(wtile_kernel<0>, dim3(nwg), dim3(512), 0, 0, y, 16, rowB, tileB); };
+            go();
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 10; ++i) go();
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double bytes = (double)nwg * 16 * 64 * 128;
+            printf("wtile nt=%d: %.1f us  %.2f TB/s  (%.1f B/clk/CU at 2.1 GHz)\n", nt, ms * 100, bytes / (ms * 100) / 1e6, bytes / (ms * 1e-4) / 256 / 2.1e9);
+        }
+        return 0;
+    }
     {
         const long nw = 16384; const int rows = 64;
         char* y; CK(hipMalloc(&y, nw * rows * 1152 + 4096));
