@@ -279,6 +279,7 @@ WINO4_CASES = [
     (2, 64, 64, 32, 32), (1, 13, 70, 33, 36), (3, 8, 3, 40, 64), (2, 72, 130, 35, 68), (1, 128, 64, 64, 96), (2, 5, 5, 32, 44),
     (1, 512, 96, 48, 32),     # 64 K-chunks: the style table spans a whole wave
     (1, 16, 16, 32, 33), (2, 16, 16, 16, 32),      # W % 4 != 0 -> direct kernel; fewer than WINO4_MIN rows -> F(2x2,3x3)
+    (1, 24, 70, 21, 132), (2, 16, 64, 32, 128), (1, 8, 8, 40, 200),      # W >= 128: the 8 x 64 tile shape, ragged in both directions
 ]
 
 
