@@ -546,19 +546,19 @@ extern "C" int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, i
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
-#ifndef SHG_W4_WIDE
-#define SHG_W4_WIDE 1
-#endif
-    // tile shape: 8 rows x 64 pixels where the image is wide enough -- the same window area as 16 x 32 (10 x 72 against 18 x 40
-    // floats per channel), but every output row piece is 256 contiguous bytes instead of 128
-    // (syn512.conv1 1286 -> 1237 us, 256^2 layers 1037 -> 1004, 128^2 881 -> 867; at W = 64 no gain: 809 vs 813)
-    const bool wide = SHG_W4_WIDE && W >= 128 && H >= 8;
-    p.tiles_x = shg_cdiv(W, wide ? 64 : 32); p.tiles_y = shg_cdiv(H, wide ? 8 : 16);
+    // tile shape: the same 32 blocks as 16 x 32 pixels, 8 x 64 for W >= 128 or 4 x 128 for W >= 256.  The 8 x 64 window has the
+    // same area as the 16 x 32 one (10 x 72 against 18 x 40 floats per channel), the 4 x 128 one a fourth piece per channel
+    // (6 x 136), but every output row piece is 256 / 512 contiguous bytes instead of 128, which is what the store path wants
+    // (DESIGN section 5): syn512.conv1 1286 -> 1237 -> 1226 us, 256^2 layers 1037 -> 1004 -> 990; at W = 64 no gain (809 vs 813).
+    const int shape = (W >= 256 && H >= 4) ? 2 : ((W >= 128 && H >= 8) ? 1 : 0);
+    p.tiles_x = shg_cdiv(W, 32 << shape); p.tiles_y = shg_cdiv(H, 16 >> shape);
     p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino4::KC);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
-    if (wide) hipLaunchKernelGGL((conv_wino4_kernel<2, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(wino4::NT), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_wino4_kernel<4, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(wino4::NT), 0, (hipStream_t)stream, p);
+    const dim3 grid(p.n_ttiles * p.n_otiles);
+    if (shape == 2) hipLaunchKernelGGL((conv_wino4_kernel<1, 32>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
+    else if (shape == 1) hipLaunchKernelGGL((conv_wino4_kernel<2, 16>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wino4_kernel<4, 8>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -280,6 +280,7 @@ WINO4_CASES = [
     (1, 512, 96, 48, 32),     # 64 K-chunks: the style table spans a whole wave
     (1, 16, 16, 32, 33), (2, 16, 16, 16, 32),      # W % 4 != 0 -> direct kernel; fewer than WINO4_MIN rows -> F(2x2,3x3)
     (1, 24, 70, 21, 132), (2, 16, 64, 32, 128), (1, 8, 8, 40, 200),      # W >= 128: the 8 x 64 tile shape, ragged in both directions
+    (1, 16, 70, 18, 260), (2, 8, 64, 16, 256),                           # W >= 256: the 4 x 128 tile shape
 ]
 
 
