@@ -746,12 +746,13 @@ extern "C" int shg_conv2d_down_poly_f32(const float* xp, const float* wu_a, cons
     else hipLaunchKernelGGL((conv_poly_down_kernel<poly::DA, 8, 8, 0>), ga, dim3(poly::NT), 0, s, p);
     SHG_CHECK_LAUNCH();
     // scheme DB: 2x2 output blocks + the layer tail
-    const bool bwide = OW >= 32;
+    const bool bwide = OW >= 32, bxwide = OW >= 64;          // 4 x 16 blocks = 8 x 32 pixels; 2 x 32 blocks = 4 x 64 pixels (256-byte rows)
     p.b.wu = wu_b; p.b.nby = OH / 2; p.b.nbx = OW / 2;
-    p.b.tiles_x = shg_cdiv(p.b.nbx, bwide ? 16 : 8); p.b.tiles_y = shg_cdiv(p.b.nby, bwide ? 4 : 8);
+    p.b.tiles_x = shg_cdiv(p.b.nbx, bxwide ? 32 : (bwide ? 16 : 8)); p.b.tiles_y = shg_cdiv(p.b.nby, bxwide ? 2 : (bwide ? 4 : 8));
     p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
     const dim3 gb(p.b.n_ttiles * p.n_otiles);
-    if (bwide) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 4, 16, 0>), gb, dim3(poly::NT), 0, s, p);
+    if (bxwide) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 2, 32, 0>), gb, dim3(poly::NT), 0, s, p);
+    else if (bwide) hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 4, 16, 0>), gb, dim3(poly::NT), 0, s, p);
     else hipLaunchKernelGGL((conv_poly_down_kernel<poly::DB, 8, 8, 0>), gb, dim3(poly::NT), 0, s, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
