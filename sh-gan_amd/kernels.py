@@ -185,7 +185,7 @@ def sep_taps(f):
     taps = None
     if np.isfinite(fh).all() and abs(tot) > 1e-30:
         fy, fx = fh.sum(1), fh.sum(0) / tot
-        if np.abs(np.outer(fy, fx) - fh).max() <= 1e-7 * np.abs(fh).max():
+        if np.abs(np.outer(fy, fx) - fh).max() <= 5e-7 * np.abs(fh).max():      # (fp32 rounding of an outer product: ~1e-7)
             taps = (ctypes.c_float * 8)(*[float(v) for v in fx], *[float(v) for v in fy])
     try:
         f._shg_sep = (key, taps)

@@ -109,7 +109,8 @@ def test_fir_march_pad2_vs_oracle_and_tiled_kernel(mods, shape):
                 assert lib.shg_fir_pad2_sep_supported(h, w, (w // 2 + 1 + 3) // 4 * 4) == 1
                 for pp in ((w // 2 + 1 + 3) // 4 * 4, (w // 2 + 1 + 31) // 32 * 32):
                     xp = torch.full((4, n, ch, h // 2 + 1, pp), float('nan'), device=DEV)
-                    K.check(lib.shg_fir_pad2_sep_f32(K._ptr(x.to(DEV)), K.sep_taps(fd), K._ptr(xp), n, ch, h, w, pp, int(flip), 1.5,
+                    xd = x.to(DEV)                 # (kept alive across the raw C call)
+                    K.check(lib.shg_fir_pad2_sep_f32(K._ptr(xd), K.sep_taps(fd), K._ptr(xp), n, ch, h, w, pp, int(flip), 1.5,
                                                      None), 'fir_pad2_sep')
                     full = np.zeros((n, ch, 2 * (h // 2 + 1), 2 * pp), np.float32)
                     full[:, :, :h + 1, :w + 1] = ref
