@@ -26,6 +26,9 @@ for case in range(n_cases):
     co = int(rs.choice([3, 16, 33, 64, 70, 128, 192]))
     h = int(rs.choice([4, 7, 8, 16, 31, 32, 33, 40, 64, 68]))
     w = int(rs.choice([4, 8, 12, 16, 31, 32, 36, 44, 64, 65]))
+    if kind == 'same' and rs.rand() < 0.4:      # wide images: the 8 x 64 and 4 x 128 tile shapes of the F(4x4) kernel
+        w, h = int(rs.choice([128, 132, 200, 256, 260])), int(rs.choice([8, 12, 20, 33]))
+        ci, co, n = int(rs.choice([8, 16, 24])), int(rs.choice([16, 64, 70])), int(rs.choice([1, 2]))
     x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
     if kind == 'fir':
         f = torch.from_numpy(rs.rand(4, 4).astype(np.float32))
