@@ -581,3 +581,51 @@ def test_conv2d_gradfix_surface(mods):
     wt = torch.from_numpy(rs.standard_normal((6, 8, 3, 3)).astype(np.float32))
     y = mods['gradfix'].conv_transpose2d(x.to(DEV), wt.to(DEV), stride=2)
     assert rel_err(c(y), F.conv_transpose2d(x, wt, stride=2).numpy()) < 2e-5
+
+
+def test_fir_march_at_baseline_sizes_vs_tiled_kernels(mods):
+    """The marching FIR kernels at the layer sizes of BASELINE config 3 (512 x 512, batch 16: 64 channels at 512^2 ... 512 at 64^2)
+    against the tiled kernels they replace (which the oracle tests above pin), plus the size-independent checks the domain offers:
+    a constant image filters to the filter's DC gain away from the border, and the polyphase planes re-interleave to the plain result."""
+    K, ufd, orc = mods['kernels'], mods['ufd'], mods['orc']
+    f = orc.setup_filter([1, 3, 3, 1]).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for ch, r in ((64, 512), (128, 256), (256, 128), (512, 64)):
+        x = torch.randn(16, ch, r, r, device=DEV, generator=g)
+        y = ufd.upfirdn2d(x, f, padding=[2, 2, 2, 2])
+        K.FIR_MARCH = False
+        try:
+            y_old = ufd.upfirdn2d(x, f, padding=[2, 2, 2, 2])
+        finally:
+            K.FIR_MARCH = True
+        assert float((y - y_old).abs().max()) < 2e-6 * float(y_old.abs().max())
+        # planes of fir_conv_down2's first half == the plain result, re-interleaved
+        lib = K._lib.get_lib()
+        pp = (r // 2 + 1 + 31) // 32 * 32 if r % 256 == 0 else (r // 2 + 1 + 3) // 4 * 4
+        xp = torch.empty((4, 16, ch, r // 2 + 1, pp), device=DEV)
+        K.check(lib.shg_fir_pad2_sep_f32(K._ptr(x), K.sep_taps(f), K._ptr(xp), 16, ch, r, r, pp, 0, 1.0, None), 'fir_pad2_sep')
+        for a in range(2):
+            for b in range(2):
+                d = xp[a * 2 + b][:, :, :(r + 2 - a) // 2, :(r + 2 - b) // 2] - y[:, :, a::2, b::2]      # (two kernels: FMA contraction differs)
+                assert float(d.abs().max()) < 1e-6 * float(y.abs().max())
+        assert float(xp[1][:, :, :, r // 2:].abs().max()) == 0.0 and float(xp[2][:, :, r // 2:].abs().max()) == 0.0
+        del xp, y, y_old
+        # FIR-from-planes with the whole tail, low-resolution r/2 -> r
+        h = r // 2
+        mid = torch.randn(4, 16, ch, h + 1, h + 1, device=DEV, generator=g)
+        kw = dict(scale=torch.rand(16 * ch, device=DEV, generator=g) + 0.5, bias=torch.randn(ch, device=DEV, generator=g),
+                  noise=torch.randn(16, 1, r, r, device=DEV, generator=g), residual=torch.randn(16, ch, r, r, device=DEV, generator=g))
+        z = K.upfir_planar(mid, f, noise_strength=0.3, act=True, **kw)
+        K.FIR_MARCH = False
+        try:
+            z_old = K.upfir_planar(mid, f, noise_strength=0.3, act=True, **kw)
+        finally:
+            K.FIR_MARCH = True
+        assert float((z - z_old).abs().max()) < 2e-6 * float(z_old.abs().max())
+        del mid, kw, z, z_old, x
+    ones = torch.ones(2, 3, 256, 256, device=DEV)
+    yc = ufd.upfirdn2d(ones, f, padding=[2, 2, 2, 2])
+    assert float((yc[:, :, 2:-2, 2:-2] - 1.0).abs().max()) < 1e-6            # [1,3,3,1] x [1,3,3,1] / 64 sums to 1
+    yd = ufd.upfirdn2d(ones, f, down=2, padding=[1, 1, 1, 1])
+    yu = ufd.upfirdn2d(ones[:, :, :128, :128], f, up=2, padding=[2, 1, 2, 1], gain=4)
+    assert float((yd[:, :, 1:-1, 1:-1] - 1.0).abs().max()) < 1e-6 and float((yu[:, :, 2:-2, 2:-2] - 1.0).abs().max()) < 1e-6
