@@ -120,7 +120,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         store_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);
-#pragma unroll 2
         for (int ks = grp; ks < PX / 2; ks += 2) {               // the two wave groups take alternate k-steps
             const int k = 2 * ks + half;                         // pixel of this lane's operand row
             const float a = Gs[k * CP + mo * 32 + l31];
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradPa
                 if (dst[j] >= 0) Xs[dst[j]] = v[j];
         }
         __syncthreads();
-#pragma unroll 2
         for (int ks = grp; ks < PX / 2; ks += 2) {
             const int k = 2 * ks + half;
             const float a = Gs[k * CP + mo * 32 + l31];

@@ -377,7 +377,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         // p+1 are issued BEFORE the stores of pass p: a conditional load makes the compiler wait with vmcnt(0), and on this chip
         // vmcnt also counts stores -- the tail then waited for its own previous row to reach memory (1200 cycles per row, 5000 of a
         // pass's 6500).  Out-of-range rows / channels are clamped for the loads and masked for the stores.
-        const ShgAct actc = shg_act_make(p.act, p.alpha, p.gain, p.clamp);
         const bool col_ok = oy < p.H && ox < p.W;
         const int oxc = ox < p.W ? ox : 0;
         long rowoff[4];
