@@ -627,8 +627,8 @@ class discrim_epilogue(nn.Module):
             x = self.mbstd(x)
         x = self.conv(x)
         x = self.out(self.fc(x.flatten(1)))
-        if self.cmap_dim is not None:
-            raise NotImplementedError('conditional projection (c_dim > 0) is not used by any shipped SH-GAN config')
+        if self.cmap_dim is not None:        # conditional projection (stylegan.py:752-753): [N, cmap_dim] x [N, cmap_dim] -> [N, 1]
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
         return x
 
 
@@ -647,8 +647,6 @@ class Discriminator(nn.Module):
             raise ValueError
         if use_fp16_before_res is not None and resolution > use_fp16_before_res:
             raise NotImplementedError('the HIP path is fp32: pass use_fp16_before_res=None (as all shipped configs do)')
-        if c_dim is not None and c_dim > 0:
-            raise NotImplementedError('label-conditioned critics are not used by any shipped SH-GAN config')
         self.encode_res = [2 ** i for i in range(log2res, 1, -1)]
         self.ic_n, self.ch_base, self.ch_max = ic_n, ch_base, ch_max
         self.resample_filter, self.activation = resample_filter, activation
@@ -658,6 +656,10 @@ class Discriminator(nn.Module):
                                                           resample_filter=resample_filter, activation=activation,
                                                           reslink=True, use_fp16=False))
         self.mapping = None
+        if c_dim is not None and c_dim > 0:
+            # the reference cannot build this either: its Mapping passes an unknown keyword to `dense` when c_dim > 0
+            # (stylegan.py:377), and its critic builds the epilogue without the projection (cmap_dim=None, :818-825)
+            raise NotImplementedError('label-conditioned critics: the reference constructor fails for c_dim > 0 (stylegan.py:377)')
         c4 = min(ch_base // self.encode_res[-1], ch_max)
         self.b4 = discrim_epilogue(c4, resolution=4, cmap_dim=None, activation=activation,
                                    mbstd_group_size=mbstd_group_size, mbstd_c_n=mbstd_c_n)
@@ -666,4 +668,5 @@ class Discriminator(nn.Module):
         x = None
         for res in self.encode_res[0:-1]:
             x, img = getattr(self, 'b{}'.format(res))(x, img)
-        return self.b4(x, img, None)
+        cmap = self.mapping(None, c) if self.mapping is not None else None
+        return self.b4(x, img, cmap)

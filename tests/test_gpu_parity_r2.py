@@ -262,6 +262,18 @@ def test_discriminator_forward_golden(mods):
         assert rel_err(c(logits), g[f'logits{n}']) < 1e-4, n
 
 
+def test_discriminator_epilogue_conditional_projection_golden(mods):
+    """`discrim_epilogue` with `cmap_dim` (stylegan.py:707-755): fromrgb + minibatch-std + conv + fc + out and the projection on the
+    label embedding, against the reference; the label-conditioned critic itself raises (the reference's constructor does too)."""
+    g = load_golden('discriminator_conditional')
+    sg = mods['stylegan']
+    ep = _load_sd(sg.discrim_epilogue(16, resolution=4, cmap_dim=8, rgb_n=3, mbstd_group_size=2, mbstd_c_n=1), g, 'sd__')
+    out = ep(torch.from_numpy(g['x4']).to(DEV), torch.from_numpy(g['img4']).to(DEV), torch.from_numpy(g['cmap']).to(DEV))
+    assert tuple(out.shape) == (4, 1) and rel_err(c(out), g['proj']) < 1e-4
+    with pytest.raises(NotImplementedError):
+        sg.Discriminator(resolution=16, ic_n=3, ch_base=128, ch_max=16, use_fp16_before_res=None, c_dim=5, cmap_dim=8)
+
+
 POLY_UP_CASES = [
     # n, ci, co, h, w: ragged channel counts (I % 8, O % 64), several tiles per image, both tile shapes of both schemes
     (2, 16, 64, 32, 32), (1, 13, 70, 34, 40), (2, 72, 130, 64, 64), (1, 8, 3, 32, 128), (3, 24, 24, 66, 36), (1, 128, 64, 128, 128),

@@ -468,6 +468,22 @@ def gen_discriminator():
     save('discriminator', **out)
 
 
+def gen_discriminator_conditional():
+    """stylegan.py:707-755: the epilogue's conditional projection `(x * cmap).sum(1) / sqrt(cmap_dim)` (the label-conditioned
+    critic itself cannot be built in the reference: Mapping(c_dim > 0) passes an unknown keyword to dense, stylegan.py:377)."""
+    torch.manual_seed(2031)
+    ep = stylegan.discrim_epilogue(16, resolution=4, cmap_dim=8, rgb_n=3, mbstd_group_size=2, mbstd_c_n=1,
+                                   activation=ACT).eval().requires_grad_(False)
+    for n_, p_ in ep.named_parameters():
+        if n_.endswith('.bias'):
+            p_.copy_(torch.randn_like(p_) * 0.1)
+    out = _sd_arrays(ep)
+    x4, img4, cmap = torch.randn(4, 16, 4, 4), torch.randn(4, 3, 4, 4), torch.randn(4, 8)
+    out['x4'], out['img4'], out['cmap'] = x4.numpy(), img4.numpy(), cmap.numpy()
+    out['proj'] = ep(x4, img4, cmap).numpy()
+    save('discriminator_conditional', **out)
+
+
 def gen_generator_grads():
     """Training row N3: gradients of a scalar functional of the generator output (sum(img * r) / N, noise_mode='const', dropout
     off) with respect to EVERY generator parameter and to z, through the reference's own modules under autograd at reduced width
@@ -559,7 +575,8 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
-            discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads)
+            discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
+            discriminator_conditional=gen_discriminator_conditional)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
