@@ -44,13 +44,39 @@ class one_hot_2d(object):
         return oh
 
 
+def _interp_matrix(pos, size, kind):
+    """[len(pos), size] weights of `F.grid_sample(..., padding_mode='border', align_corners=True)` along one axis for pixel
+    coordinates `pos` (already clipped to [0, size-1]): the bilinear hat, or the cubic convolution kernel (A = -0.75) on the four
+    taps floor(p)-1 .. floor(p)+2 with out-of-range taps clamped to the border."""
+    m = np.zeros((len(pos), size), dtype=np.float64)
+    if kind == 'piecewise_linear':
+        for j in range(size):
+            m[:, j] = np.clip(1 - np.abs(pos - j), 0, 1)
+        return m
+    A = -0.75
+    i0 = np.floor(pos).astype(np.int64)
+    t = pos - i0
+
+    def c1(x):                     # |x| <= 1
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def c2(x):                     # 1 < |x| < 2
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    coef = [c2(t + 1), c1(t), c1(1 - t), c2(2 - t)]
+    for k in range(4):
+        idx = np.clip(i0 - 1 + k, 0, size - 1)
+        np.add.at(m, (np.arange(len(pos)), idx), coef[k])
+    return m
+
+
 def make_cweight(half_size, half_sample, type='piecewise_linear', oddeven_aligned=True, device='cpu'):
     """Band-weight table cw[h0*w0, hs, ws] (shgan.py:70-121): every cell of an h0 x w0 control grid
-    is a one-hot image, mirrored along w so it spans [-1,1], and sampled bilinearly
+    is a one-hot image, mirrored along w so it spans [-1,1], and sampled bilinearly or bicubically
     (align_corners, border clamp) at rows -1+2(i+1)/hs (even hs, 'oddeven aligned') and columns
-    i/(ws-1).  Evaluated here in closed form with numpy -- the result is a partition of unity."""
-    if type != 'piecewise_linear':
-        raise NotImplementedError("only the 'piecewise_linear' heterogeneous filter is implemented")
+    i/(ws-1).  Evaluated here in closed form with numpy (both interpolations are separable) -- the result is a
+    partition of unity."""
+    if type not in ('piecewise_linear', 'bicubic'):
+        raise NotImplementedError("heterogeneous filter types: 'piecewise_linear', 'bicubic' (shgan.py:113-120)")
     h0, w0 = half_size
     hs, ws = half_sample
     wpad = 2 * w0 - 1                                    # reflect pad on the left by w0-1
@@ -62,16 +88,16 @@ def make_cweight(half_size, half_sample, type='piecewise_linear', oddeven_aligne
     # align_corners=True: pixel coordinate = (g+1)/2 * (size-1)
     py = np.clip((gy.astype(np.float32).astype(np.float64) + 1) / 2 * (h0 - 1), 0, h0 - 1)
     px = np.clip((gx.astype(np.float32).astype(np.float64) + 1) / 2 * (wpad - 1), 0, wpad - 1)
+    my, mx = _interp_matrix(py, h0, type), _interp_matrix(px, wpad, type)      # [hs, h0], [ws, wpad]
     cw = np.zeros((h0 * w0, hs, ws), dtype=np.float64)
     for a in range(h0):
-        wy = np.clip(1 - np.abs(py - a), 0, 1)           # bilinear hat along h
         for b in range(w0):
             # padded columns: index j in [0, wpad) maps to original column |j - (w0-1)|
             wx = np.zeros(ws)
             for j in range(wpad):
                 if abs(j - (w0 - 1)) == b:
-                    wx += np.clip(1 - np.abs(px - j), 0, 1)
-            cw[a * w0 + b] = wy[:, None] * wx[None, :]
+                    wx += mx[:, j]
+            cw[a * w0 + b] = my[:, a][:, None] * wx[None, :]
     return torch.tensor(cw, dtype=torch.float32, device=device)
 
 
@@ -83,7 +109,7 @@ class heterogeneous_filter(nn.Module):
     def __init__(self, in_channels, out_channels, freedom, type, init='ones'):
         super().__init__()
         self.in_channels, self.out_channels, self.freedom, self.type = in_channels, out_channels, freedom, type
-        if type not in ('piecewise_linear',):
+        if type not in ('piecewise_linear', 'bicubic'):       # (shgan.py:133-137)
             raise NotImplementedError
         fh, fw = freedom
         self.weight = nn.Parameter(torch.empty(in_channels, out_channels * fh * fw), requires_grad=True)

@@ -532,6 +532,13 @@ def test_shu_golden(mods):
     out = shu(x)
     for r in (4, 8, 16, 32, 64):
         assert rel_err(c(out[r]), gd[f'shu__y{r}']) < TOL, r
+    # the same unit on bicubic band weights (shu_df_type='bicubic')
+    shu_b = shgan.SHU(32, 32, [2, 3], 'bicubic', input_res=64, lowest_res=4, tail_sigma_mult=3)
+    shu_b.load_state_dict(shu.state_dict(), strict=True)
+    out_b = shu_b.to(DEV).eval()(x)
+    for r in (4, 8, 16, 32, 64):
+        assert rel_err(c(out_b[r]), gd[f'shu_bicubic__y{r}']) < TOL, r
+        assert rel_err(c(out_b[r]), gd[f'shu__y{r}']) > 1e-3              # (and it is a different filter)
     # spectrum alone against torch.fft on the CPU
     t = c(mods['kernels'].shu_rfft2_shift(x))
     sp = torch.fft.rfftn(torch.from_numpy(gd['shu__x']), dim=(2, 3), norm='forward')

@@ -76,6 +76,11 @@ def test_constant_tables_match_reference():
     g = load_golden('shu')
     cw = shgan.make_cweight([2, 3], (64, 33))
     assert np.abs(cw.numpy() - g['cweight_2x3_64x33']).max() < 1e-6
+    # the bicubic sampling of the control grid (shgan.py:116-118), closed form vs F.grid_sample of the reference
+    assert np.abs(shgan.make_cweight([2, 3], (64, 33), type='bicubic').numpy() - g['cweight_bicubic_2x3_64x33']).max() < 2e-6
+    assert np.abs(shgan.make_cweight([3, 2], (16, 9), type='bicubic').numpy() - g['cweight_bicubic_3x2_16x9']).max() < 2e-6
+    with pytest.raises(NotImplementedError):
+        shgan.make_cweight([2, 3], (64, 33), type='nearest')
     shu = shgan.SHU(32, 32, [2, 3], 'piecewise_linear', input_res=64, lowest_res=4, tail_sigma_mult=3)
     for r in (4, 8, 16, 32, 64):
         assert np.abs(shu.gaussian_weight_map[r].numpy() - g[f'gauss_{r}']).max() < 1e-7

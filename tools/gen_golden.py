@@ -247,6 +247,15 @@ def gen_shu():
     with torch.no_grad():
         out['hf__y'] = hf(t).numpy()
     out['hf__x'] = t.numpy()
+    # the bicubic band weights (shgan.py:116-118) and a SHU built on them
+    out['cweight_bicubic_2x3_64x33'] = shgan.make_cweight([2, 3], (64, 33), type='bicubic').numpy()
+    out['cweight_bicubic_3x2_16x9'] = shgan.make_cweight([3, 2], (16, 9), type='bicubic').numpy()
+    shu_b = shgan.SHU(32, 32, [2, 3], 'bicubic', input_res=64, lowest_res=4, tail_sigma_mult=3, gaussian_at_input_res=False).eval()
+    shu_b.load_state_dict(sub, strict=True)
+    with torch.no_grad():
+        yb = shu_b(x)
+    for r, t in yb.items():
+        out[f'shu_bicubic__y{r}'] = t.numpy()
     save('shu', **out)
 
 
