@@ -2,4 +2,4 @@
 ``shgan_amd`` through the alias module at the repository root)."""
 from . import _lib  # noqa: F401
 
-__all__ = ['_lib', 'kernels', 'model_zoo', 'eval_harness', 'configs', 'masks', 'fid_stats', 'grad_sync', 'losses', 'train_stage']
+__all__ = ['_lib', 'kernels', 'model_zoo', 'eval_harness', 'configs', 'masks', 'fid_stats', 'grad_sync', 'losses', 'train_stage', 'datasets']
