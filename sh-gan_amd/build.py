@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libshgan_hip.so'
+VARDIR = os.path.join(os.path.dirname(HERE), 'tools', '_variants')      # study builds (-DSHG_ABLATE, A/B knobs) live with the tools, never beside the product library
 SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-inline-asm']
 
@@ -40,8 +41,8 @@ def _digest(extra=()):
 
 def lib_path(ablate=False, variant=None):
     if variant:
-        return os.path.join(LIBDIR, f'libshgan_hip_{variant}.so')
-    return os.path.join(LIBDIR, 'libshgan_hip_ablate.so' if ablate else LIBNAME)
+        return os.path.join(VARDIR, f'libshgan_hip_{variant}.so')
+    return os.path.join(VARDIR, 'libshgan_hip_ablate.so') if ablate else os.path.join(LIBDIR, LIBNAME)
 
 
 def build(force=False, verbose=True, ablate=False, variant=None, defines=()):
@@ -49,10 +50,12 @@ def build(force=False, verbose=True, ablate=False, variant=None, defines=()):
     that make kernels skip work) as a SEPARATE library for tools/; the product library has no such switches.
     ``variant='name', defines=['-DX=1']`` builds libshgan_hip_<name>.so with extra compile-time knobs for A/B runs in tools/."""
     os.makedirs(LIBDIR, exist_ok=True)
+    outdir = VARDIR if (ablate or variant) else LIBDIR
+    os.makedirs(outdir, exist_ok=True)
     extra = (['-DSHG_ABLATE'] if ablate else []) + list(defines)
     if variant:
         ablate = True            # (shares the .abl.o object names / separate stamp below)
-    stamp = os.path.join(LIBDIR, f'.build_digest_{variant}' if variant else ('.build_digest_ablate' if ablate else '.build_digest'))
+    stamp = os.path.join(outdir, f'.build_digest_{variant}' if variant else ('.build_digest_ablate' if ablate else '.build_digest'))
     dig = _digest(extra)
     if not force and os.path.exists(lib_path(ablate, variant)) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         if verbose:
@@ -62,7 +65,7 @@ def build(force=False, verbose=True, ablate=False, variant=None, defines=()):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace('.hip', (f'.{variant}.o' if variant else '.abl.o') if ablate else '.o'))
+        obj = os.path.join(outdir, src.replace('.hip', (f'.{variant}.o' if variant else '.abl.o') if ablate else '.o'))
         objs.append(obj)
         cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:

@@ -281,9 +281,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
 #ifdef SHG_W4_PRIO
         if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
 #endif
-#ifdef SHG_W4_PRIO
-        if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
-#endif
         W4_TRACE_T(1);
         const int last = p.nchunk - 1;
         auto fetch = [&](const float* bb, int ks, int pb) __attribute__((always_inline)) {

@@ -6,9 +6,9 @@ import torch
 import shgan_amd
 from shgan_amd import _lib, kernels as kk
 if os.environ.get('SHG_VARIANT'):     # A/B runs: python sh-gan_amd/build.py --variant=<name> -DKNOB=1
-    _lib.use_library(os.path.join(os.path.dirname(_lib.LIB_PATH), 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 if os.environ.get('SHG_ABLATE'):      # timing studies: the -DSHG_ABLATE build (python sh-gan_amd/build.py --ablate) honours SHG_*_DBG
-    _lib.use_library(os.path.join(os.path.dirname(_lib.LIB_PATH), 'libshgan_hip_ablate.so'))
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_ablate.so'))
 
 N = 16
 # name, I, O, H(in), mode, modulated

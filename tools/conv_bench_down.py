@@ -6,7 +6,7 @@ import torch
 import shgan_amd
 from shgan_amd import _lib, kernels as kk
 if os.environ.get('SHG_VARIANT'):     # A/B runs: python sh-gan_amd/build.py --variant=<name> -DKNOB=1
-    _lib.use_library(os.path.join(os.path.dirname(_lib.LIB_PATH), 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd.model_zoo.stylegan_utils import upfirdn2d as ufd
 
 N = 16

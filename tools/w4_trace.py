@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import shgan_amd
 from shgan_amd import _lib, kernels as kk
-path = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libshgan_hip_%s.so' % os.environ.get('SHG_VARIANT', 'trace'))
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ.get('SHG_VARIANT', 'trace'))
 _lib.use_library(path)
 lib = ctypes.CDLL(path)
 N, ci, co, h = int(os.environ.get("NB", 16)), int(os.environ.get('CI', 512)), int(os.environ.get('CO', 512)), int(os.environ.get('H', 64))

@@ -3,14 +3,15 @@
 # (A/B timing runs: SHG_VARIANT=<tag> python tools/wino4_check.py).  usage: tools/w4_variant.sh <tag> [-DKNOB=1 ...]
 set -e
 cd "$(dirname "$0")/../sh-gan_amd"
+V=../tools/_variants
 TAG=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -Wno-inline-asm"
-mkdir -p lib/objcache
+mkdir -p $V/objcache
 for f in csrc/*.hip; do
   b=$(basename $f .hip); [ $b = conv_wino4 ] && continue
-  if [ ! -f lib/objcache/$b.o ] || [ $f -nt lib/objcache/$b.o ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o lib/objcache/$b.o & fi
+  if [ ! -f $V/objcache/$b.o ] || [ $f -nt $V/objcache/$b.o ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o $V/objcache/$b.o & fi
 done
 wait
-/opt/rocm/bin/hipcc $FLAGS "$@" -c csrc/conv_wino4.hip -o lib/objcache/conv_wino4.$TAG.obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libshgan_hip_$TAG.so lib/objcache/*.o lib/objcache/conv_wino4.$TAG.obj
-echo built lib/libshgan_hip_$TAG.so
+/opt/rocm/bin/hipcc $FLAGS "$@" -c csrc/conv_wino4.hip -o $V/objcache/conv_wino4.$TAG.obj
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libshgan_hip_$TAG.so $V/objcache/*.o $V/objcache/conv_wino4.$TAG.obj
+echo built $V/libshgan_hip_$TAG.so
