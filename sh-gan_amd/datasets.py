@@ -92,7 +92,7 @@ class ImageOnlyFormatter:
 
 
 class RandomMaskFormatter:
-    """ds_ffhq.py:332-347: (x in [-1,1], mask [1,s,s] float32 with 1 = known, unique_id); the flip draw comes before the mask's."""
+    """ds_ffhq.py:332-347: (x in [-1,1], mask [s,s] float32 with 1 = known -- ``RandomMask(...)[0]``; the eval loop adds the channel axis, shgan_default.py:270 --, unique_id), s = ``mask_resolution`` which must equal the image resolution; the flip draw comes before the mask's."""
 
     def __init__(self, random_flip=True, mask_resolution=256, hole_range=(0, 1)):
         self.random_flip, self.mask_resolution, self.hole_range = random_flip, mask_resolution, list(hole_range)
@@ -154,7 +154,13 @@ class DeviceFeeder:
         if not self.device_masks:
             if mask is None:
                 raise ValueError('DeviceFeeder: the loader yields no masks and device_masks is off')
-            md = self._to_device(torch.as_tensor(np.asarray(mask), dtype=torch.float32).reshape(x.shape[0], 1, *x.shape[2:]).contiguous())
+            m = torch.as_tensor(np.asarray(mask), dtype=torch.float32)
+            if m.ndim == 4 and m.shape[1] == 1:
+                m = m[:, 0]
+            if tuple(m.shape) != (x.shape[0], x.shape[2], x.shape[3]):
+                raise ValueError(f'DeviceFeeder: masks {tuple(m.shape)} do not match the images {tuple(x.shape)} -- the formatter\'s '
+                                 f'mask_resolution must equal the image resolution ({x.shape[2]}x{x.shape[3]})')
+            md = self._to_device(m[:, None].contiguous())
         ev = None
         if self.copy_stream is not None:
             ev = torch.cuda.Event()

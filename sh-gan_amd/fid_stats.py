@@ -54,6 +54,22 @@ class FidStats:
         pos = (torch.arange(k0, k0 + b, device=feats.device) * world + rank)
         self.add(feats, (pos < sample_n).to(torch.float32))
 
+    def add_images(self, detector, images, k0=None, rank=0, world=1, sample_n=None):
+        """The detector hand-off of ``fid_evaluator.add_batch`` (eva_fid.py:194-206): ``images`` [B,3,H,W] in 0..255 (the uint8
+        composite of ``run_generator`` or ``real*127.5+127.5``, shgan_default.py:281-288) -> ``detector(images.float(),
+        return_features=True)`` -> moments.  ``detector`` is the caller's Inception-v3 TorchScript module (a download,
+        eva_fid.py:20,145-158: not shipped and not reproduced); any callable with that signature works.  With ``k0`` the batch
+        is this rank's items k0.. of its sampler list and padded duplicates beyond ``sample_n`` get weight 0 (``add_shard``)."""
+        with torch.no_grad():
+            feats = detector(images.to(self.device).float(), return_features=True)
+        if feats.ndim != 2 or feats.shape[1] != self.dim:
+            raise _lib.ShgError(f'FidStats.add_images: the detector returned {tuple(feats.shape)}, expected [B, {self.dim}]')
+        if k0 is None:
+            self.add(feats)
+        else:
+            self.add_shard(feats, k0, rank, world, sample_n)
+        return feats
+
     def all_reduce(self):
         """Sum the moments over all ranks (one collective per evaluation)."""
         import torch.distributed as dist
@@ -61,14 +77,18 @@ class FidStats:
             dist.all_reduce(self.S, op=dist.ReduceOp.SUM)
         return self
 
-    def mean_cov(self):
-        """-> (n, mu [dim], sigma [dim, dim]) numpy float64; sigma = E[x x^T] - mu mu^T as eva_fid.py:252-255."""
+    def mean_cov(self, sample_n=None):
+        """-> (n, mu [dim], sigma [dim, dim]) numpy float64; ``mu = mean``, ``sigma = x^T x / sample_n - mu mu^T`` as
+        eva_fid.py:252-255 (the reference divides the second moment by ``sample_n``, not by the row count; they differ only
+        when fewer than ``sample_n`` features exist -- default: the accumulated count)."""
         S = self.S.cpu().numpy()
         S = np.triu(S) + np.triu(S, 1).T                     # the kernel keeps tiles on / above the diagonal
         d = self.dim
         n = float(S[d, d])
+        if not n > 0:
+            raise ValueError('FidStats.mean_cov: no samples accumulated (empty accumulator, or every sample had weight 0)')
         mu = S[:d, d] / n
-        sigma = S[:d, :d] / n - np.outer(mu, mu)
+        sigma = S[:d, :d] / (n if sample_n is None else float(sample_n)) - np.outer(mu, mu)
         return n, mu, sigma
 
 

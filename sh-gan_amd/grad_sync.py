@@ -9,7 +9,11 @@ cannot overlap with the backward pass.  ``BucketedAllReduce`` therefore
     discriminator is 4 buckets, the 79 M-parameter generator 5), filled in REVERSE registration order -- the order in which
     backward produces gradients;
   * launches ``all_reduce(bucket, async_op=True)`` from a post-accumulate hook as soon as the last gradient of a bucket has
-    been written, i.e. while the rest of backward is still running (RCCL runs on its own stream);
+    been written, i.e. while the rest of backward is still running (RCCL runs on its own stream) -- but ONLY in a backward
+    pass that was announced with ``arm()``.  One phase runs several backward passes into the same buckets (Dgen then Dreal,
+    Gmain then Gpl, ``effective_batch_gpu`` rounds: ``stylegan_default_loss.py:64,72,93,104,126``) and the reference
+    suppresses DDP's reduction in all but the last (``misc.ddp_sync(module, sync)``, ``:32,43,49``); the loss arms the
+    buckets before exactly that backward.  Un-armed passes only accumulate;
   * ``finish()`` waits for the outstanding handles, divides by the world size and applies the StyleGAN2 sanitisation
     (``nan_to_num(nan=0, posinf=1e5, neginf=-1e5)``) in one pass per bucket.
 One process per GPU, backend ``nccl`` (= RCCL on ROCm); the CPU tests drive the same code over ``gloo``."""
@@ -32,6 +36,7 @@ class BucketedAllReduce:
         self._handles = []
         self._hooks = []
         self._touched = set()      # id(param) of the parameters that received a gradient since zero_grad()
+        self._armed = False        # True only inside the LAST backward pass of a phase (arm())
         cap = max(int(bucket_bytes) // 4, 1)
         cur, cur_n = [], 0
         groups = []
@@ -69,6 +74,8 @@ class BucketedAllReduce:
         if p.grad.data_ptr() != flat[off:off + n].data_ptr():            # autograd replaced the view (first accumulation)
             flat[off:off + n].copy_(p.grad.reshape(-1))
             p.grad = flat[off:off + n].view_as(p)
+        if not self._armed:                      # an earlier backward of the phase: accumulate only
+            return
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and self.reduce:
             self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
@@ -85,6 +92,16 @@ class BucketedAllReduce:
         self._pending = list(self._sizes)
         self._handles = []
         self._touched = set()
+        self._armed = False
+
+    def arm(self):
+        """Announce the last backward pass of the phase (the reference's ``sync=True`` forward under ``misc.ddp_sync``): from now on
+        a bucket is reduced as soon as every parameter in it has received THIS pass's gradient.  Buckets holding a parameter the
+        pass does not reach are reduced in ``finish()``."""
+        if self._armed:
+            raise RuntimeError('BucketedAllReduce.arm(): already armed -- finish() must run between two armed backward passes')
+        self._armed = True
+        self._pending = list(self._sizes)
 
     def untouched(self):
         """Parameters that received no gradient since ``zero_grad()`` -- their bucket slots hold zeros; an optimiser that must skip
@@ -92,8 +109,8 @@ class BucketedAllReduce:
         return [p for p in self.params if id(p) not in self._touched]
 
     def finish(self):
-        """Wait for the reductions of this backward pass; average, sanitise.  Buckets whose parameters did not all receive a
-        gradient (unused branches) are reduced here, synchronously."""
+        """Wait for the reductions launched by the armed backward pass; average, sanitise.  Buckets that were not launched (a
+        parameter the armed pass did not reach, or no armed pass at all) are reduced here, synchronously."""
         launched = {bi for bi, _ in self._handles}
         for bi, h in self._handles:
             h.wait()
@@ -106,6 +123,7 @@ class BucketedAllReduce:
                 torch.nan_to_num(flat, nan=0.0, posinf=1e5, neginf=-1e5, out=flat)
         self._handles = []
         self._pending = list(self._sizes)
+        self._armed = False
 
     def remove(self):
         for h in self._hooks:

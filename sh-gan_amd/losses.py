@@ -5,8 +5,10 @@ path-length regularisation on the generator, style mixing), so that the referenc
 
 What differs: gradients flow through this package's differentiable operators (``model_zoo/stylegan_utils/conv2d_gradfix.py``,
 ``grad_ops.py``, ``upfirdn2d.py`` -- convolution, FIR and activation forward and backward in HIP, twice differentiable);
-``sync`` is accepted and ignored (gradient reduction is ``grad_sync.BucketedAllReduce``, not DDP's implicit hooks, so there is
-nothing to suppress between accumulation rounds); an ADA ``augment_pipe`` is not supported; the statistics reporting of the
+``sync`` keeps the reference's meaning -- only the LAST backward pass of a phase call with ``sync=True`` may reduce gradients
+across ranks (``misc.ddp_sync``: Gmain ``sync and not do_Gpl``, Gpl ``sync``, Dgen never, Dreal ``sync``; ``:56-106``) -- and is
+delivered to ``grad_sync.BucketedAllReduce`` as ``self.grad_sync.arm()`` right before that backward (``grad_sync`` is set by the
+training stage per phase; None = single process); an ADA ``augment_pipe`` is not supported; the statistics reporting of the
 reference (``training_stats.report``) is replaced by ``self.stats``, a plain dict of the last values."""
 import numpy as np
 import torch
@@ -35,6 +37,11 @@ class StyleGAN2Loss(Loss):
         self.pl_mean = torch.zeros([], device=device)
         self.randn_like = torch.randn_like          # (tests substitute a fixed draw for the path-length noise)
         self.stats = {}
+        self.grad_sync = None                       # the running phase's BucketedAllReduce (train_stage.run_phases sets it)
+
+    def _arm(self, sync):
+        if sync and self.grad_sync is not None:
+            self.grad_sync.arm()
 
     # -- forward helpers (stylegan_default_loss.py:31-51) ----------------------------------------------------------------
     def run_G(self, z, c, sync=True):
@@ -43,10 +50,11 @@ class StyleGAN2Loss(Loss):
             # with probability p the rows from a random cutoff on come from a second latent
             cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
             cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
-            cut = int(cutoff)
-            if cut < ws.shape[1]:
-                ws2 = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
-                ws = torch.cat([ws[:, :cut], ws2[:, cut:]], dim=1)
+            # the second mapping always runs (stylegan_default_loss.py:39: same consumption of the device RNG stream whether or
+            # not mixing is drawn) and the rows are selected on the device -- no host sync on the cutoff
+            ws2 = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
+            rows = torch.arange(ws.shape[1], device=ws.device).reshape(1, -1, 1)
+            ws = torch.where(rows >= cutoff, ws2, ws)
         return self.G_synthesis(ws), ws
 
     def run_D(self, img, c, sync=True):
@@ -66,6 +74,7 @@ class StyleGAN2Loss(Loss):
                 gen_logits = self.run_D(gen_img, gen_c)
                 loss_Gmain = F.softplus(-gen_logits)                 # -log(sigmoid(logits))
                 self.stats.update({'Loss/scores/fake': gen_logits.detach(), 'Loss/G/loss': loss_Gmain.detach()})
+                self._arm(sync and not do_Gpl)                       # (may get synced by Gpl, :56)
                 loss_Gmain.mean().mul(gain).backward()
 
             if do_Gpl:                                               # path-length regularisation on a shrunk batch
@@ -81,6 +90,7 @@ class StyleGAN2Loss(Loss):
                 pl_penalty = (pl_lengths - pl_mean).square()
                 loss_Gpl = pl_penalty * self.pl_weight
                 self.stats.update({'Loss/pl_penalty': pl_penalty.detach(), 'Loss/G/reg': loss_Gpl.detach()})
+                self._arm(sync)
                 (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
 
             loss_Dgen = 0
@@ -108,4 +118,5 @@ class StyleGAN2Loss(Loss):
                     r1_penalty = r1_grads.square().sum([1, 2, 3])
                     loss_Dr1 = (r1_penalty * (self.r1_gamma / 2)).reshape(-1, 1)
                     self.stats.update({'Loss/r1_penalty': r1_penalty.detach(), 'Loss/D/reg': loss_Dr1.detach()})
+                self._arm(sync)                                      # Dgen's backward above never syncs (:87)
                 (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()

@@ -274,7 +274,19 @@ class Generator(Generator_StyleGan):
         self.encoder = encoder if isinstance(encoder, nn.Module) else get_model()(encoder)
         self.ic_n = self.encoder.ic_n
 
+    _warned_training_route = False
+
     def forward(self, x, z, c, truncation_psi=1, truncation_cutoff=None, noise_mode='random'):
+        if not self.training and not Generator._warned_training_route and torch.is_grad_enabled() \
+                and any(p.requires_grad for p in self.parameters()):
+            # Routes are chosen by grad mode (grad_ops.wants_grad), like autograd itself: an eval() module whose parameters still
+            # require grad, called outside torch.no_grad(), records a graph and runs the differentiable (non-fused) kernels.
+            import warnings
+            warnings.warn('shgan_amd Generator: eval() module called with gradients enabled and parameters that require grad -- this '
+                          'takes the differentiable training route (several times slower than the fused inference kernels). Call '
+                          '.requires_grad_(False) as the reference eval loop does (shgan_default.py:255) or wrap the call in '
+                          'torch.no_grad().', RuntimeWarning, stacklevel=2)
+            Generator._warned_training_route = True
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         x, feats = self.encoder(x)
         return self.synthesis(x, feats, ws, noise_mode=noise_mode)

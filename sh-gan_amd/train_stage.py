@@ -84,11 +84,15 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
         else:
             phase.opt.zero_grad(set_to_none=True)
         phase.module.requires_grad_(True)
+        if hasattr(loss, 'grad_sync'):
+            loss.grad_sync = phase.sync                  # the loss arms it before the phase's LAST backward (sync=True round only)
         rounds = batch_gpu // eff
         for round_idx, (ri, rc, gz, gc) in enumerate(zip(real_img_r, real_c_r, phase_gen_z, phase_gen_c)):
             loss.accumulate_gradients(phase=phase.name, real_img=ri, real_c=rc, gen_z=gz, gen_c=gc,
                                       sync=(round_idx == rounds - 1), gain=phase.interval)
         phase.module.requires_grad_(False)
+        if hasattr(loss, 'grad_sync'):
+            loss.grad_sync = None
         if phase.sync is not None:
             phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
             for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them

@@ -151,7 +151,10 @@ for step, scale in enumerate((1.0, 3.0)):
         for p in params:                 # what optimizer.zero_grad(set_to_none=True) does
             p.grad = None
         sync.zero_grad()
+    if step == 0:
+        sync.arm()                       # reductions launched from the hooks; step 1 stays un-armed: everything reduced in finish()
     (net(data[r]).square().mean() * scale).backward()
+    assert (len(sync._handles) > 0) == (step == 0)
     if step == 0 and r == 1:
         sync.buckets[0][0] = float("nan")            # a non-finite value on one rank must not survive
     sync.finish()
@@ -169,6 +172,52 @@ dist.destroy_process_group()
 print("rank", r, "ok")
 '''
     port = str(33500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
+
+
+def test_gloo_world2_two_backward_passes_per_phase_reduce_once():
+    """ADVICE r2 (high): one phase runs several backward passes into the same buckets (Dgen then Dreal,
+    stylegan_default_loss.py:93,126; effective_batch_gpu rounds).  Only the armed, LAST pass may launch reductions; the result
+    is the world mean of the SUM of every pass's gradient.  The advisor's repro: per-rank gradients (1, 10) then (2, 20) -> 16.5."""
+    script = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd.grad_sync import BucketedAllReduce
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"], rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+w = torch.nn.Parameter(torch.zeros(3)); v = torch.nn.Parameter(torch.zeros(2000)); u = torch.nn.Parameter(torch.zeros(4))
+sync = BucketedAllReduce([w, v, u], bucket_bytes=4096)
+assert len(sync.buckets) >= 2
+for trial in range(3):
+    sync.zero_grad()
+    first, second = (1.0, 2.0) if r == 0 else (10.0, 20.0)
+    ((w.sum() + v.sum()) * first).backward()             # un-armed: accumulate only (u not reached at all)
+    assert not sync._handles
+    time.sleep(0.05)
+    ((w.sum() + v.sum()) * first).backward()             # a second accumulation round, still un-armed
+    sync.arm()
+    ((w.sum() + v.sum() + (u.sum() if trial == 1 else 0.0)) * second).backward()
+    sync.finish()
+    want = (2 * 1.0 + 2.0 + 2 * 10.0 + 20.0) / 2
+    assert torch.allclose(w.grad, torch.full_like(w, want)) and torch.allclose(v.grad, torch.full_like(v, want)), (w.grad, want)
+    assert torch.allclose(u.grad, torch.full_like(u, 11.0 if trial == 1 else 0.0))
+    assert [id(p) for p in sync.untouched()] == ([] if trial == 1 else [id(u)])
+try:
+    sync.arm(); sync.arm()
+    raise SystemExit("double arm() must raise")
+except RuntimeError:
+    pass
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+    port = str(37500 + os.getpid() % 2000)
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)

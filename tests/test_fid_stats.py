@@ -1,6 +1,8 @@
 """FID statistics (reference lib/evaluator/eva_fid.py:194-277, eva_base.py:96-230) on synthetic
-[B, 2048] features (the Inception detector is a download and cannot be pinned offline).  Oracle = the reference's own
-formula restated in numpy / scipy on the features in dataset order."""
+[B, 2048] features (the Inception detector is a download and cannot be pinned offline).  The checker is the REFERENCE: ``tests/golden/fid.npz``
+holds FID values computed by the reference's own ``zipzap_arrange`` + ``compute_fid`` (tools/gen_golden.py: gen_fid) on feature sets sharded by
+its ``DistributedSampler(extend=True)``; ``reference_fid`` below (numpy restatement of eva_fid.py:239-261) is itself held to those values
+and serves only for intermediate quantities (mu, sigma) the reference does not expose."""
 import os
 import subprocess
 import sys
@@ -23,6 +25,69 @@ def reference_fid(fake, real, n_fake=None, n_real=None):
     sig_r = real.T @ real / real.shape[0] - np.outer(mu_r, mu_r)
     s, _ = scipy.linalg.sqrtm(np.dot(sig_f, sig_r), disp=False)
     return float(np.real(np.square(mu_f - mu_r).sum() + np.trace(sig_f + sig_r - s * 2))), (mu_f, sig_f, mu_r, sig_r)
+
+
+def golden_cases():
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'fid.npz'))
+    for name in z['names']:
+        name = str(name)
+        D, n, world, bs, sfn, srn = (int(v) for v in z[name + '__meta'])
+        yield name, dict(D=D, n=n, world=world, bs=bs, sample_fake_n=n if sfn < 0 else sfn, sample_real_n=n if srn < 0 else srn,
+                         real=z[name + '__real'], fake=z[name + '__fake'], shards=z[name + '__shards'], fid=float(z[name + '__fid']))
+
+
+def replay_sharded(case, device, accumulate_fn):
+    """Every rank's batches through ``FidStats.add_shard`` (ranks emulated in turn; summing their moments is what the one all-reduce does)."""
+    out = []
+    for feats, sample_n in ((case['fake'], case['sample_fake_n']), (case['real'], case['sample_real_n'])):
+        total = fid_stats.FidStats(case['D'], device, accumulate_fn)
+        for r in range(case['world']):
+            st = fid_stats.FidStats(case['D'], device, accumulate_fn)
+            ids = case['shards'][r]
+            for k0 in range(0, len(ids), case['bs']):
+                st.add_shard(torch.from_numpy(feats[ids[k0:k0 + case['bs']]]).to(device), k0, r, case['world'], sample_n=sample_n)
+            total.S += st.S
+        out.append(total.mean_cov(sample_n))
+    return out
+
+
+@pytest.mark.parametrize('name,case', list(golden_cases()))
+def test_fid_statistics_match_the_reference_compute_fid(name, case):
+    """Host logic (weights for padded duplicates, truncation to sample_n, moments -> mu/sigma -> sqrtm tail) against the reference's own
+    ``compute_fid`` value; the restatement used elsewhere in this file is pinned on the same values."""
+    (n_f, mu_f, sig_f), (n_r, mu_r, sig_r) = replay_sharded(case, 'cpu', numpy_accumulate)
+    assert (n_f, n_r) == (case['sample_fake_n'], case['sample_real_n'])
+    got = fid_stats.fid_from_stats(mu_f, sig_f, mu_r, sig_r)
+    assert abs(got - case['fid']) <= 1e-7 * abs(case['fid']), (got, case['fid'])
+    ref, _ = reference_fid(case['fake'].astype(np.float64), case['real'].astype(np.float64), case['sample_fake_n'], case['sample_real_n'])
+    assert abs(ref - case['fid']) <= 1e-7 * abs(case['fid']), (ref, case['fid'])
+
+
+def test_empty_accumulator_raises():
+    st = fid_stats.FidStats(8, 'cpu', numpy_accumulate)
+    with pytest.raises(ValueError):
+        st.mean_cov()
+    st.add(torch.ones(3, 8), torch.zeros(3))
+    with pytest.raises(ValueError):
+        st.mean_cov()
+
+
+def test_add_images_hands_the_batch_to_the_detector():
+    """eva_fid.py:194-206: detector(images.float(), return_features=True) on 0..255 images; padded duplicates weighted out."""
+    calls = []
+
+    def detector(img, return_features=False):
+        calls.append((img.dtype, tuple(img.shape), return_features))
+        return img.flatten(1)[:, :8] / 255.0
+
+    st = fid_stats.FidStats(8, 'cpu', numpy_accumulate)
+    u8 = torch.arange(4 * 3 * 2 * 2, dtype=torch.uint8).reshape(4, 3, 2, 2)
+    f = st.add_images(detector, u8, k0=2, rank=1, world=2, sample_n=10)      # positions 5, 7, 9, 11 -> the last one is padding
+    assert calls == [(torch.float32, (4, 3, 2, 2), True)]
+    n, mu, _ = st.mean_cov()
+    assert n == 3 and np.allclose(mu, f[:3].double().mean(0).numpy())
+    with pytest.raises(Exception):
+        st.add_images(lambda img, return_features: img.flatten(1)[:, :5], u8)
 
 
 def numpy_accumulate(S, feats, weights):
@@ -112,6 +177,17 @@ def test_device_moment_kernel_vs_numpy(dtype):
     assert np.abs(got - S).max() <= 1e-12 * np.abs(S).max()
     n, mu, sigma = st.mean_cov()
     assert n == S[d, d] and np.allclose(mu, S[:d, d] / n, atol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,case', list(golden_cases()))
+def test_device_fid_matches_the_reference_compute_fid(name, case):
+    """The HIP moment kernel end to end against the reference's ``compute_fid`` values (tests/golden/fid.npz): sharded replay with padded
+    duplicates, world 1 / 2 / 4, feature width 64 and 2048."""
+    (n_f, mu_f, sig_f), (n_r, mu_r, sig_r) = replay_sharded(case, 'cuda:0', None)
+    assert (n_f, n_r) == (case['sample_fake_n'], case['sample_real_n'])
+    got = fid_stats.fid_from_stats(mu_f, sig_f, mu_r, sig_r)
+    assert abs(got - case['fid']) <= 1e-6 * abs(case['fid']), (got, case['fid'])
 
 
 @pytest.mark.gpu

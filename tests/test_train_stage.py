@@ -128,19 +128,22 @@ def nets():
     return G, D
 class Loss:
     def __init__(self, G, D, world_mean):
-        self.G, self.D, self.wm = G, D, world_mean
+        self.G, self.D, self.wm, self.grad_sync = G, D, world_mean, None
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
         with torch.enable_grad():
             if phase == "Gmain":   l = torch.nn.functional.softplus(-self.D(self.G(gen_z))).mean()
             elif phase == "Greg":  l = self.G[0](gen_z).square().mean()                      # touches only the first layer
-            elif phase == "Dmain": l = torch.nn.functional.softplus(self.D(self.G(gen_z).detach())).mean() + torch.nn.functional.softplus(-self.D(real_img.flatten(1))).mean()
+            elif phase == "Dmain":                                                            # TWO backward passes, like Dgen + Dreal
+                (torch.nn.functional.softplus(self.D(self.G(gen_z).detach())).mean() * gain / self.wm).backward()
+                l = torch.nn.functional.softplus(-self.D(real_img.flatten(1))).mean()
             else:                  l = self.D(real_img.flatten(1)).square().mean()
+            if sync and self.grad_sync is not None: self.grad_sync.arm()
             (l * gain / self.wm).backward()
 kw = dict(lr=0.01, betas=(0.0, 0.99), eps=1e-8)
 def run(rank_data, world_mean, G, D):
     torch.manual_seed(123)                       # same latents on every rank / in the reference run
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=2, d_reg_interval=3)
-    return ts.train(G, D, copy.deepcopy(G), Loss(G, D, world_mean), iter(rank_data), phases, z_dim=6, batch_size=8, batch_gpu=4, total_kimg=1)
+    return ts.train(G, D, copy.deepcopy(G), Loss(G, D, world_mean), iter(rank_data), phases, z_dim=6, batch_size=8, batch_gpu=4, total_kimg=1, effective_batch_gpu=2)
 data = [[torch.randn(4, 3, 2, 2, generator=torch.Generator().manual_seed(100 * k + it)) for it in range(4)] for k in range(2)]
 G, D = nets()
 run(data[r], 1.0, G, D)

@@ -580,12 +580,53 @@ def gen_discriminator_grads():
     save('discriminator_grads', **out)
 
 
+def gen_fid():
+    """N1: the reference's own FID tail -- ``base_evaluator.zipzap_arrange`` (eva_base.py:196-230) applied per batch the way
+    ``fid_evaluator.add_batch`` arranges the per-rank features after ``sync`` (eva_fid.py:217-237), then ``compute_fid``
+    (eva_fid.py:239-263) incl. its ``[0:sample_n]`` truncation of the padded tail.  The detector (a TorchScript download,
+    eva_fid.py:145-158) and the broadcasts of ``sync_`` are bypassed: the per-rank feature arrays go straight into the list
+    ``sync`` would have returned.  Rank shards come from the reference's own ``DistributedSampler(extend=True)``."""
+    from lib.evaluator import eva_fid
+    from lib.data_factory.common import ds_sampler as ref_sampler
+    cases = {}
+    # name: (D, n_items, world, batch per rank, sample_fake_n, sample_real_n)
+    spec = dict(w1_d64=(64, 300, 1, 32, None, None),              # one rank, ragged last batch
+                w2_d64_padded=(64, 301, 2, 16, None, None),       # odd dataset on two ranks: one padded duplicate
+                w4_d2048_padded=(2048, 66, 4, 6, None, None),    # the real feature width, two padded duplicates, n << D
+                w2_d64_trunc=(64, 300, 2, 25, 200, 260))          # explicit sample_fake_n / sample_real_n
+    for ci, (name, (D, n, world, bs, sfn, srn)) in enumerate(spec.items()):
+        g = rs(4100 + ci)
+        mix = g.standard_normal((D, D)) / np.sqrt(D)
+        real = f32(np.abs(g.standard_normal((n, D)) @ mix + 0.3 * g.standard_normal(D)))
+        fake = f32(np.abs(g.standard_normal((n, D)) @ (mix + 0.15 * g.standard_normal((D, D)) / np.sqrt(D)) + 0.3 * g.standard_normal(D) + 0.05))
+        shards = [list(ref_sampler.DistributedSampler(list(range(n)), num_replicas=world, rank=r, shuffle=False, extend=True))
+                  for r in range(world)]
+        ev = object.__new__(eva_fid.fid_evaluator)          # (no __init__: it downloads the detector)
+        ev.final, ev.sample_n, ev.sample_fake_n, ev.sample_real_n = {}, n, sfn, srn
+        ev.dsstat_use_cache, ev.dsstat_cache_file = False, None
+        ev.data_fake_feat, ev.data_real_feat = [], []
+        per_rank = len(shards[0])
+        for k0 in range(0, per_rank, bs):
+            ids = [sh[k0:k0 + bs] for sh in shards]
+            ff = tuple(fake[i].astype(float) for i in ids)   # what zip(*sync([fake_feat, real_feat, fn])) yields (eva_fid.py:217-219)
+            rf = tuple(real[i].astype(float) for i in ids)
+            ev.data_fake_feat.append(ev.zipzap_arrange(ff))
+            ev.data_real_feat.append(ev.zipzap_arrange(rf))
+        fid = float(ev.compute_fid())
+        cases[name + '__real'], cases[name + '__fake'] = real, fake
+        cases[name + '__meta'] = np.asarray([D, n, world, bs, -1 if sfn is None else sfn, -1 if srn is None else srn], dtype=np.int64)
+        cases[name + '__fid'] = np.asarray(fid, dtype=np.float64)
+        cases[name + '__shards'] = np.asarray(shards, dtype=np.int64)
+        print(f'    {name}: fid = {fid:.10f}')
+    save('fid', names=np.asarray(list(spec.keys())), **cases)
+
+
 GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modconv=gen_modconv,
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
-            discriminator_conditional=gen_discriminator_conditional)
+            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
