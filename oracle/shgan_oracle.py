@@ -520,6 +520,19 @@ def composite_u8(x, img):
 # ----------------------------------------------------------------------------
 
 
+def seeded_fill_(module, seed, bias_std=0.1):
+    """Fill every parameter of ``module`` (the reference's or this package's -- same key schema) in ``named_parameters()`` order from
+    numpy's legacy ``RandomState(seed)``: weights ~ N(0,1) as the reference initialises them (stylegan.py:80,219), biases ~
+    N(0, bias_std) instead of 0 so the bias paths carry signal.  Lets a fixture for a 29 M-parameter discriminator record a seed
+    instead of the weights (tests / tools only)."""
+    g = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            v = torch.from_numpy(g.standard_normal(tuple(p.shape)).astype(np.float32))
+            p.copy_(v * bias_std if name.endswith('bias') else v)
+    return module
+
+
 def init_state_dict(resolution, seed=0, ch_base=32768, ch_max=512, w_dim=512, z_dim=512,
                     w0_dim=1024, shu_channels=32, noise_strength=0.0, bias_std=0.0):
     """Random-init weights with the reference's initialisers and key schema (appendix E).

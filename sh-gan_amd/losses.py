@@ -44,8 +44,7 @@ class StyleGAN2Loss(Loss):
             self.grad_sync.arm()
 
     # -- forward helpers (stylegan_default_loss.py:31-51) ----------------------------------------------------------------
-    def run_G(self, z, c, sync=True):
-        ws = self.G_mapping(z, c)
+    def _style_mix(self, ws, z, c):
         if self.style_mixing_prob > 0:
             # with probability p the rows from a random cutoff on come from a second latent
             cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
@@ -55,6 +54,10 @@ class StyleGAN2Loss(Loss):
             ws2 = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
             rows = torch.arange(ws.shape[1], device=ws.device).reshape(1, -1, 1)
             ws = torch.where(rows >= cutoff, ws2, ws)
+        return ws
+
+    def run_G(self, z, c, sync=True):
+        ws = self._style_mix(self.G_mapping(z, c), z, c)
         return self.G_synthesis(ws), ws
 
     def run_D(self, img, c, sync=True):
@@ -120,3 +123,41 @@ class StyleGAN2Loss(Loss):
                     self.stats.update({'Loss/r1_penalty': r1_penalty.detach(), 'Loss/D/reg': loss_Dr1.detach()})
                 self._arm(sync)                                      # Dgen's backward above never syncs (:87)
                 (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()
+
+
+class InpaintingLoss(StyleGAN2Loss):
+    """The same four phases for the co-modulated inpainting generator of SH-GAN (BASELINE config 5: FFHQ-512 G + D step).  The
+    reference ships no training stage for ``shgan``, so this is formula-level: the phase algebra is
+    ``stylegan_default_loss.py:53-128`` unchanged; what differs is how the two networks are fed, following CoModGAN:
+      * ``real_img`` is the discriminator's real input ``[N, 4, R, R] = cat([mask - 0.5, real])`` (``ic_n = 4``);
+      * the generator input is derived from it as the evaluation loop does (``shgan_default.py:268-273``):
+        ``x = cat([mask - 0.5, real * mask])``, ``img = G.synthesis(*G.encoder(x), ws)`` with ``ws`` from ``G.mapping`` (style mixing on ``ws``);
+      * generated images reach the discriminator as ``cat([mask - 0.5, img])``; R1 differentiates the logits w.r.t. the 4-channel real input.
+    ``noise_mode`` is the synthesis noise ('random' in training; tests pin 'const')."""
+
+    def __init__(self, device, G, D, noise_mode='random', **kw):
+        super().__init__(device, G.mapping, None, D, **kw)
+        self.G = G
+        self.noise_mode = noise_mode
+        self._m05 = self._x = None
+
+    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync=True, gain=1):
+        if real_img.ndim != 4 or real_img.shape[1] != 4:
+            raise AssertionError('InpaintingLoss: real_img must be [N, 4, R, R] = cat([mask - 0.5, real])')
+        self._m05 = real_img[:, 0:1].detach()
+        self._x = torch.cat([self._m05, real_img[:, 1:4].detach() * (self._m05 + 0.5)], dim=1)
+        try:
+            super().accumulate_gradients(phase, real_img, real_c, gen_z, gen_c, sync=sync, gain=gain)
+        finally:
+            self._m05 = self._x = None
+
+    def run_G(self, z, c, sync=True):
+        n = z.shape[0]
+        ws = self._style_mix(self.G.mapping(z, c), z, c)
+        x_global, feats = self.G.encoder(self._x[:n])
+        return self.G.synthesis(x_global, feats, ws, noise_mode=self.noise_mode), ws
+
+    def run_D(self, img, c, sync=True):
+        if img.shape[1] == 3:                                   # a generated image: prepend the mask channel it was conditioned on
+            img = torch.cat([self._m05[:img.shape[0]], img], dim=1)
+        return self.D(img, c)

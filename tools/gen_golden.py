@@ -580,6 +580,147 @@ def gen_discriminator_grads():
     save('discriminator_grads', **out)
 
 
+def _sampled(gn, k=512):
+    gn = gn.reshape(-1)
+    return gn if gn.size <= 2 * k else np.concatenate([gn[:k], gn[-k:]])
+
+
+def gen_config5_step():
+    """BASELINE config 5 at FULL width (FFHQ-512: ch_base 32768, ch_max 512, w/z 512, w0 1024; discriminator 512, ic_n 4), batch 2:
+    the four phases of stylegan_default_loss.py:53-128 -- Gmain :56-66, Dmain :94-127 (Dgen + Dreal), Dreg (R1, gamma 10) :118-124,
+    Greg (path length on the shrunk batch, pl_weight 2) :69-91 -- evaluated with the REFERENCE's own modules under torch autograd on CPU.
+    The reference's loss class itself is not importable (undefined misc / training_stats / dnnlib), so the formulae are
+    applied here to its modules; the co-modulated generator takes x = cat([mask-.5, real*mask]) and the discriminator
+    cat([mask-.5, image]) (ic_n = 4).  train() mode (non-fused modulated convolutions, stylegan.py:172-181, comodgan.py:307-309) with the
+    encoder's dropout switched off and noise_mode='const' so that the run is deterministic.  Weights: generator
+    ``init_state_dict(512, seed)``, discriminator ``seeded_fill_(D, seed)``; parameter gradients are stored as first / last 512 entries
+    + (sum, L2 norm)."""
+    R, N = 512, 2
+    G = build_reference_generator(R, 32768, 512, 512, 512, 1024)
+    sd = orc.init_state_dict(R, seed=51, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    G = G.train()
+    for m in G.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    D = stylegan.Discriminator(resolution=R, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=None,
+                               resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=4, mbstd_c_n=1,
+                               c_dim=None, cmap_dim=None).train()
+    orc.seeded_fill_(D, seed=52, bias_std=0.1)
+    real_u8, mask, z = synth_inputs(N, R, 512, seed=53)
+    x = assemble_x(real_u8, mask)
+    real = torch.from_numpy(real_u8.astype(np.float32)) / 127.5 - 1.0
+    m05 = x[:, 0:1]
+    cnd = torch.zeros(N, 0)
+    zt = torch.from_numpy(z)
+    sp = torch.nn.functional.softplus
+    out = dict(mask_bits=np.packbits(mask), z=z, seeds=np.array([51, 52, 53, 54], dtype=np.int64), cfg=np.array([R, N], dtype=np.int64))
+
+    def store(prefix, module):
+        for n_, p_ in module.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.reshape(-1).double()
+            out[prefix + 'sum__' + n_] = np.array([g.sum().item(), g.norm().item()])
+            out[prefix + '__' + n_] = _sampled(p_.grad.numpy()).astype(np.float32)
+
+    import time
+    t0 = time.time()
+    # ---- Gmain (:56-66)
+    G.requires_grad_(True); D.requires_grad_(False)
+    with torch.enable_grad():
+        img = G(x=x, z=zt, c=cnd, noise_mode='const')
+        logits = D(torch.cat([m05, img], 1), None)
+        loss = sp(-logits).mean()
+        loss.backward()
+    out['img_ds'] = img.detach()[:, :, ::8, ::8].numpy()
+    out['img_stats'] = np.array([img.mean().item(), img.std().item(), img.min().item(), img.max().item()])
+    out['gmain_logits'], out['gmain_loss'] = logits.detach().numpy(), np.float64(loss.item())
+    store('gmain', G)
+    fake = img.detach()
+    print(f'    Gmain done {time.time() - t0:.0f}s  loss {loss.item():.6f}')
+    # ---- Dmain (:94-127)
+    G.zero_grad(); G.requires_grad_(False); D.requires_grad_(True)
+    with torch.enable_grad():
+        lf = D(torch.cat([m05, fake], 1), None)
+        sp(lf).mean().backward()
+        lr = D(torch.cat([m05, real], 1), None)
+        sp(-lr).mean().backward()
+    out['dmain_logits_fake'], out['dmain_logits_real'] = lf.detach().numpy(), lr.detach().numpy()
+    out['dmain_loss'] = np.float64((sp(lf) + sp(-lr)).mean().item())
+    store('dmain', D)
+    print(f'    Dmain done {time.time() - t0:.0f}s')
+    # ---- Dreg (:104-127, r1_gamma = 10)
+    D.zero_grad()
+    with torch.enable_grad():
+        rt = torch.cat([m05, real], 1).detach().requires_grad_(True)
+        lr = D(rt, None)
+        r1g = torch.autograd.grad(outputs=[lr.sum()], inputs=[rt], create_graph=True, only_inputs=True)[0]
+        r1 = r1g.square().sum([1, 2, 3])
+        (lr * 0 + (r1 * 5.0).reshape(-1, 1)).mean().backward()
+    out['r1_penalty'] = r1.detach().numpy()
+    store('dreg', D)
+    print(f'    Dreg done {time.time() - t0:.0f}s  r1 {r1.detach().numpy()}')
+    # ---- Greg (:69-91, batch // pl_batch_shrink = 1, pl_weight = 2, pl_mean = 0 -> lerp(mean, 0.01))
+    D.zero_grad(); D.requires_grad_(False); G.requires_grad_(True)
+    pl_noise = torch.from_numpy(rs(54).standard_normal((1, 3, R, R)).astype(np.float32)) / np.sqrt(R * R)
+    with torch.enable_grad():
+        ws = G.mapping(zt[:1], cnd[:1])
+        xg, feats = G.encoder(x[:1])
+        img1 = G.synthesis(xg, feats, ws, noise_mode='const')
+        plg = torch.autograd.grad(outputs=[(img1 * pl_noise).sum()], inputs=[ws], create_graph=True, only_inputs=True)[0]
+        pll = plg.square().sum(2).mean(1).sqrt()
+        plm = torch.zeros([]).lerp(pll.mean(), 0.01)
+        (img1[:, 0, 0, 0] * 0 + (pll - plm).square() * 2.0).mean().backward()          # (pl_mean carries its graph, :84-86)
+    out['pl_lengths'], out['pl_mean'] = pll.detach().numpy(), np.float64(plm.item())
+    store('greg', G)
+    print(f'    Greg done {time.time() - t0:.0f}s  pl {pll.detach().numpy()}')
+    # ---- the same Gmain and Greg in FLOAT64 (the reference's modules with their hard-wired ``torch.float32`` casts -- stylegan.py:403,
+    # 486,517,567, comodgan.py:43,238,305,337,398 -- redirected to float64): the yardstick for the fp32 round-off of ~1e5-term
+    # sums in the generator's gradients.  Tests hold the HIP path's distance to float64 against the reference's OWN fp32 distance.
+    import copy
+
+    class _Torch64:
+        float32 = torch.float64
+
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+    mods = [stylegan, comodgan, shgan, ref_utils, ref_ufd, ref_c2r]
+    saved = [m_.torch for m_ in mods]
+    try:
+        for m_ in mods:
+            m_.torch = _Torch64()
+        G64, D64 = copy.deepcopy(G).double(), copy.deepcopy(D).double()
+        x64, z64, m64 = x.double(), zt.double(), m05.double()
+        G64.zero_grad(); G64.requires_grad_(True); D64.requires_grad_(False)
+        with torch.enable_grad():
+            img = G64(x=x64, z=z64, c=cnd.double(), noise_mode='const')
+            assert img.dtype == torch.float64
+            logits = D64(torch.cat([m64, img], 1), None)
+            sp(-logits).mean().backward()
+        out['gmain64_logits'] = logits.detach().numpy()
+        out['img64_ds'] = img.detach()[:, :, ::8, ::8].numpy()
+        store('gmain64', G64)
+        print(f'    Gmain fp64 done {time.time() - t0:.0f}s')
+        G64.zero_grad()
+        with torch.enable_grad():
+            ws = G64.mapping(z64[:1], cnd[:1].double())
+            xg, feats = G64.encoder(x64[:1])
+            img1 = G64.synthesis(xg, feats, ws, noise_mode='const')
+            plg = torch.autograd.grad(outputs=[(img1 * pl_noise.double()).sum()], inputs=[ws], create_graph=True, only_inputs=True)[0]
+            pll = plg.square().sum(2).mean(1).sqrt()
+            plm = torch.zeros([], dtype=torch.float64).lerp(pll.mean(), 0.01)
+            (img1[:, 0, 0, 0] * 0 + (pll - plm).square() * 2.0).mean().backward()
+        out['pl_lengths64'] = pll.detach().numpy()
+        store('greg64', G64)
+        print(f'    Greg fp64 done {time.time() - t0:.0f}s  pl {pll.detach().numpy()}')
+    finally:
+        for m_, t_ in zip(mods, saved):
+            m_.torch = t_
+    save('config5_step512', **out)
+
+
 def gen_fid():
     """N1: the reference's own FID tail -- ``base_evaluator.zipzap_arrange`` (eva_base.py:196-230) applied per batch the way
     ``fid_evaluator.add_batch`` arranges the per-rank features after ``sync`` (eva_fid.py:217-237), then ``compute_fid``
@@ -626,7 +767,7 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
-            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid)
+            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
