@@ -54,6 +54,17 @@ def pmc_traffic(resolution, batch, kernel='conv_wino4_kernel'):
     return round((d['read_bytes_per_launch'] + d['write_bytes_per_launch']) / 1e9, 4), os.path.relpath(path, ROOT)
 
 
+def pmc_traffic_classes(resolution, batch, kernels_=('conv_wino4_kernel', 'conv_poly_up_kernel', 'conv_poly_down_kernel', 'conv_mfma_kernel',
+                                                     'fir_up_march_kernel', 'fir_down_march4_kernel', 'torgb4_kernel')):
+    """Per kernel class: HBM read / write GB per launch from the same committed profile (largest convolution and FIR classes)."""
+    path = os.path.join(ROOT, 'profiles', f'traffic_{resolution}x{batch}.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {k: {'launches_profiled': d[k]['launches'], 'read_GB_per_launch': round(d[k]['read_bytes_per_launch'] / 1e9, 4),
+                'write_GB_per_launch': round(d[k]['write_bytes_per_launch'] / 1e9, 4)} for k in kernels_ if k in d}
+
+
 def cpu_model():
     try:
         for ln in open('/proc/cpuinfo'):
@@ -64,34 +75,40 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(resolution, bench_batch, n_images, forwards, noise_mode, seed):
-    """the CPU restatement (oracle, torch CPU fp32) on this host: 1 warm-up + ``forwards`` timed forwards
-    + composite with the bench's noise mode.  The batch is truncated from the bench batch to ``n_images`` so that the
-    default run stays within ~30 s of CPU work (a 512x16 forward alone takes ~18 s on 32 threads); stated in ``sample``."""
+def cpu_baseline(resolution, bench_batch, n_images, forwards, noise_mode, seed, sweep=(16, 32, 64)):
+    """the CPU restatement (oracle, torch CPU fp32) on this host, the FULL bench batch: a thread-count sweep on a
+    2-image sample picks the fastest setting (more threads than ~32 make torch's CPU grouped convolutions *slower* on a 256-core
+    host: 16 thr 0.94, 32 thr 0.97, 64 thr 0.59, 256 thr 0.04 img/s at 512x512, round 2), then 1 warm-up (1 image) + ``forwards`` timed
+    forwards + composite of ``n_images`` images with the bench's noise mode.  The sweep result is kept in the record."""
     import torch
     from oracle import shgan_oracle as orc
     import shgan_amd  # noqa: F401
     from shgan_amd import configs
-    # more threads than ~32 make torch's CPU grouped convolutions *slower* on a 256-core host
-    # (measured: 16 thr 0.94, 32 thr 0.97, 64 thr 0.59, 256 thr 0.04 img/s at 512x512), so cap at 32
-    threads = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(threads)
     G = configs.seeded_init_(configs.build_generator(resolution), seed=seed)
     sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
     del G
     x, z, _, _ = orc.synthetic_batch(n_images, resolution, 512, seed=seed + 1)
-    times = []
+    swept = {}
     with torch.no_grad():
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
         orc.run_generator(sd, x[:1], z[:1], resolution, noise_mode=noise_mode)      # page-in / warm-up
+        for th in [t for t in sweep if t <= (os.cpu_count() or 1)] or [os.cpu_count() or 1]:
+            torch.set_num_threads(th)
+            t0 = time.perf_counter()
+            orc.run_generator(sd, x[:2], z[:2], resolution, noise_mode=noise_mode)
+            swept[th] = round(2 / (time.perf_counter() - t0), 4)
+        threads = max(swept, key=swept.get)
+        torch.set_num_threads(threads)
+        times = []
         for _ in range(forwards):
             t0 = time.perf_counter()
             orc.run_generator(sd, x, z, resolution, noise_mode=noise_mode)
             times.append(time.perf_counter() - t0)
     best = min(times)
     return dict(value=round(n_images / best, 4), unit='images/s', cores=threads, kind='port', cpu=cpu_model(),
-                host_cores=os.cpu_count(),
+                host_cores=os.cpu_count(), thread_sweep_images_per_s_on_2_images=swept,
                 sample=f'{forwards} timed forwards + composite (best of; all: {[round(t, 2) for t in times]} s) after a 1-image '
-                       f'warm-up, batch truncated {bench_batch} -> {n_images} images {resolution}x{resolution}, noise_mode='
+                       f'warm-up and a thread sweep, batch {n_images} of the bench batch {bench_batch}, {resolution}x{resolution}, noise_mode='
                        f'{noise_mode!r}, oracle/shgan_oracle.py (torch CPU fp32, {threads} threads)')
 
 
@@ -104,8 +121,12 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 16 @512, 32 @256)')
     ap.add_argument('--noise-mode', default='random')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=4)
-    ap.add_argument('--cpu-forwards', type=int, default=3)
+    ap.add_argument('--cpu-images', type=int, default=None, help='images per CPU forward (default: the full bench batch, SURVEY 8d)')
+    ap.add_argument('--cpu-forwards', type=int, default=2)
+    ap.add_argument('--no-second-config', action='store_true', help='skip the 256x256 batch-32 block (BASELINE config 2)')
+    ap.add_argument('--no-train-step', action='store_true', help='skip the config-5 training-step block')
+    ap.add_argument('--train-batch', type=int, default=8)
+    ap.add_argument('--train-steps', type=int, default=3)
     ap.add_argument('--pipeline-depth', type=int, default=None,
                     help='HIP streams the consecutive (independent) batches are issued on round-robin; 1 = one stream')
     ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
@@ -118,6 +139,124 @@ def free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def max_over_ranks(dt, use_dist, backend, dev):
+    import torch
+    import torch.distributed as dist
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_dist, backend):
+    """The headline loop on another configuration (BASELINE config 2: FFHQ-256 batch 32): same pipeline, same barrier / max-over-ranks timing."""
+    import torch
+    from shgan_amd import configs, eval_harness
+    G = configs.seeded_init_(configs.build_generator(res), seed=0).eval().requires_grad_(False).to(dev)
+    ids = [rank + world * k for k in range(batch)]
+    x, z, _, _ = eval_harness.synthetic_items(ids, res, G.z_dim, seed=1000, device=dev)
+
+    def step():
+        return eval_harness.run_generator(G, x, z, noise_mode=a.noise_mode)
+    pipe = eval_harness.StreamPipeline(dev, depth=a.pipeline_depth)
+    for _ in range(warmup):
+        pipe.run(step)
+    pipe.join()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run(step)
+    pipe.join()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    lat = (time.perf_counter() - t1) / 3 * 1e3
+    barrier()
+    del G, x, z
+    torch.cuda.empty_cache()
+    return {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU', 'value': round(world * batch * steps / dt, 3),
+            'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warmup, 'n_gpus': world,
+            'ms_per_step_single_stream': round(lat, 3), 'gflop_per_image_direct_form': GFLOP_PER_IMAGE.get(res)}
+
+
+def train_block(a, dev, rank, world, barrier, use_dist, backend):
+    """BASELINE config 5: FFHQ-512 G + D training step (stylegan_default_loss.py:53-128 on the co-modulated generator, losses.InpaintingLoss),
+    batch ``--train-batch`` per GPU, fp32, Adam, noise_mode='random', style mixing 0.9, gradients in RCCL all-reduce buckets (world > 1).
+    A step = Gmain + Dmain (every iteration); the lazy regularisers Greg (every 4th) / Dreg (every 16th) are timed in one full iteration and
+    reported amortised.  Not part of the headline; one extra instrumented iteration gives the per-class kernel times."""
+    import torch
+    from shgan_amd import configs, kernels, losses, train_stage as ts
+    from shgan_amd.model_zoo import stylegan
+    b, res = a.train_batch, 512
+    torch.manual_seed(1234)                              # identical initial weights on every rank
+    G = configs.seeded_init_(configs.build_generator(res), seed=0).to(dev).train().requires_grad_(False)
+    D = stylegan.Discriminator(resolution=res, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=None, mbstd_group_size=4,
+                               mbstd_c_n=1).to(dev).train().requires_grad_(False)
+    torch.manual_seed(4321 + rank)                       # per-rank data / latents / noise
+    real = torch.rand(b, 3, res, res, device=dev) * 2 - 1
+    mask = (torch.rand(b, 1, res, res, device=dev) < 0.7).float()
+    real4 = torch.cat([mask - 0.5, real], dim=1)
+    L = losses.InpaintingLoss(dev, G, D, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
+    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8)
+    phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
+
+    def iteration(idx):
+        return ts.run_phases(real4, 512, phases, batch_idx=idx, loss=L, batch_gpu=b, device=dev)
+
+    def timed(idxs):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in idxs:
+            iteration(i)
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev) / len(idxs) * 1e3
+    iteration(0)                                          # warm-up: all four phases (weight-layout caches, allocator)
+    iteration(1)
+    ms_main = timed([1 + (k % 3) for k in range(a.train_steps)])       # Gmain + Dmain only (batch_idx % 4 != 0)
+    ms_all = timed([0])                                   # Gmain + Greg + Dmain + Dreg
+    finite = all(bool(torch.isfinite(v).all()) for v in L.stats.values())
+    cls = {}
+    if rank == 0:
+        timer = kernels.KernelTimer()
+        kernels.set_timer(timer)
+        iteration(1)
+        torch.cuda.synchronize()
+        kernels.set_timer(None)
+        for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]['ms']):
+            if v['ms'] <= 0:
+                continue
+            e = {'ms_per_step': round(v['ms'], 3), 'launches': v['calls']}
+            if k.startswith('conv'):
+                sec = v['ms'] * 1e-3
+                e.update(direct_form_tflops=round(v['work'] / sec / 1e12, 2), executed_tflops=round(v['executed'] / sec / 1e12, 2),
+                         frac_of_fp32_mfma_peak=round(v['executed'] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+            cls[k] = e
+    barrier()
+    mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    for ph in phases:
+        if ph.sync is not None:
+            ph.sync.remove()
+    del G, D, L, phases
+    torch.cuda.empty_cache()
+    # Greg runs every 4th and Dreg every 16th iteration: (ms_all - ms_main) is their joint cost in an iteration where both run
+    return {'workload': f'FFHQ-512 G + D training step (Gmain + Dmain: non-saturating logistic loss, Adam), random-init, batch {b} per GPU, fp32',
+            'ms_per_step': round(ms_main, 2), 'images_per_s': round(world * b / ms_main * 1e3, 2), 'steps': a.train_steps, 'n_gpus': world,
+            'ms_iteration_with_both_lazy_regularisers': round(ms_all, 2),
+            'lazy_regularisers': 'Greg (path length, batch/2) every 4th, Dreg (R1) every 16th iteration (stylegan_default.py:304-321)',
+            'dtype': 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
+            'grad_all_reduce': (backend if world > 1 else None), 'kernel_classes_one_step_rank0': cls,
+            'conv_kernel_ms': round(sum(v['ms_per_step'] for k, v in cls.items() if k.startswith('conv')), 2) if cls else None}
 
 
 def worker(local_rank, a, spawned_world=None, port=None):
@@ -184,11 +323,12 @@ def worker(local_rank, a, spawned_world=None, port=None):
     pipe.join()
     torch.cuda.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev)
+    ranks_counted = 1
+    if use_dist:                           # every rank contributes 1: the line proves how many ranks the collective really spanned
+        t = torch.ones(1, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_counted = int(t.item())
     assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
     # one batch alone on one stream (latency of a step; not the headline)
     lat_ms = None
@@ -213,6 +353,19 @@ def worker(local_rank, a, spawned_world=None, port=None):
         kernels.set_timer(None)
         tsum = timer.summary()
     barrier()
+    del pipe
+    second = train = None
+    if not a.no_second_config and res == 512 and a.batch is None:
+        second = forward_block(256, 32, max(10, a.steps // 2), 3, a, dev, rank, world, barrier, use_dist, backend)
+    if not a.no_train_step and res == 512 and a.batch is None:
+        del G, x, z, out
+        torch.cuda.empty_cache()
+        try:
+            train = train_block(a, dev, rank, world, barrier, use_dist, backend)
+        except Exception as e:             # informational block: never lose the headline over it
+            if world > 1:
+                raise                      # (a rank that dropped out of a collective would hang the others)
+            train = {'error': repr(e)}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -260,6 +413,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
                 'direct_form_tflops': dom['direct_form_tflops'] if dom else None,
                 'traffic': traffic, 'traffic_unit': 'GB per launch (HBM read+write, PMC FETCH_SIZE*2 + WRITE_SIZE)',
                 'traffic_source': f'constant of the committed profile {traffic_src}, not measured in this run' if traffic_src else None,
+                'traffic_classes': pmc_traffic_classes(res, batch),
                 'classes': conv,
                 'all_conv': {'ms_per_step': round(conv_ms / psteps, 3) if psteps else None,
                              'executed_tflops': round(conv_exec / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
@@ -277,7 +431,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
                        'resolution': res, 'batch_per_gpu': batch, 'global_batch': batch * world, 'noise_mode': a.noise_mode,
                        'parallelism': f'batch-shard x{world}', 'launcher': 'self-spawn' if spawned_world else
                        ('torch.distributed.run' if 'RANK' in os.environ and spawned_world is None and use_dist else 'single process'),
-                       'collective_backend': backend, 'ranks_share_devices': oversub,
+                       'collective_backend': backend, 'ranks_all_reduced': ranks_counted, 'ranks_share_devices': oversub,
                        'stream_pipeline_depth': a.pipeline_depth},
             'pipeline': {'depth': a.pipeline_depth, 'ms_per_step_single_stream': round(lat_ms, 3) if lat_ms else None,
                          'note': 'the K timed steps are independent batches issued round-robin on `depth` HIP streams '
@@ -288,10 +442,14 @@ def worker(local_rank, a, spawned_world=None, port=None):
                       f'{psteps} steps (HIP events on the launch stream)',
             'roofline': roof,
             'hbm': {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'classes': hbm},
+            'second_config': second,
+            'train_step': train,
         }
         if not a.no_cpu_baseline and world == 1:
             try:
-                line['cpu_baseline'] = cpu_baseline(res, batch, a.cpu_images, a.cpu_forwards, a.noise_mode, seed=0)
+                line['cpu_baseline'] = cpu_baseline(res, batch, a.cpu_images or batch, a.cpu_forwards, a.noise_mode, seed=0)
+                if second is not None:
+                    line['cpu_baseline']['second_config'] = cpu_baseline(256, 32, a.cpu_images or 32, a.cpu_forwards, a.noise_mode, seed=0)
             except Exception as e:   # the baseline is informational; never lose the GPU number over it
                 line['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
                                         'sample': f'failed: {e!r}'}
