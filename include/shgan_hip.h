@@ -230,6 +230,30 @@ int shg_fid_accumulate_f64(const void* feats, int is_f64, const float* weights, 
  * x [N,C,H,W] -> y [N,C+F,H,W]; N % G == 0, C % F == 0; stat [N/G * F] is caller-owned scratch. */
 int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, int H, int W, int G, int F, void* stream);
 
+/* ---- next row N3, fp16 route (the reference's `use_fp16` branches: stylegan.py:136-138,486,660-667, comodgan.py:40-47,305; its native
+ * op is instantiated for half as well, upfirdn2d.cpp:59 AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Layout of every fp16 activation:
+ * channels-LAST, [N,H,W,C] IEEE halves (torch.channels_last on a [N,C,H,W] tensor) -- 8 consecutive channels are one 16-byte MFMA
+ * operand.  Arithmetic: v_mfma_f32_32x32x16_f16, fp32 accumulation, one rounding to fp16.
+ * shg_conv2d_f16: w [k*k][O][I] halves (correlation taps, row-major (ky,kx)), bias fp32 [O] or NULL, I % 16 == 0.
+ *   mode 0: y [N,OH,OW,O] = conv2d(x, w, stride, pad);  mode 1: rows / columns [crop, crop+OH) x [crop, crop+OW) of
+ *   conv_transpose2d(x, w, stride 2), 3x3, w[t][o][i] = torch weight[i][o][ky][kx] (conv2d_gradfix.py:109-116); entries beyond the
+ *   (2H+1) x (2W+1) result are NOT written (shg_conv2d_f16_needs_clear: zero y first). */
+int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad,
+                   int mode, int crop, int OH, int OW, void* stream);
+int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW);
+/* weight gradient (replaces the cuDNN backward-weight call of conv2d_gradfix.py:140-146 for halves): dw [k*k][O][I] FP32 =
+ * sum_{n,oy,ox} g[n,oy,ox,o] * x[n, oy*stride-pad+ky, ox*stride-pad+kx, i]; x [N,H,W,I], g [N,OH,OW,O] halves; I, O % 8 == 0;
+ * deterministic (fp32 partial sums per pixel slice in `workspace`, reduced in a fixed order). */
+size_t shg_conv2d_wgrad_f16_workspace_bytes(int N, int I, int O, int OH, int OW, int k);
+int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int N, int I, int O, int H, int W, int OH, int OW, int k, int stride, int pad,
+                         void* workspace, size_t ws_bytes, void* stream);
+/* upfirdn2d on halves (same argument meaning as shg_upfirdn2d_f32; f stays fp32 [fh,fw], fp32 accumulation; C % 8 == 0). */
+int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, int C, int H, int W, int fh, int fw, int upx, int upy, int downx, int downy,
+                      int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
+/* y = lrelu_agc(x + bias[c]) (act = 0: (x + bias) * gain) over `pixels` x C halves, and dL/dx from dL/dy and the saved OUTPUT y. */
+int shg_bias_act_f16(const void* x, const float* bias, void* y, long pixels, int C, int act, float alpha, float gain, float clamp, void* stream);
+int shg_bias_act_backward_f16(const void* g, const void* y, void* dx, long total, int act, float alpha, float gain, float clamp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -85,6 +85,13 @@ _SIGS = {
     'shg_mask_raster_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp],
     'shg_fid_accumulate_f64': [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_minibatch_std_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'shg_conv2d_f16': [c_fp, c_fp, c_fp, c_fp] + [c_i] * 12 + [c_fp],
+    'shg_conv2d_f16_needs_clear': [c_i] * 5,
+    'shg_conv2d_wgrad_f16_workspace_bytes': [c_i] * 6,
+    'shg_conv2d_wgrad_f16': [c_fp, c_fp, c_fp] + [c_i] * 10 + [c_fp, ctypes.c_size_t, c_fp],
+    'shg_upfirdn2d_f16': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],
+    'shg_bias_act_f16': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_f, c_f, c_f, c_fp],
+    'shg_bias_act_backward_f16': [c_fp, c_fp, c_fp, c_l, c_i, c_f, c_f, c_f, c_fp],
 }
 
 _lib = None
@@ -118,6 +125,7 @@ def get_lib():
     lib.shg_last_error.restype = ctypes.c_char_p
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_wgrad_f16_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv_wino4_weight_elems.restype = c_l
     ver = lib.shg_abi_version()
     if ver != ABI_VERSION:

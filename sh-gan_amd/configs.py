@@ -16,8 +16,11 @@ ACT = 'lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)'
 NUM_WS = {256: 14, 512: 16, 1024: 18}                    # comodgan.py:367-372
 
 
-def model_cfg(name='shgan_g512', ch_base=32768, ch_max=512, w_dim=512, z_dim=512, w0_dim=1024):
-    """Registry config (``type`` / ``args``) of a shipped generator; the width arguments exist for reduced-size tests."""
+def model_cfg(name='shgan_g512', ch_base=32768, ch_max=512, w_dim=512, z_dim=512, w0_dim=1024, use_fp16_before_res=None,
+              use_fp16_after_res=None):
+    """Registry config (``type`` / ``args``) of a shipped generator; the width arguments exist for reduced-size tests.  The shipped
+    configs are float32 (``use_fp16_*: null``, comodgan.yaml:27,46); ``use_fp16_before_res`` (encoder blocks above that resolution) /
+    ``use_fp16_after_res`` (synthesis blocks above it) switch the reference's half-precision blocks on (BASELINE config 5)."""
     if name not in ('shgan_g256', 'shgan_g512'):
         raise KeyError(f'unknown model config {name!r} (shipped: shgan_g256, shgan_g512)')
     res = int(name[-3:])
@@ -25,21 +28,21 @@ def model_cfg(name='shgan_g512', ch_base=32768, ch_max=512, w_dim=512, z_dim=512
         z_dim=z_dim, c_dim=0, w_dim=w_dim, num_ws=NUM_WS[res], num_layers=8, embed_features=None, layer_features=None,
         activation=ACT, lr_multiplier=0.01, w_avg_beta=0.995))
     encoder = dict(type='shgan_encoder', args=dict(
-        resolution=res, ic_n=4, oc_n=w0_dim, ch_base=ch_base, ch_max=ch_max, use_fp16_before_res=None,
+        resolution=res, ic_n=4, oc_n=w0_dim, ch_base=ch_base, ch_max=ch_max, use_fp16_before_res=use_fp16_before_res,
         resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=0, mbstd_c_n=0, c_dim=None, cmap_dim=None,
         use_dropout=True, has_extra_final_layer=False, shu_channels=32, shu_df_freedom=[2, 3],
         shu_df_type='piecewise_linear', shu_input_res=64, shu_lowest_res=4, shu_tail_sigma_mult=3,
         shu_gaussian_at_input_res=False))
     synthesis = dict(type='comodgan_synthesis', args=dict(
-        w_dim=w_dim, w0_dim=w0_dim, resolution=res, rgb_n=3, ch_base=ch_base, ch_max=ch_max, use_fp16_after_res=None,
+        w_dim=w_dim, w0_dim=w0_dim, resolution=res, rgb_n=3, ch_base=ch_base, ch_max=ch_max, use_fp16_after_res=use_fp16_after_res,
         resample_filter=[1, 3, 3, 1], activation=ACT))
     return dict(type='comodgan_generator', args=dict(mapping=mapping, encoder=encoder, synthesis=synthesis))
 
 
-def discriminator_cfg(resolution=512, ch_base=32768, ch_max=512):
+def discriminator_cfg(resolution=512, ch_base=32768, ch_max=512, use_fp16_before_res=None):
     """comodgan.yaml:51-58 / stylegan.yaml:31-46: the training-time critic (mask + image, 4 input channels)."""
     return dict(type='stylegan2_discriminator', args=dict(
-        resolution=resolution, ic_n=4, ch_base=ch_base, ch_max=ch_max, use_fp16_before_res=None,
+        resolution=resolution, ic_n=4, ch_base=ch_base, ch_max=ch_max, use_fp16_before_res=use_fp16_before_res,
         resample_filter=[1, 3, 3, 1], activation=ACT, mbstd_group_size=4, mbstd_c_n=1, c_dim=None, cmap_dim=None))
 
 

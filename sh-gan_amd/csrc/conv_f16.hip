@@ -1,0 +1,469 @@
+// fp16 route of the training / config-5 rows (reference: the `use_fp16` branches -- stylegan.py:136-138,486,660-667,
+// comodgan.py:40-47,305 -- whose convolutions are cuDNN half kernels with fp32 accumulation, and upfirdn2d.cu's half
+// instantiation, upfirdn2d.cpp:59).  gfx950 only.
+//
+// Data layout: fp16 activations live in HBM channels-LAST ([N,H,W,C], torch.channels_last on a [N,C,H,W] tensor): the
+// v_mfma_f32_32x32x16_f16 operands are 8 consecutive K values per lane, and with K = input channels that is ONE 16-byte load
+// per lane from an NHWC tensor (an NCHW tensor would need a transposing gather for every operand).  Weights are prepared as
+// [tap][O][I] (I fastest), accumulation is fp32, results are rounded to fp16 once.
+//
+//   conv_f16_kernel      y[n,oy,ox,o] = sum_t sum_i w[t][o][i] * x[n, oy'*s_in + dy_t, ox'*s_in + dx_t, i]  with the output pixel
+//                        (oy,ox) = (oy'*s_out + oy0, ox'*s_out + ox0): stride-1 / stride-2 convolutions (s_out = 1) and, launched once
+//                        per sub-pixel phase, the stride-2 transposed convolution (s_out = 2, each phase has its own 1 / 2 / 4 taps:
+//                        no multiplies by inserted zeros).  Implicit GEMM: M = output channels (A = weights, global/L2 -> registers),
+//                        N = a tile of 8x16 output pixels (B = the input patch of a 32-channel chunk in LDS, one ds_read_b128 per
+//                        operand, pixel stride 80 B = conflict-free), K = taps x channels.
+//   conv_wgrad_f16       dw[t][o][i] = sum_{n,oy,ox} g[n,oy,ox,o] * x[n, oy*s + dy_t, ox*s + dx_t, i]: K = pixels, so both operands
+//                        are read from [pixel][channel] LDS tiles with the pixel index varying inside a lane's 8 values (2-byte LDS
+//                        gathers); 64 x 64 (o,i) tile per workgroup, all taps per wave, split over pixel slices with fp32 partials +
+//                        a fixed-order reduction (deterministic).
+//   upfirdn2d_f16        the generic gather of upfirdn2d.cu:29-92 on NHWC halves, 8 channels per lane, fp32 accumulation.
+//   bias_act_f16 (+bwd)  x + bias[c] -> lrelu_agc, and its gradient from the saved output (common/utils.py:135-143).
+#include "shg_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+namespace f16 {
+
+constexpr int TH = 8, TW = 16;       // output-pixel tile of a workgroup (4 waves x 2 rows x 16 columns)
+constexpr int KC = 32;               // channels per LDS chunk (two MFMA k-steps)
+constexpr int PSTR = 40;             // halves per staged pixel: 32 + 8 padding -> 80-byte stride, conflict-free ds_read_b128
+
+struct ConvP {
+    const _Float16* x;
+    const _Float16* w;               // [ntaps_total][O][I]
+    const float* bias;               // optional [O]
+    _Float16* y;
+    int N, I, O, H, W;               // input tensor
+    int OHt, OWt;                    // output tensor extent
+    int GH, GW;                      // extent of the computed pixel grid (oy', ox')
+    int tiles_x, tiles_y;
+    int s_in, s_out, oy0, ox0;
+    int ntaps;
+    int tdy[9], tdx[9], tw[9];       // input offset of tap t (already minus the patch origin) and its weight slot
+    int org_y, org_x;                // patch origin: input row of patch row 0 for grid row 0 = org_y
+    int PH, PW;                      // patch extent
+};
+
+template <int MB, int NT>
+__global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 patch[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
+    int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y, n = tile / p.tiles_y;
+    const int o0 = blockIdx.y * (MB * 32);
+    const int gy = ty * TH + wave * 2 + (j >> 4), gx = tx * TW + (j & 15);          // this lane's pixel in the computed grid
+    const int ly = (wave * 2 + (j >> 4)) * p.s_in, lx = (j & 15) * p.s_in;            // its position in the patch (tap offset added below)
+    const int iy_base = ty * TH * p.s_in + p.org_y, ix_base = tx * TW * p.s_in + p.org_x;
+    f16x acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const int npix = p.PH * p.PW;
+    const _Float16* xn = p.x + (long)n * p.H * p.W * p.I;
+    for (int c0 = 0; c0 < p.I; c0 += KC) {
+        __syncthreads();
+        // stage the patch of this channel chunk: 4 lanes x 16 bytes per pixel, zero outside the image / beyond I
+        for (int pp = tid >> 2; pp < npix; pp += 64) {
+            const int q = tid & 3, py = pp / p.PW, px = pp - py * p.PW;
+            const int iy = iy_base + py, ix = ix_base + px;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c0 + q * 8 < p.I)
+                v = *(const h8*)(xn + ((long)iy * p.W + ix) * p.I + c0 + q * 8);
+            *(h8*)(patch + pp * PSTR + q * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const _Float16* bp = patch + ((ly + p.tdy[t]) * p.PW + lx + p.tdx[t]) * PSTR + kg * 8;
+            const _Float16* wp = p.w + ((long)p.tw[t] * p.O + o0 + j) * p.I + c0 + kg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const h8 b = *(const h8*)(bp + ks * 16);
+                const bool kin = c0 + ks * 16 < p.I;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    h8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (kin && o0 + m * 32 + j < p.O) a = *(const h8*)(wp + (long)m * 32 * p.I + ks * 16);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (gy >= p.GH || gx >= p.GW) return;
+    const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
+    if (oy < 0 || oy >= p.OHt || ox < 0 || ox >= p.OWt) return;
+    _Float16* yp = p.y + (((long)n * p.OHt + oy) * p.OWt + ox) * p.O;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = o0 + m * 32 + q * 8 + kg * 4;
+            if ((p.O & 3) == 0 && o + 3 < p.O) {
+                h4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q * 4 + e] + (p.bias ? p.bias[o + e] : 0.f));
+                *(h4*)(yp + o) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (o + e < p.O) yp[o + e] = (_Float16)(acc[m][q * 4 + e] + (p.bias ? p.bias[o + e] : 0.f));
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int WR = 4;                // output rows per staged block
+constexpr int WC = 16;               // output columns per staged block = one MFMA k-step
+constexpr int WPS = 72;              // halves per staged pixel (64 channels + 8 padding: 144-byte stride)
+
+struct WgradP {
+    const _Float16* x;               // [N,H,W,I]
+    const _Float16* g;               // [N,OH,OW,O]
+    float* part;                     // [slices][NT][OP][IP] fp32 partial sums (OP, IP = O, I rounded up to 64)
+    int N, I, O, H, W, OH, OW;
+    int s, pad, k;                   // stride, padding, kernel size (1 or 3)
+    int bx, by;                      // blocks per image along x / y
+    long nblocks;                    // N * by * bx
+    int slices, OP, IP;
+    int XR, XC;                      // staged input rows / columns per block
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
+    _Float16* sg = sm;                               // [WR*WC][WPS]   g tile: pixel-major, 64 output channels
+    _Float16* sx = sm + WR * WC * WPS;               // [XR*XC][WPS]   x tile: pixel-major, 64 input channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
+    const int it = blockIdx.x % (p.IP / 64), ot = blockIdx.x / (p.IP / 64);
+    const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;                 // this wave's 32 x 32 corner of the 64 x 64 tile
+    f16x acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int K = p.k;
+    for (long blk = blockIdx.y; blk < p.nblocks; blk += p.slices) {
+        const int bxi = (int)(blk % p.bx);
+        const long rest = blk / p.bx;
+        const int byi = (int)(rest % p.by), n = (int)(rest / p.by);
+        const int oy0 = byi * WR, ox0 = bxi * WC;
+        __syncthreads();
+        // g tile: WR x WC pixels x 64 channels (8 lanes x 16 bytes per pixel)
+        for (int e = tid; e < WR * WC * 8; e += 256) {
+            const int q = e & 7, pp = e >> 3, r = pp / WC, c = pp - r * WC;
+            const int oy = oy0 + r, ox = ox0 + c, ch = ot * 64 + q * 8;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (oy < p.OH && ox < p.OW && ch < p.O) v = *(const h8*)(p.g + (((long)n * p.OH + oy) * p.OW + ox) * p.O + ch);
+            *(h8*)(sg + pp * WPS + q * 8) = v;
+        }
+        const int iy0 = oy0 * p.s - p.pad, ix0 = ox0 * p.s - p.pad;
+        for (int e = tid; e < p.XR * p.XC * 8; e += 256) {
+            const int q = e & 7, pp = e >> 3, r = pp / p.XC, c = pp - r * p.XC;
+            const int iy = iy0 + r, ix = ix0 + c, ch = it * 64 + q * 8;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.I) v = *(const h8*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.I + ch);
+            *(h8*)(sx + pp * WPS + q * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < WR; ++r) {
+            // A[o][k]: 8 consecutive pixels of row r for output channel wo + j
+            h8 a;
+            const _Float16* ap = sg + (r * WC + kg * 8) * WPS + wo + j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = ap[e * WPS];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ky = t / K, kx = t - ky * K;
+                const _Float16* bp = sx + ((r * p.s + ky) * p.XC + kg * 8 * p.s + kx) * WPS + wi + j;
+                h8 b;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[e] = bp[e * p.s * WPS];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // partial sums: row (o) = (r & 3) + 8 (r >> 2) + 4 kg, column (i) = j
+    float* pp = p.part + (long)blockIdx.y * NT * p.OP * p.IP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = ot * 64 + wo + (r & 3) + 8 * (r >> 2) + 4 * kg, i = it * 64 + wi + j;
+            pp[((long)t * p.OP + o) * p.IP + i] = acc[t][r];
+        }
+}
+
+// dw[t][o][i] = sum over slices, fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, int slices, int NT, int O, int I, int OP, int IP) {
+    const long total = (long)NT * O * I;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int i = (int)(e % I);
+        const long r = e / I;
+        const int o = (int)(r % O), t = (int)(r / O);
+        const long src = ((long)t * OP + o) * IP + i, sl = (long)NT * OP * IP;
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += part[k * sl + src];
+        dw[e] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FIR resampling, NHWC halves (upfirdn2d.cu:29-92 generic gather; fp32 accumulation as its `scalar_t` -> float path)
+// ---------------------------------------------------------------------------------------------------------------------------
+struct UfdH {
+    const _Float16* x;
+    const float* f;
+    _Float16* y;
+    int N, C, H, W, OH, OW, fh, fw, upx, upy, dnx, dny, px0, py0, flip;
+    float gain;
+};
+
+__global__ __launch_bounds__(256) void upfirdn2d_f16_kernel(const UfdH p) {
+    __shared__ float sf[64];
+    for (int k = threadIdx.x; k < p.fh * p.fw; k += 256) {
+        const int ky = k / p.fw, kx = k - ky * p.fw;
+        const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
+        sf[k] = p.f[sy * p.fw + sx] * p.gain;
+    }
+    __syncthreads();
+    const int c8n = p.C >> 3;
+    const long total = (long)p.N * p.OH * p.OW * c8n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % c8n);
+        long r = e / c8n;
+        const int ox = (int)(r % p.OW);
+        r /= p.OW;
+        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ky = 0; ky < p.fh; ++ky) {
+            const int uy = oy * p.dny + ky - p.py0;
+            if (uy < 0 || (uy % p.upy) != 0) continue;
+            const int iy = uy / p.upy;
+            if (iy >= p.H) continue;
+            for (int kx = 0; kx < p.fw; ++kx) {
+                const int ux = ox * p.dnx + kx - p.px0;
+                if (ux < 0 || (ux % p.upx) != 0) continue;
+                const int ix = ux / p.upx;
+                if (ix >= p.W) continue;
+                const h8 xv = *(const h8*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.C + c8 * 8);
+                const float fk = sf[ky * p.fw + kx];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += (float)xv[q] * fk;
+            }
+        }
+        h8 out;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[q] = (_Float16)v[q];
+        *(h8*)(p.y + e * 8) = out;
+    }
+}
+
+// y = lrelu_agc(x + bias[c]) on NHWC halves (arithmetic in fp32, one rounding), and its gradient from the saved output
+__global__ __launch_bounds__(256) void bias_act_f16_kernel(const _Float16* x, const float* bias, _Float16* y, long total8, int C, int act,
+                                                           float alpha, float gain, float clamp) {
+    const int c8n = C >> 3;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % c8n) * 8;
+        const h8 v = *(const h8*)(x + e * 8);
+        h8 out;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float t = (float)v[q] + (bias ? bias[c + q] : 0.f);
+            t = act ? shg_lrelu_agc(t, alpha, gain, clamp) : t * gain;
+            out[q] = (_Float16)t;
+        }
+        *(h8*)(y + e * 8) = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float16* g, const _Float16* y, _Float16* dx, long total8, int act,
+                                                                    float alpha, float gain, float clamp) {
+    const float gp = gain, gn = act ? alpha * gain : gain;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long)gridDim.x * 256) {
+        const h8 gv = *(const h8*)(g + e * 8), yv = *(const h8*)(y + e * 8);
+        h8 out;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v = (float)yv[q];
+            const float slope = (act && clamp >= 0.f && fabsf(v) >= clamp) ? 0.f : (v > 0.f ? gp : gn);
+            out[q] = (_Float16)((float)gv[q] * slope);
+        }
+        *(h8*)(dx + e * 8) = out;
+    }
+}
+
+template <int MB>
+static int launch_conv(const ConvP& p, hipStream_t st) {
+    const dim3 grid((unsigned)((long)p.N * p.tiles_x * p.tiles_y), (unsigned)shg_cdiv(p.O, MB * 32));
+    const size_t lds = (size_t)p.PH * p.PW * PSTR * sizeof(_Float16);
+    switch (p.ntaps) {
+        case 1: hipLaunchKernelGGL((conv_f16_kernel<MB, 1>), grid, dim3(256), lds, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_f16_kernel<MB, 2>), grid, dim3(256), lds, st, p); break;
+        case 4: hipLaunchKernelGGL((conv_f16_kernel<MB, 4>), grid, dim3(256), lds, st, p); break;
+        case 9: hipLaunchKernelGGL((conv_f16_kernel<MB, 9>), grid, dim3(256), lds, st, p); break;
+        default: shg_set_error("conv2d_f16: %d taps", p.ntaps); return SHG_ERR_UNSUPPORTED;
+    }
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// one launch of the gather convolution for a tap list; dy/dx are INPUT offsets relative to (oy'*s_in, ox'*s_in)
+static int conv_taps(ConvP p, int ntaps, const int* dy, const int* dx, const int* slot, int GH, int GW, hipStream_t st) {
+    if (GH <= 0 || GW <= 0) return SHG_OK;
+    int mny = dy[0], mxy = dy[0], mnx = dx[0], mxx = dx[0];
+    for (int t = 1; t < ntaps; ++t) {
+        mny = dy[t] < mny ? dy[t] : mny; mxy = dy[t] > mxy ? dy[t] : mxy;
+        mnx = dx[t] < mnx ? dx[t] : mnx; mxx = dx[t] > mxx ? dx[t] : mxx;
+    }
+    p.ntaps = ntaps;
+    for (int t = 0; t < ntaps; ++t) { p.tdy[t] = dy[t] - mny; p.tdx[t] = dx[t] - mnx; p.tw[t] = slot[t]; }
+    p.org_y = mny; p.org_x = mnx;
+    p.PH = (TH - 1) * p.s_in + (mxy - mny) + 1;
+    p.PW = (TW - 1) * p.s_in + (mxx - mnx) + 1;
+    p.GH = GH; p.GW = GW;
+    p.tiles_y = shg_cdiv(GH, TH); p.tiles_x = shg_cdiv(GW, TW);
+    if (p.O > 128) return launch_conv<4>(p, st);
+    if (p.O > 32) return launch_conv<2>(p, st);
+    return launch_conv<1>(p, st);
+}
+
+}  // namespace f16
+
+// x [N,H,W,I] halves, w [kh*kw][O][I] halves (cross-correlation taps in row-major (ky,kx) order), bias fp32 [O] or null, y halves.
+//   mode 0: y[N,OH,OW,O] = conv2d(x, w, stride, pad)                      OH = (H + 2 pad - k) / stride + 1
+//   mode 1: y[N,OH,OW,O] = rows / columns [crop, crop + OH) of conv_transpose2d(x, w, stride 2) (3x3; w[t][o][i] = torch weight[i][o][ky][kx]),
+//           zero where the (2H+1) x (2W+1) result ends earlier.  I % 16 == 0.
+extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride,
+                              int pad, int mode, int crop, int OH, int OW, void* stream) {
+    SHG_CHECK_ARG(x && w && y, "conv2d_f16: null pointer");
+    SHG_CHECK_ARG(N >= 1 && I >= 16 && (I % 16) == 0 && O >= 1 && H >= 1 && W >= 1, "conv2d_f16: bad shape (I must be a multiple of 16)");
+    SHG_CHECK_ARG((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= k, "conv2d_f16: 1x1 / 3x3 kernels, stride 1 / 2");
+    f16::ConvP p{};
+    p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.y = (_Float16*)y;
+    p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OHt = OH; p.OWt = OW;
+    hipStream_t st = (hipStream_t)stream;
+    int dy[9], dx[9], slot[9];
+    if (mode == 0) {
+        SHG_CHECK_ARG(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1 && OH >= 1 && OW >= 1, "conv2d_f16: output extent");
+        p.s_in = stride; p.s_out = 1; p.oy0 = 0; p.ox0 = 0;
+        for (int t = 0; t < k * k; ++t) { dy[t] = t / k - pad; dx[t] = t % k - pad; slot[t] = t; }
+        return f16::conv_taps(p, k * k, dy, dx, slot, OH, OW, st);
+    }
+    SHG_CHECK_ARG(mode == 1 && k == 3 && stride == 2 && crop >= 0 && OH >= 1 && OW >= 1, "conv2d_f16: the transposed form is 3x3 stride 2");
+    // full[oy][ox] = sum_{ky,kx} x[(oy-ky)/2][(ox-kx)/2] w[ky][kx] over even (oy-ky), (ox-kx); phase (py,px) = parity of (oy,ox)
+    p.s_in = 1; p.s_out = 2;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            int nt = 0;
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2) { dy[nt] = -(ky / 2); dx[nt] = -(kx / 2); slot[nt] = ky * 3 + kx; ++nt; }
+            p.oy0 = py - crop; p.ox0 = px - crop;
+            // grid rows oy' with 0 <= 2 oy' + py < 2H+1 intersected with the crop window [crop, crop + OH)
+            const int GH = py ? H : H + 1, GW = px ? W : W + 1;
+            const int rc = f16::conv_taps(p, nt, dy, dx, slot, GH, GW, st);
+            if (rc != SHG_OK) return rc;
+        }
+    return SHG_OK;
+}
+
+// the transposed form writes every pixel of its crop window only where the (2H+1) x (2W+1) result exists: callers zero y first when
+// crop + OH > 2H + 1 (shg_conv2d_f16_needs_clear says so)
+extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW) {
+    return (crop + OH > 2 * H + 1 || crop + OW > 2 * W + 1) ? 1 : 0;
+}
+
+extern "C" size_t shg_conv2d_wgrad_f16_workspace_bytes(int N, int I, int O, int OH, int OW, int k) {
+    const int OP = (O + 63) / 64 * 64, IP = (I + 63) / 64 * 64;
+    const long nblocks = (long)N * shg_cdiv(OH, f16::WR) * shg_cdiv(OW, f16::WC);
+    const long tiles = (long)(OP / 64) * (IP / 64);
+    long slices = (2048 + tiles - 1) / tiles;
+    if (slices > nblocks) slices = nblocks;
+    if (slices < 1) slices = 1;
+    return (size_t)slices * k * k * OP * IP * sizeof(float);
+}
+
+// dw [k*k][O][I] fp32 = sum_{n,oy,ox} g[n,oy,ox,o] x[n, oy*stride - pad + ky, ox*stride - pad + kx, i]; x [N,H,W,I], g [N,OH,OW,O] halves
+extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int N, int I, int O, int H, int W, int OH, int OW, int k, int stride,
+                                    int pad, void* workspace, size_t ws_bytes, void* stream) {
+    SHG_CHECK_ARG(x && g && dw && workspace, "conv2d_wgrad_f16: null pointer");
+    SHG_CHECK_ARG(N >= 1 && I >= 8 && (I % 8) == 0 && O >= 8 && (O % 8) == 0, "conv2d_wgrad_f16: I and O must be multiples of 8");
+    SHG_CHECK_ARG((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad >= 0, "conv2d_wgrad_f16: 1x1 / 3x3 kernels, stride 1 / 2");
+    SHG_CHECK_ARG(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1, "conv2d_wgrad_f16: output extent");
+    SHG_CHECK_ARG(ws_bytes >= shg_conv2d_wgrad_f16_workspace_bytes(N, I, O, OH, OW, k), "conv2d_wgrad_f16: workspace too small");
+    f16::WgradP p{};
+    p.x = (const _Float16*)x; p.g = (const _Float16*)g; p.part = (float*)workspace;
+    p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.s = stride; p.pad = pad; p.k = k;
+    p.OP = (O + 63) / 64 * 64; p.IP = (I + 63) / 64 * 64;
+    p.by = shg_cdiv(OH, f16::WR); p.bx = shg_cdiv(OW, f16::WC);
+    p.nblocks = (long)N * p.by * p.bx;
+    const long tiles = (long)(p.OP / 64) * (p.IP / 64);
+    long slices = (2048 + tiles - 1) / tiles;
+    if (slices > p.nblocks) slices = p.nblocks;
+    p.slices = (int)slices;
+    p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
+    const size_t lds = ((size_t)f16::WR * f16::WC + (size_t)p.XR * p.XC) * f16::WPS * sizeof(_Float16);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)tiles, (unsigned)slices);
+    if (k == 3) hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<9>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<1>), grid, dim3(256), lds, st, p);
+    SHG_CHECK_LAUNCH();
+    const long total = (long)k * k * O * I;
+    hipLaunchKernelGGL(f16::wgrad_reduce_kernel, dim3(shg_cdiv(total, 256) > 2048 ? 2048 : shg_cdiv(total, 256)), dim3(256), 0, st,
+                       (const float*)workspace, dw, p.slices, k * k, O, I, p.OP, p.IP);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// upfirdn2d on NHWC halves: the semantics of shg_upfirdn2d_f32 / upfirdn2d.cu:29-92; C % 8 == 0
+extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, int C, int H, int W, int fh, int fw, int upx, int upy, int downx,
+                                 int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream) {
+    SHG_CHECK_ARG(x && f && y, "upfirdn2d_f16: null pointer");
+    SHG_CHECK_ARG(N >= 1 && C >= 8 && (C % 8) == 0 && H >= 1 && W >= 1, "upfirdn2d_f16: bad shape (C must be a multiple of 8)");
+    SHG_CHECK_ARG(fh >= 1 && fw >= 1 && fh * fw <= 64 && upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "upfirdn2d_f16: bad filter / factors");
+    const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx, OH = (H * upy + pady0 + pady1 - fh + downy) / downy;
+    SHG_CHECK_ARG(OW >= 1 && OH >= 1, "upfirdn2d_f16: empty output");
+    f16::UfdH p{(const _Float16*)x, f, (_Float16*)y, N, C, H, W, OH, OW, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain};
+    const long total = (long)N * OH * OW * (C / 8);
+    int grid = shg_cdiv(total, 256);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(f16::upfirdn2d_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+extern "C" int shg_bias_act_f16(const void* x, const float* bias, void* y, long pixels, int C, int act, float alpha, float gain, float clamp,
+                                void* stream) {
+    SHG_CHECK_ARG(x && y, "bias_act_f16: null pointer");
+    SHG_CHECK_ARG(pixels >= 0 && C >= 8 && (C % 8) == 0, "bias_act_f16: C must be a multiple of 8");
+    const long total8 = pixels * (C / 8);
+    if (total8 == 0) return SHG_OK;
+    int grid = shg_cdiv(total8, 256);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(f16::bias_act_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, bias, (_Float16*)y, total8, C,
+                       act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+extern "C" int shg_bias_act_backward_f16(const void* g, const void* y, void* dx, long total, int act, float alpha, float gain, float clamp,
+                                         void* stream) {
+    SHG_CHECK_ARG(g && y && dx, "bias_act_backward_f16: null pointer");
+    SHG_CHECK_ARG(total >= 0 && (total % 8) == 0, "bias_act_backward_f16: element count must be a multiple of 8");
+    if (total == 0) return SHG_OK;
+    int grid = shg_cdiv(total / 8, 256);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(f16::bias_act_backward_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)g, (const _Float16*)y,
+                       (_Float16*)dx, total / 8, act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

@@ -1,0 +1,170 @@
+"""Host wrappers of the fp16 entry points of libshgan_hip.so (csrc/conv_f16.hip; include/shgan_hip.h "fp16 route") -- the kernels
+behind the reference's ``use_fp16`` branches (stylegan.py:136-138,486,660-667; comodgan.py:40-47,305).
+
+Every fp16 activation is a ``[N,C,H,W]`` torch tensor in ``torch.channels_last`` memory format (= dense NHWC in HBM): the module
+API keeps the reference's logical shapes, the kernels get 8 consecutive channels per 16-byte MFMA operand.  A tensor that arrives in
+another layout is converted (one pass); outputs are channels_last.  fp32 accumulation everywhere, one rounding to fp16.
+No CPU path, no fallback: a non-HIP tensor raises."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, kernels
+from ._lib import check
+
+CL = torch.channels_last
+
+
+def _h(L, t, name):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.ShgError(f'{name} must reside on a HIP (cuda) device: libshgan_hip has no CPU path')
+    if t.dtype != torch.float16 or t.ndim != 4:
+        raise _lib.ShgError(f'{name} must be a rank-4 float16 tensor (got {t.dtype}, rank {t.ndim})')
+    L._own(t, name)
+    if not t.is_contiguous(memory_format=CL):
+        t = t.contiguous(memory_format=CL)
+    L.keep.append(t)
+    return t
+
+
+def _new_cl(L, n, c, h, w, zero=False):
+    y = torch.empty((n, c, h, w), device=L.dev, dtype=torch.float16, memory_format=CL)
+    return y.zero_() if zero else y
+
+
+def _pad_channels(x, mult):
+    """Zero-pad the channel dimension of an NHWC tensor to a multiple of ``mult`` (thin inputs: fromrgb has 4 channels)."""
+    c = x.shape[1]
+    cp = (c + mult - 1) // mult * mult
+    if cp == c:
+        return x
+    y = torch.empty((x.shape[0], cp, x.shape[2], x.shape[3]), device=x.device, dtype=x.dtype, memory_format=CL).zero_()
+    y[:, :c] = x
+    return y
+
+
+def _taps_weight(w_oihw, i_mult):
+    """[O,I,kh,kw] halves -> [kh*kw][O][Ip] contiguous, input channels zero-padded to a multiple of ``i_mult``."""
+    o, i, kh, kw = w_oihw.shape
+    wt = w_oihw.permute(2, 3, 0, 1)
+    ip = (i + i_mult - 1) // i_mult * i_mult
+    if ip != i:
+        wt = F.pad(wt, (0, ip - i))
+    return wt.contiguous()
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0):
+    """F.conv2d(x, weight, bias, stride, padding) on halves: x [N,I,H,W], weight [O,I,k,k] (k = 1 | 3) -> [N,O,OH,OW]."""
+    L = kernels._Launch()
+    x = _h(L, x, 'x')
+    if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
+        raise _lib.ShgError('conv2d_f16: weight must be float16 [O,I,k,k] with k = 1 or 3')
+    if weight.shape[1] != x.shape[1]:
+        raise _lib.ShgError(f'conv2d_f16: weight expects {weight.shape[1]} input channels, x has {x.shape[1]}')
+    L._own(weight, 'weight')
+    n, i, h, w = x.shape
+    o, k = weight.shape[0], weight.shape[2]
+    oh, ow = (h + 2 * padding - k) // stride + 1, (w + 2 * padding - k) // stride + 1
+    if oh < 1 or ow < 1:
+        raise _lib.ShgError('conv2d_f16: empty output')
+    xp = _pad_channels(x, 16)
+    wt = _taps_weight(weight.detach(), 16)
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    y = _new_cl(L, n, o, oh, ow)
+    with kernels._timed(L, 'conv_f16', 2.0 * n * o * i * k * k * oh * ow):
+        check(_lib.get_lib().shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, k,
+                                            stride, padding, 0, 0, oh, ow, L.stream()), 'conv2d_f16')
+    return y
+
+
+def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None):
+    """Rows / columns [padding, padding + oh) of F.conv_transpose2d(x, weight [Cin,Cout,3,3], stride 2) on halves, zero where the
+    (2H+1) x (2W+1) result ends earlier (the ``output_padding`` rule of conv2d_gradfix.py:96-105 when used as an input gradient)."""
+    L = kernels._Launch()
+    x = _h(L, x, 'x')
+    if weight.dtype != torch.float16 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[0] != x.shape[1]:
+        raise _lib.ShgError('conv_transpose2d_f16: weight must be float16 [Cin,Cout,3,3] matching x')
+    L._own(weight, 'weight')
+    n, i, h, w = x.shape
+    o = weight.shape[1]
+    oh, ow = out_hw if out_hw is not None else (2 * h + 1 - 2 * padding, 2 * w + 1 - 2 * padding)
+    xp = _pad_channels(x, 16)
+    wt = _taps_weight(weight.detach().transpose(0, 1), 16)
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    lib = _lib.get_lib()
+    y = _new_cl(L, n, o, oh, ow, zero=bool(lib.shg_conv2d_f16_needs_clear(h, w, padding, oh, ow)))
+    with kernels._timed(L, 'conv_f16_up', 2.0 * n * o * i * 9 * h * w):
+        check(lib.shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, 3, 2, 0, 1,
+                                 padding, oh, ow, L.stream()), 'conv_transpose2d_f16')
+    return y
+
+
+def conv2d_wgrad(x, g, k, stride, padding):
+    """dL/dweight [O,I,k,k] (float16, as the weight it belongs to) of y = conv2d(x, weight, stride, padding) from g = dL/dy; the sum
+    over pixels runs in fp32 on the device and is rounded once."""
+    L = kernels._Launch()
+    x, g = _h(L, x, 'x'), _h(L, g, 'g')
+    n, i, h, w = x.shape
+    o, oh, ow = g.shape[1], g.shape[2], g.shape[3]
+    if g.shape[0] != n or oh != (h + 2 * padding - k) // stride + 1 or ow != (w + 2 * padding - k) // stride + 1:
+        raise _lib.ShgError(f'conv2d_wgrad_f16: g {tuple(g.shape)} is not the output extent of x {tuple(x.shape)} (k={k}, stride={stride}, padding={padding})')
+    xp, gp = _pad_channels(x, 8), _pad_channels(g, 8)
+    ip, op = xp.shape[1], gp.shape[1]
+    lib = _lib.get_lib()
+    nbytes = lib.shg_conv2d_wgrad_f16_workspace_bytes(n, ip, op, oh, ow, k)
+    ws = torch.empty(max(nbytes // 4, 1), device=L.dev, dtype=torch.float32)
+    dw = torch.empty((k * k, op, ip), device=L.dev, dtype=torch.float32)
+    with kernels._timed(L, 'conv_wgrad_f16', 2.0 * n * o * i * k * k * oh * ow):
+        check(lib.shg_conv2d_wgrad_f16(kernels._ptr(xp), kernels._ptr(gp), kernels._ptr(dw), n, ip, op, h, w, oh, ow, k, stride, padding,
+                                       kernels._ptr(ws), ctypes.c_size_t(nbytes), L.stream()), 'conv2d_wgrad_f16')
+    return dw[:, :o, :i].reshape(k, k, o, i).permute(2, 3, 0, 1).to(torch.float16).contiguous()
+
+
+def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0):
+    """``upfirdn2d_plugin.upfirdn2d`` for halves (upfirdn2d.cpp:59 dispatches the same op for at::Half): f float32 [fh,fw]."""
+    L = kernels._Launch()
+    x = _h(L, x, 'x')
+    f = L.req(f, 'f')
+    if f.ndim != 2:
+        raise _lib.ShgError('f must be rank 2')
+    n, c, h, w = x.shape
+    fh, fw = f.shape
+    oh, ow = kernels.upfirdn2d_out_size(h, w, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1)
+    if oh < 1 or ow < 1:
+        raise _lib.ShgError('upfirdn2d: output must be at least 1x1')
+    xp = _pad_channels(x, 8)
+    y = _new_cl(L, n, xp.shape[1], oh, ow)
+    with kernels._timed(L, 'upfirdn2d_f16', 2.0 * (x.numel() + n * c * oh * ow)):
+        check(_lib.get_lib().shg_upfirdn2d_f16(kernels._ptr(xp), kernels._ptr(f), kernels._ptr(y), n, xp.shape[1], h, w, fh, fw, upx, upy,
+                                               downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), L.stream()), 'upfirdn2d_f16')
+    return y if xp.shape[1] == c else y[:, :c].contiguous(memory_format=CL)
+
+
+def bias_act(x, bias=None, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    L = kernels._Launch()
+    x = _h(L, x, 'x')
+    n, c, h, w = x.shape
+    if c % 8:
+        raise _lib.ShgError('bias_act_f16: channel count must be a multiple of 8')
+    b = None if bias is None else L.req(bias.detach().to(torch.float32), 'bias')
+    a, al, g, cl = kernels._act_args(act, gain, alpha, act_gain, clamp)
+    y = _new_cl(L, n, c, h, w)
+    with kernels._timed(L, 'bias_act_f16', 2.0 * 2 * x.numel()):
+        check(_lib.get_lib().shg_bias_act_f16(kernels._ptr(x), kernels._ptr(b), kernels._ptr(y), n * h * w, c, a, al, g, cl, L.stream()), 'bias_act_f16')
+    return y
+
+
+def bias_act_backward(g, y, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    L = kernels._Launch()
+    g, y = _h(L, g, 'g'), _h(L, y, 'y')
+    if g.shape != y.shape or g.numel() % 8:
+        raise _lib.ShgError('bias_act_backward_f16: g and y must have the same shape, a multiple of 8 elements')
+    a, al, gn, cl = kernels._act_args(act, gain, alpha, act_gain, clamp)
+    dx = _new_cl(L, *g.shape)
+    with L:
+        check(_lib.get_lib().shg_bias_act_backward_f16(kernels._ptr(g), kernels._ptr(y), kernels._ptr(dx), g.numel(), a, al, gn, cl, L.stream()),
+              'bias_act_backward_f16')
+    return dx

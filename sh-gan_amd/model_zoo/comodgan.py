@@ -30,8 +30,9 @@ class encoder_block(discrim_block):
     """Down block that also returns its pre-downsample feature map (comodgan.py:38-64)."""
 
     def forward(self, x, img):
+        x = grad_ops.to_block_dtype(x, self.use_fp16)                            # comodgan.py:39-43
         if self.fromrgb is not None:
-            y = self.fromrgb(img.to(torch.float32))
+            y = self.fromrgb(grad_ops.to_block_dtype(img, self.use_fp16))        # :45-50
             x = _add(x, y) if x is not None else y
         if self.reslink:
             y = self.skip(x, gain=np.sqrt(0.5))
@@ -55,6 +56,7 @@ class encoder_epilogue(discrim_epilogue):
         self.dropout = nn.Dropout(p=0.5) if use_dropout else None
 
     def forward(self, x, img=None, cmap=None):
+        x = grad_ops.to_block_dtype(x, False)                                    # comodgan.py:99: the tail is always float32
         if self.fromrgb is not None:
             x = _add(x, self.fromrgb(img.to(torch.float32)))
         if self.mbstd is not None:
@@ -79,8 +81,6 @@ class Encoder(nn.Module):
         log2res = int(np.log2(resolution))
         if 2 ** log2res != resolution:
             raise ValueError
-        if use_fp16_before_res is not None and resolution > use_fp16_before_res:
-            raise NotImplementedError('the HIP path is fp32: pass use_fp16_before_res=None (as all shipped configs do)')
         if c_dim is not None and c_dim > 0:
             raise NotImplementedError('label-conditioned encoders are not on the SH-GAN path')
         self.encode_res = [2 ** i for i in range(log2res, 1, -1)]
@@ -89,8 +89,8 @@ class Encoder(nn.Module):
         for idx, (ri, rj) in enumerate(zip(self.encode_res[:-1], self.encode_res[1:])):
             ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
             setattr(self, 'b{}'.format(ri), encoder_block(ci, ci, cj, rgb_n=(ic_n if idx == 0 else None),
-                                                        resample_filter=resample_filter, activation=activation,
-                                                        reslink=False, use_fp16=False))
+                                                        resample_filter=resample_filter, activation=activation, reslink=False,
+                                                        use_fp16=(use_fp16_before_res is not None and ri > use_fp16_before_res)))   # comodgan.py:149
         self.mapping = None
         c4 = min(ch_base // self.encode_res[-1], ch_max)
         self.b4 = encoder_epilogue(c4, oc_n, resolution=4, cmap_dim=None, activation=activation,
@@ -164,6 +164,7 @@ class synthesis_block(stylegan_synthesis_block):
             self.torgb = torgb_layer(oc_n, rgb_n, 1, w_dim=w_dim + w0_dim, activation=None)
 
     def forward(self, x, x0, img, ws, w0, fused_modconv=None, noise_mode='random', style_cache=None):
+        x, x0 = grad_ops.to_block_dtype(x, self.use_fp16), grad_ops.to_block_dtype(x0, self.use_fp16)      # comodgan.py:305-312
         w_iter = iter(ws.unbind(dim=1))
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
@@ -191,8 +192,6 @@ class Synthesis(nn.Module):
         log2res = int(np.log2(resolution))
         if 2 ** log2res != resolution:
             raise ValueError
-        if use_fp16_after_res is not None and resolution > use_fp16_after_res:
-            raise NotImplementedError('the HIP path is fp32: pass use_fp16_after_res=None (as all shipped configs do)')
         self.block_res = [2 ** i for i in range(2, log2res + 1)]
         self.w_dim, self.resolution, self.rgb_n = w_dim, resolution, rgb_n
         if resolution in (256, 512, 1024):        # comodgan.py:367-372
@@ -202,8 +201,9 @@ class Synthesis(nn.Module):
         for ri, rj in zip(self.block_res[:-1], self.block_res[1:]):
             ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
             setattr(self, 'b{}'.format(rj), synthesis_block(ci, cj, w_dim=w_dim, w0_dim=w0_dim, resolution=rj, rgb_n=rgb_n,
-                                                          resample_filter=resample_filter, activation=activation,
-                                                          res_link=False, use_fp16=False))
+                                                          resample_filter=resample_filter, activation=activation, res_link=False,
+                                                          use_fp16=(use_fp16_after_res is not None and rj > use_fp16_after_res)))     # comodgan.py:382
+        self._any_fp16 = use_fp16_after_res is not None and resolution > use_fp16_after_res
 
     def forward(self, x, feats, ws, noise_mode='random'):
         ws = ws.to(torch.float32)
@@ -215,7 +215,8 @@ class Synthesis(nn.Module):
             w_idx += block.num_conv
         w0 = x
         # (training rows: every layer derives its own styles under autograd; the grouped style kernels are an inference-path fusion)
-        cache = None if grad_ops.wants_grad(x, ws, *self.parameters()) else self._all_styles(ws, w0.to(torch.float32))
+        # (... and so is the style cache: with float16 blocks every layer takes the generic route and derives its own styles)
+        cache = None if self.__dict__.get('_any_fp16') or grad_ops.wants_grad(x, ws, *self.parameters()) else self._all_styles(ws, w0.to(torch.float32))
         x, img = self.b4(x, feats[4], block_ws[0], noise_mode=noise_mode, style_cache=cache)
         for res, cur_ws in zip(self.block_res[1:], block_ws[1:]):
             x, img = getattr(self, f'b{res}')(x, feats[res], img, cur_ws, w0, noise_mode=noise_mode, style_cache=cache)

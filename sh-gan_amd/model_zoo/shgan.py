@@ -317,9 +317,12 @@ class Encoder(Encoder_base):
         x, feats = super().forward(img, c)
         src = feats[self.shu_input_res]
         ch = self.shu_channels
-        if grad_ops.wants_grad(src, *self.shu.parameters()):
-            # training rows (shgan.py:374-382): out-of-place split / add / cat so that autograd sees the hints
-            for r, v in self.shu(src[:, src.shape[1] - ch:]).items():
+        any_half = any(f.dtype == torch.float16 for f in feats.values())
+        if any_half or grad_ops.wants_grad(src, *self.shu.parameters()):
+            # training rows (shgan.py:374-382): out-of-place split / add / cat so that autograd sees the hints.  With float16 encoder
+            # blocks the SHU itself stays float32 -- its input is cast up (the reference hands a half tensor to torch.fft, which only
+            # cuFFT accepts: not reproducible on the CPU reference, stated in DESIGN.md) -- and `fb + v`, `cat` promote as torch does.
+            for r, v in self.shu(src[:, src.shape[1] - ch:].to(torch.float32)).items():
                 fa, fb = torch.split(feats[r], [feats[r].size(1) - ch, ch], dim=1)
                 feats[r] = torch.cat([fa, fb + v], dim=1)
             return x, feats

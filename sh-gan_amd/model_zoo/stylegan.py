@@ -12,7 +12,8 @@ MI355X-first differences:
   * weight layout transforms / demodulation tables are cached per layer and refreshed when the
     parameter changes (version counter), so an eval forward does no per-call weight work;
   * bias, noise, activation, skip-add, FIR and RGB-upsample are epilogues of the producing kernels.
-Inference only: there is no autograd support in the HIP path."""
+float32 is the default and the only arithmetic of the shipped configs; the ``use_fp16`` options of the reference run on the NHWC
+fp16-MFMA kernels (csrc/conv_f16.hip) through the non-fused algebra, with or without autograd."""
 import math
 
 import numpy as np
@@ -47,7 +48,7 @@ def _act_kwargs(act_obj, gain=1.0):
 
 def _add(a, b):
     """a + b: one fused kernel on the inference path, a differentiable tensor op on the training path."""
-    if grad_ops.wants_grad(a, b):
+    if grad_ops.generic_route(a, b):
         return a + b
     return kernels.bias_act(a, residual=b, act=False)
 
@@ -164,7 +165,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
     misc.assert_shape(x, [batch_size, in_channels, None, None])
     misc.assert_shape(styles, [batch_size, in_channels])
-    if grad_ops.wants_grad(x, weight, styles, noise):
+    if grad_ops.generic_route(x, weight, styles, noise):
         if _epilogue:
             raise NotImplementedError('modulated_conv2d: the fused epilogue is an inference-path extension')
         return _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight)
@@ -204,18 +205,30 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 
 
 def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight):
-    """Training rows: the non-fused form of stylegan.py:172-181 (what the reference runs while training) on differentiable
-    operators -- activations scaled by the styles, ONE shared-weight convolution (HIP forward / backward), demodulation
-    coefficient and noise applied afterwards.  The coefficient d[n,o] = rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + 1e-8) is evaluated
-    as rsqrt(s^2 @ (sum_k W^2)^T + 1e-8): the [N,O,I,k,k] tensor of stylegan.py:150-155 is never materialised."""
+    """Training rows and every float16 layer: the non-fused form of stylegan.py:172-181 (what the reference runs while training, and
+    for fp16 batches in eval: ``fused_modconv = (not training) and (fp32 or N == 1)``, :490) on differentiable operators -- activations
+    scaled by the styles, ONE shared-weight convolution (HIP forward / backward), demodulation coefficient and noise applied
+    afterwards.  The coefficient d[n,o] = rsqrt(sum_{i,k} (W[o,i,k] s[n,i])^2 + 1e-8) is evaluated as rsqrt(s^2 @ (sum_k W^2)^T + 1e-8):
+    the [N,O,I,k,k] tensor of stylegan.py:150-155 is never materialised.  float16: the pre-normalisation of :136-138 (weights by their
+    max-norm and 1/sqrt(fan-in), styles by their max-norm -- it cancels under demodulation and keeps x*s and the accumulators inside
+    the fp16 range), then styles / weights / coefficients / noise are cast to the activation dtype exactly where the reference casts."""
     n = x.shape[0]
     dcoefs = None
+    if x.dtype == torch.float16 and demodulate:
+        o, i, kh, kw = weight.shape
+        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))       # max_Ikk
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I
     if demodulate:
         weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
         styles = styles * styles.square().mean().rsqrt()                                   # :147
         dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
-    x = x * styles.reshape(n, -1, 1, 1)
-    x = conv2d_resample.conv2d_resample(x=x, w=weight, f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    if x.dtype == torch.float16:
+        # (tensor ops that keep the NHWC layout of x: the product first, the broadcast noise added in place)
+        if demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
+        return x if noise is None else x.add(noise.to(x.dtype))
     if demodulate and noise is not None:
         return torch.addcmul(noise, x, dcoefs.reshape(n, -1, 1, 1))                        # fma.py:15
     if demodulate:
@@ -251,16 +264,16 @@ class conv2d_layer(nn.Module):
     def _forward_train(self, x, gain=1):
         """Differentiable composition (training rows): convolution / FIR / bias + activation through their autograd forms."""
         ak = _act_kwargs(self.activation, gain)
-        y = conv2d_resample.conv2d_resample(x=x, w=self.weight * self.weight_gain, f=self.resample_filter, up=self.up,
+        y = conv2d_resample.conv2d_resample(x=x, w=(self.weight * self.weight_gain).to(x.dtype), f=self.resample_filter, up=self.up,
                                             down=self.down, padding=self.padding, flip_weight=(self.up == 1))
-        if ak is None:
+        if ak is None or (y.dtype == torch.float16 and y.shape[1] % 8):
             if self.bias is not None:
-                y = y + self.bias.view(1, -1, 1, 1)
-            return self.activation(y, gain=gain)
+                y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+            return self.activation(y, gain=gain) if self.activation is not None else y * gain
         return grad_ops.bias_act(y, self.bias, **ak)
 
     def forward(self, x, gain=1):
-        if grad_ops.wants_grad(x, self.weight, self.bias):
+        if grad_ops.generic_route(x, self.weight, self.bias):
             return self._forward_train(x, gain)
         ak = _act_kwargs(self.activation, gain)
         b = self.bias.detach() if self.bias is not None else None
@@ -337,8 +350,8 @@ class synthesis_layer(conv2d_layer):
         ak = _act_kwargs(self.activation, gain)
         if ak is None or self.up not in (1, 2) or self.weight.shape[2] != 3:
             raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
-        if grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight):
-            # training rows (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
+        if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight):
+            # training rows and float16 layers (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
             # non-fused modulated convolution, bias + activation; the skip tensor (extension) is added last
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w), noise=None if noise is None else noise * self.noise_strength,
                                  up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
@@ -371,10 +384,12 @@ class torgb_layer(conv2d_layer):
     def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None, styles_sd=None):
         if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
             raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
-        if grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, base_img):
-            # training rows (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338)
+        if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight, base_img):
+            # training rows and float16 blocks (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338);
+            # the RGB branch itself is float32 (`y.to(torch.float32)`, comodgan.py:337)
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w) * self.weight_gain, demodulate=False)
-            y = y + self.bias.view(1, -1, 1, 1)
+            y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
         if styles_sd is not None:
             s = styles_sd[0]
@@ -450,8 +465,6 @@ class synthesis_block(nn.Module):
     def __init__(self, ic_n, oc_n, w_dim, resolution, rgb_n=None, resample_filter=[1, 3, 3, 1],
                  activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', res_link=False, use_fp16=False):
         super().__init__()
-        if use_fp16:
-            raise NotImplementedError('the HIP path is fp32 (all shipped SH-GAN configs run fp32)')
         self.w_dim, self.resolution, self.use_fp16, self.res_link = w_dim, resolution, use_fp16, res_link
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         self.num_conv = 0
@@ -477,6 +490,7 @@ class synthesis_block(nn.Module):
     def forward(self, x, img, ws, fused_modconv=None, noise_mode='random'):
         if self.const is not None:
             x = (self.const if grad_ops.wants_grad(self.const) else self.const.detach()).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        x = grad_ops.to_block_dtype(x, self.use_fp16)                            # stylegan.py:486-495
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
         w_iter = iter(ws.unbind(dim=1))
@@ -508,7 +522,8 @@ class Synthesis(nn.Module):
             ci = min(ch_base // resi, ch_max) if resi is not None else 0
             cj = min(ch_base // resj, ch_max)
             block = synthesis_block(ci, cj, w_dim=w_dim, resolution=resj, rgb_n=rgb_n, resample_filter=resample_filter,
-                                    activation=activation, res_link=False, use_fp16=False)
+                                    activation=activation, res_link=False,
+                                    use_fp16=(use_fp16_after_res is not None and resj > use_fp16_after_res))          # stylegan.py:550
             self.num_ws += block.num_conv
             if resj == self.block_res[-1]:
                 self.num_ws += block.num_torgb
@@ -555,8 +570,6 @@ class discrim_block(nn.Module):
     def __init__(self, ic_n, mc_n, oc_n, rgb_n=None, resample_filter=[1, 3, 3, 1],
                  activation='lrelu_agc(alpha=0.2, gain=sqrt_2, clamp=256)', reslink=False, use_fp16=False):
         super().__init__()
-        if use_fp16:
-            raise NotImplementedError('the HIP path is fp32 (all shipped SH-GAN configs run fp32)')
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         self.fromrgb = None
         if rgb_n is not None:
@@ -570,8 +583,9 @@ class discrim_block(nn.Module):
         self.use_fp16 = use_fp16
 
     def forward(self, x, img):
+        x = grad_ops.to_block_dtype(x, self.use_fp16)                            # stylegan.py:659-663
         if self.fromrgb is not None:
-            y = self.fromrgb(img.to(torch.float32))
+            y = self.fromrgb(grad_ops.to_block_dtype(img, self.use_fp16))        # :665-670
             x = _add(x, y) if x is not None else y
         img = None
         if self.reslink:
@@ -621,6 +635,7 @@ class discrim_epilogue(nn.Module):
         self.out = dense(ic_n, 1 if cmap_dim is None else cmap_dim, activation=None)
 
     def forward(self, x, img=None, cmap=None):
+        x = grad_ops.to_block_dtype(x, False)                                    # stylegan.py:744: the tail is always float32
         if self.fromrgb is not None:
             x = _add(x, self.fromrgb(img.to(torch.float32)))
         if self.mbstd is not None:
@@ -645,16 +660,14 @@ class Discriminator(nn.Module):
         log2res = int(np.log2(resolution))
         if 2 ** log2res != resolution:
             raise ValueError
-        if use_fp16_before_res is not None and resolution > use_fp16_before_res:
-            raise NotImplementedError('the HIP path is fp32: pass use_fp16_before_res=None (as all shipped configs do)')
         self.encode_res = [2 ** i for i in range(log2res, 1, -1)]
         self.ic_n, self.ch_base, self.ch_max = ic_n, ch_base, ch_max
         self.resample_filter, self.activation = resample_filter, activation
         for idx, (ri, rj) in enumerate(zip(self.encode_res[:-1], self.encode_res[1:])):
             ci, cj = min(ch_base // ri, ch_max), min(ch_base // rj, ch_max)
             setattr(self, 'b{}'.format(ri), discrim_block(ci, ci, cj, rgb_n=(ic_n if idx == 0 else None),
-                                                          resample_filter=resample_filter, activation=activation,
-                                                          reslink=True, use_fp16=False))
+                                                          resample_filter=resample_filter, activation=activation, reslink=True,
+                                                          use_fp16=(use_fp16_before_res is not None and ri > use_fp16_before_res)))   # stylegan.py:788
         self.mapping = None
         if c_dim is not None and c_dim > 0:
             # the reference cannot build this either: its Mapping passes an unknown keyword to `dense` when c_dim > 0

@@ -13,7 +13,7 @@ themselves written with these operators (and ``_WgradFn`` has the derivatives of
 conv2d_gradfix.py:148-163), so gradients of gradients work: the R1 and path-length regularisers differentiate twice."""
 import torch
 
-from ... import kernels
+from ... import kernels, kernels_f16
 
 PLANAR_CONVT = True                  # transposed convolutions: phase planes + interleave pass (False: the direct interleaved kernel)
 enabled = True                       # (conv2d_gradfix.py:22) -- the HIP path is the only path; kept for interface compatibility
@@ -41,16 +41,25 @@ def _one(v):
     return int(v)
 
 
+def _dense(t):
+    """Dense in the layout the kernels of its dtype take: NCHW for float32, NHWC (channels_last) for float16."""
+    return t.contiguous(memory_format=torch.channels_last) if t.dtype == torch.float16 and t.ndim == 4 else t.contiguous()
+
+
 def _fit(y, h, w, lo):
     """Rows/cols [lo, lo+h) x [lo, lo+w) of y, zero-extended where y ends earlier (output_padding)."""
     y = y[:, :, lo:lo + h, lo:lo + w]
     dh, dw = h - y.shape[2], w - y.shape[3]
     if dh or dw:
         y = torch.nn.functional.pad(y, (0, dw, 0, dh))
-    return y.contiguous()
+    return _dense(y)
 
 
 def _conv_fwd(x, weight, bias, stride, padding, groups):
+    if x.dtype == torch.float16:             # the reference's fp16 blocks (stylegan.py:486,660-667): NHWC fp16-MFMA kernels, fp32 accumulation
+        if groups != 1:
+            raise NotImplementedError('conv2d: grouped fp16 convolutions (the fused N=1 form, stylegan.py:187-190) are not built; fp16 layers run the non-fused algebra')
+        return kernels_f16.conv2d(x, weight.to(torch.float16), bias, stride, padding)
     n, c, h, w = x.shape
     pw = kernels.conv_weight_prep(weight, groups=groups)
     y = kernels.conv2d(x.reshape(n * groups, c // groups, h, w), pw, mode=kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2,
@@ -64,6 +73,10 @@ def _conv_fwd(x, weight, bias, stride, padding, groups):
 def _convt_fwd(x, weight, bias, padding, groups, out_hw=None):
     """conv_transpose2d(x, weight [Cin, Cout/g, 3, 3], stride 2) cropped by ``padding`` on every side; with ``out_hw`` = (h, w) the
     rows / columns [padding, padding + h) x [padding, padding + w) instead, zero where the result ends earlier (``_fit``)."""
+    if x.dtype == torch.float16:
+        if groups != 1:
+            raise NotImplementedError('conv_transpose2d: grouped fp16 transposed convolutions are not built')
+        return kernels_f16.conv_transpose2d(x, weight.to(torch.float16), bias, padding, out_hw)
     n, c, h, w = x.shape
     ci_g, co_g = weight.shape[0] // groups, weight.shape[1]
     # torch layout [Cin, Cout/g, kh, kw] -> per group [Cout/g, Cin/g, kh, kw]
@@ -109,6 +122,8 @@ class _WgradFn(torch.autograd.Function):
     def forward(ctx, g, x, k, stride, padding):
         ctx.save_for_backward(g, x)
         ctx.geom = (k, stride, padding)
+        if x.dtype == torch.float16:
+            return kernels_f16.conv2d_wgrad(x.detach(), g.detach().to(torch.float16), k, stride, padding)
         return kernels.conv2d_wgrad(x.detach().contiguous(), g.detach().contiguous(), k, k, stride, padding)
 
     @staticmethod
@@ -136,7 +151,7 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         stride, padding, has_bias = ctx.geom
-        g = g.contiguous()
+        g = _dense(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(g, weight, x.shape, stride, padding)
@@ -160,7 +175,7 @@ class _ConvTranspose2dFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         padding, has_bias = ctx.geom
-        g = g.contiguous()
+        g = _dense(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = conv2d(g, weight, stride=2, padding=padding)                     # conv2d_gradfix.py:124-127, transpose flipped

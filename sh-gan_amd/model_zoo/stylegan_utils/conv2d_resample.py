@@ -21,8 +21,8 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
         if padding[0] != padding[1]:
             raise NotImplementedError('asymmetric conv padding')
         padding = padding[0]
-    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-        # training path (conv2d_resample.py:26-51 verbatim in structure): flip for a true convolution, the transposed form takes
+    if x.dtype == torch.float16 or (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
+        # training path and every float16 tensor (conv2d_resample.py:26-51 verbatim in structure): flip for a true convolution, the transposed form takes
         # the weight as [Cin, Cout, kh, kw]
         if groups != 1:
             raise NotImplementedError('grouped convolutions are forward only')

@@ -3,7 +3,9 @@
 The reference JIT-compiles its CUDA plugin with nvcc/ninja and caches it by md5 digest; here the
 HIP library is prebuilt (sh-gan_amd/build.py) and ``get_plugin`` just returns a handle exposing the
 same single entry point the pybind module had (upfirdn2d.cpp:98-101)."""
-from ... import _lib, kernels
+import torch
+
+from ... import _lib, kernels, kernels_f16
 
 _plugins = {}
 
@@ -13,6 +15,8 @@ class _Upfirdn2dPlugin:
 
     @staticmethod
     def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+        if x.dtype == torch.float16:         # upfirdn2d.cpp:59 AT_DISPATCH_FLOATING_TYPES_AND_HALF: halves, NHWC (torch.channels_last)
+            return kernels_f16.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
         return kernels.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
 
 

@@ -1,0 +1,237 @@
+"""The fp16 route (the reference's ``use_fp16`` branches: stylegan.py:136-138,486,660-667; comodgan.py:40-47,305; native op
+upfirdn2d.cpp:59) on the NHWC fp16-MFMA kernels of csrc/conv_f16.hip, against fixtures the REFERENCE produced by running those very
+branches on CPU (tests/golden/fp16.npz, tools/gen_golden.py: gen_fp16).
+
+Tolerances (stated per test): one fp16 rounding is 2^-11 = 4.9e-4 relative.  Operator outputs are compared with the fp32 evaluation on
+the same half-rounded inputs (``y32``: what fp32 accumulation + one rounding should give) at 2e-3 of the output range -- FIR-resampled
+forms round the intermediate once more -- and with the reference's own half result (``y16``) at 4e-3.  Networks accumulate these over
+~20 layers: images / logits 2e-2 of their range, gradients 5e-2 (the reference's own fp16-vs-fp32 distance is printed beside ours)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+CL = torch.channels_last
+
+
+def c(a):
+    return a.detach().float().cpu().numpy()
+
+
+def dev_h(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV).to(memory_format=CL) if np.asarray(a).ndim == 4 else torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+@pytest.fixture(scope='module')
+def g():
+    import shgan_amd  # noqa: F401
+    return load_golden('fp16')
+
+
+def test_conv2d_resample_halves_vs_reference(g):
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_resample
+    f4 = torch.from_numpy(g['f']).to(DEV)
+    for name in g['c2r_names']:
+        k = 'c2r__' + str(name) + '__'
+        up, down, pad, flipw, has_f = (int(v) for v in g[k + 'cfg'])
+        x, w = dev_h(g[k + 'x']), torch.from_numpy(g[k + 'w']).to(DEV)
+        assert x.dtype == torch.float16 and x.is_contiguous(memory_format=CL)
+        with torch.no_grad():
+            y = conv2d_resample.conv2d_resample(x=x, w=w, f=f4 if has_f else None, up=up, down=down, padding=pad, flip_weight=bool(flipw))
+        assert y.dtype == torch.float16 and tuple(y.shape) == tuple(g[k + 'y32'].shape), name
+        e32, e16 = rel_err(c(y), g[k + 'y32']), rel_err(c(y), g[k + 'y16'].astype(np.float32))
+        print(f'{name}: vs fp32-accumulate {e32:.2e}, vs reference half {e16:.2e}')
+        assert e32 < 2e-3 and e16 < 4e-3, (name, e32, e16)
+
+
+def test_upfirdn2d_halves_vs_reference(g):
+    from shgan_amd.model_zoo.stylegan_utils import upfirdn2d
+    f4 = torch.from_numpy(g['f']).to(DEV)
+    for name in g['ufd_names']:
+        k = 'ufd__' + str(name) + '__'
+        up, down, *pad = (int(v) for v in g[k + 'cfg'])
+        with torch.no_grad():
+            y = upfirdn2d.upfirdn2d(dev_h(g[k + 'x']), f4, up=up, down=down, padding=pad, gain=float(g[k + 'gain']))
+        assert y.dtype == torch.float16
+        assert rel_err(c(y), g[k + 'y32']) < 1e-3 and rel_err(c(y), g[k + 'y16'].astype(np.float32)) < 2e-3, name
+
+
+def test_modulated_conv2d_halves_with_prenormalisation_vs_reference(g):
+    from shgan_amd.model_zoo import stylegan
+    f4 = torch.from_numpy(g['f']).to(DEV)
+    for name in g['mc_names']:
+        k = 'mc__' + str(name) + '__'
+        up, demod = (int(v) for v in g[k + 'cfg'])
+        w = torch.from_numpy(g[k + 'w']).to(DEV)
+        noise = torch.from_numpy(g[k + 'noise']).to(DEV) if (k + 'noise') in g.files else None
+        with torch.no_grad():
+            y = stylegan.modulated_conv2d(x=dev_h(g[k + 'x']), weight=w, styles=torch.from_numpy(g[k + 'styles']).to(DEV), noise=noise, up=up,
+                                          padding=w.shape[2] // 2, resample_filter=f4 if up > 1 else None, demodulate=bool(demod),
+                                          flip_weight=(up == 1), fused_modconv=False)
+        assert y.dtype == torch.float16
+        e32, e16 = rel_err(c(y), g[k + 'y32']), rel_err(c(y), g[k + 'y16'].astype(np.float32))
+        print(f'modconv {name}: vs fp32 {e32:.2e}, vs reference half {e16:.2e}')
+        assert e32 < 4e-3 and e16 < 6e-3, (name, e32, e16)
+
+
+def test_bias_act_halves(g):
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    x = dev_h(g['act__x'])
+    y = grad_ops.bias_act(x, None, act=True, gain=float(np.sqrt(0.5)), alpha=0.2, act_gain=float(np.sqrt(2)), clamp=256.0)
+    assert rel_err(c(y), g['act__y'].astype(np.float32)) < 1e-3
+    # with a bias, and the gradient from the saved output (sign / clamp state)
+    b = torch.linspace(-1, 1, 16, device=DEV).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = grad_ops.bias_act(xr, b, act=True, gain=1.0, alpha=0.2, act_gain=float(np.sqrt(2)), clamp=256.0)
+        y.float().sum().backward()
+    with torch.enable_grad():
+        xf = x.float().cpu().requires_grad_(True)
+        bf = b.detach().cpu().requires_grad_(True)
+        yf = (F.leaky_relu(xf + bf.view(1, -1, 1, 1), 0.2) * np.sqrt(2)).clamp(-256, 256)
+        yf.sum().backward()
+    assert rel_err(c(y), yf.detach().numpy()) < 1e-3
+    # The backward reads the clamp state from the saved OUTPUT: a value that reaches +-256 only by the fp16 rounding of an unclamped
+    # 255.9 (a sliver of one half-precision spacing below the clamp) is indistinguishable from a clamped one and gets slope 0 where
+    # autograd of the float32 chain passes the gradient -- allowed on those elements only.
+    gd, gr, yo = c(xr.grad), xf.grad.numpy(), np.abs(c(y))
+    bad = np.abs(gd - gr) > 1e-3 * np.abs(gr).max()
+    assert bad.sum() <= 4 and np.all(yo[bad] == 256.0), (int(bad.sum()), yo[bad])
+    db = (gr * ~bad).sum((0, 2, 3))
+    assert np.abs(c(b.grad) - db).max() < 3e-3 * np.abs(db).max()
+
+
+CONV_BWD = [(2, 32, 48, 20, 24, 3, 1, 1), (1, 64, 160, 16, 16, 3, 1, 1), (2, 16, 24, 33, 33, 3, 2, 0), (2, 32, 32, 16, 18, 3, 2, 1),
+            (2, 48, 40, 9, 17, 1, 1, 0), (2, 4, 32, 16, 16, 1, 1, 0), (2, 32, 3, 16, 16, 1, 1, 0), (3, 24, 40, 7, 5, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,k,stride,pad', CONV_BWD)
+def test_conv2d_halves_forward_backward_vs_float64_autograd(n, ci, co, h, w, k, stride, pad):
+    """fp16-MFMA convolution, its input gradient (the opposite operator) and the fp16 weight-gradient kernel against float64 autograd
+    of F.conv2d on the same half-rounded operands: 2e-3 of each result's range (fp32 accumulation, one rounding)."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    rs = np.random.RandomState(n + ci + co + h + k + stride)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32)).half()
+    wt = torch.from_numpy((rs.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)).astype(np.float32)).half()
+    with torch.enable_grad():
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+        gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32)).half()
+        yr.backward(gy.double())
+    xd, wd = x.to(DEV).to(memory_format=CL).requires_grad_(), wt.to(DEV).requires_grad_()
+    with torch.enable_grad():
+        y = conv2d_gradfix.conv2d(xd, wd, stride=stride, padding=pad)
+        y.backward(gy.to(DEV).to(memory_format=CL))
+    assert y.dtype == torch.float16 and xd.grad.dtype == torch.float16 and wd.grad.dtype == torch.float16
+    assert rel_err(c(y), yr.detach().numpy()) < 2e-3
+    assert rel_err(c(xd.grad), xr.grad.numpy()) < 2e-3
+    assert rel_err(c(wd.grad), wr.grad.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,pad', [(2, 32, 24, 8, 8, 0), (1, 48, 64, 9, 20, 0), (2, 16, 16, 16, 16, 1)])
+def test_conv_transpose2d_halves_forward_backward_vs_float64_autograd(n, ci, co, h, w, pad):
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    rs = np.random.RandomState(n + ci + co + h + pad)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32)).half()
+    wt = torch.from_numpy((rs.standard_normal((ci, co, 3, 3)) / np.sqrt(ci * 9)).astype(np.float32)).half()
+    with torch.enable_grad():
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        yr = F.conv_transpose2d(xr, wr, stride=2, padding=pad)
+        gy = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32)).half()
+        yr.backward(gy.double())
+    xd, wd = x.to(DEV).to(memory_format=CL).requires_grad_(), wt.to(DEV).requires_grad_()
+    with torch.enable_grad():
+        y = conv2d_gradfix.conv_transpose2d(xd, wd, stride=2, padding=pad)
+        y.backward(gy.to(DEV).to(memory_format=CL))
+    assert rel_err(c(y), yr.detach().numpy()) < 2e-3
+    assert rel_err(c(xd.grad), xr.grad.numpy()) < 2e-3
+    assert rel_err(c(wd.grad), wr.grad.numpy()) < 2e-3
+
+
+def test_discriminator_fp16_blocks_vs_reference(g):
+    """stylegan2_discriminator with use_fp16_before_res = 16 at R = 64 (blocks 64 and 32 in half): logits, loss, every parameter gradient
+    and the gradient of the input image against the reference's fp16 run."""
+    from shgan_amd.model_zoo import stylegan
+    from oracle import shgan_oracle as orc
+    D = stylegan.Discriminator(resolution=64, ic_n=4, ch_base=1024, ch_max=32, use_fp16_before_res=16, mbstd_group_size=4, mbstd_c_n=1)
+    assert D.b64.use_fp16 and D.b32.use_fp16 and not D.b16.use_fp16
+    orc.seeded_fill_(D, seed=71, bias_std=0.1)
+    D = D.to(DEV).train().requires_grad_(True)
+    img = torch.from_numpy(np.random.RandomState(72).standard_normal((4, 4, 64, 64)).astype(np.float32)).to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        logits = D(img, None)
+        loss = F.softplus(logits).mean()
+        loss.backward()
+    ref_gap = rel_err(g['D__logits'], g['D__logits_fp32'])
+    e = rel_err(c(logits), g['D__logits'])
+    print(f'D logits: ours vs reference fp16 {e:.2e}; reference fp16 vs its fp32 {ref_gap:.2e}')
+    assert e < 2e-2 and abs(float(loss) - float(g['D__loss'])) < 1e-2 * abs(float(g['D__loss']))
+    assert rel_err(c(img.grad)[:, :, ::2, ::2], g['D__grad_img']) < 5e-2
+    errs = {n_: rel_err(c(p.grad), g['D__grad__' + n_]) for n_, p in D.named_parameters()}
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print('D parameter gradients, largest errors:', [(k, float('%.2e' % v)) for k, v in top])
+    assert all(p.grad.dtype == torch.float32 for p in D.parameters())
+    assert max(errs.values()) < 5e-2, top
+    with torch.no_grad():                                   # the same modules without autograd
+        assert rel_err(c(D(img.detach(), None)), c(logits)) < 1e-6
+
+
+def test_generator_fp16_blocks_vs_reference(g):
+    """SH-GAN generator with fp16 encoder blocks (256, 128) and fp16 synthesis blocks (64, 128, 256): eval and train-mode images and the
+    parameter gradients of sum(img * r) / N against the reference's fp16 run (reduced width, noise_mode='const')."""
+    from shgan_amd import configs, eval_harness
+    from oracle import shgan_oracle as orc
+    kw = dict(ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = configs.build_generator(256, use_fp16_before_res=64, use_fp16_after_res=32, **kw)
+    G.load_state_dict(orc.init_state_dict(256, seed=int(g['G__seed']), noise_strength=0.1, bias_std=0.1, **kw), strict=True)
+    assert G.encoder.b256.use_fp16 and G.encoder.b128.use_fp16 and not G.encoder.b64.use_fp16
+    assert G.synthesis.b256.use_fp16 and G.synthesis.b64.use_fp16 and not G.synthesis.b32.use_fp16
+    G = G.to(DEV)
+    for m in G.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    rs = np.random.RandomState(74)
+    real_u8 = rs.randint(0, 256, size=(2, 3, 256, 256)).astype(np.uint8)
+    real = torch.from_numpy(real_u8.astype(np.float32)) / 127.5 - 1.0
+    mask = torch.from_numpy(np.unpackbits(g['G__mask_bits'])[: 2 * 256 * 256].reshape(2, 1, 256, 256).astype(np.float32))
+    x = eval_harness.assemble_input(real, mask).to(DEV)
+    z = torch.from_numpy(g['G__z']).to(DEV)
+    cnd = torch.zeros(2, 0, device=DEV)
+    ref_gap = rel_err(g['G__img_eval'], g['G__img_fp32'])
+    with torch.no_grad():
+        img = G.eval()(x=x, z=z, c=cnd, noise_mode='const')
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    e = rel_err(c(img)[:, :, ::4, ::4], g['G__img_eval'])
+    print(f'G eval image: ours vs reference fp16 {e:.2e}; reference fp16 vs its fp32 {ref_gap:.2e}')
+    assert e < 2e-2
+    G = G.train().requires_grad_(True)
+    r = torch.from_numpy(np.random.RandomState(75).standard_normal((2, 3, 256, 256)).astype(np.float32)).to(DEV)
+    with torch.enable_grad():
+        img = G(x=x, z=z, c=cnd, noise_mode='const')
+        ((img * r).sum() / 2).backward()
+    assert rel_err(c(img)[:, :, ::4, ::4], g['G__img_train']) < 2e-2
+    # Gradients: the reference's own fp16 gradients are noisy -- broadcast reductions (noise, bias, style gradients) and ~1e4-term
+    # cancellations are carried out in half on both sides, in different orders -- so the yardstick is the reference's FLOAT32 gradient
+    # (G__grad32__*): the MEDIAN distance to it over all parameters may be at most 1.5 x the reference-fp16 median (measured: 1.8e-2 against
+    # 1.5e-2), and single parameters -- heavy-tailed on both sides: 0.25 / 0.41 at worst -- at most max(10 x the reference's own, 5e-2).
+    errs, ref_errs = {}, {}
+    for n_, p in G.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, n_
+        r32, r16 = g['G__grad32__' + n_], g['G__grad__' + n_]
+        gn = p.grad.reshape(-1)
+        got = c(gn) if gn.numel() <= 512 else np.concatenate([c(gn[:256]), c(gn[-256:])])
+        if float(np.abs(r32).max()) > 0:
+            errs[n_], ref_errs[n_] = rel_err(got, r32), rel_err(r16, r32)
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    med, med_ref = float(np.median(list(errs.values()))), float(np.median(list(ref_errs.values())))
+    print(f'G parameter gradients vs reference float32: ours median {med:.2e} max {max(errs.values()):.2e} | reference fp16 median {med_ref:.2e} '
+          f'max {max(ref_errs.values()):.2e}; largest ours', [(k, float('%.2e' % v), float('%.2e' % ref_errs[k])) for k, v in top])
+    for n_, e_ in errs.items():
+        assert e_ <= max(10 * ref_errs[n_], 5e-2), (n_, e_, ref_errs[n_])
+    assert med <= 1.5 * med_ref + 1e-4, (med, med_ref)

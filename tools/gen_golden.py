@@ -721,6 +721,153 @@ def gen_config5_step():
     save('config5_step512', **out)
 
 
+def gen_fp16():
+    """The reference's ``use_fp16`` branches, run by the reference itself on CPU (torch 2.10 has half convolutions / FIR on CPU):
+    operator level -- conv2d_resample branches, upfirdn2d, the non-fused modulated convolution with the fp16 pre-normalisation
+    (stylegan.py:136-138,172-181), lrelu_agc -- on half tensors (each case also in float32 on the SAME half-rounded inputs: the
+    fp32-accumulate answer the MFMA path should round to); module level -- the discriminator with ``use_fp16_before_res`` (logits,
+    every parameter gradient, the gradient of the input image), the co-modulated SH-GAN generator with fp16 encoder / synthesis blocks
+    (image, parameter gradients).  Encoder blocks at the SHU's input resolution stay float32: torch.fft rejects half on CPU
+    ('Unsupported dtype Half'), so ``use_fp16_before_res`` >= 64 is the most the CPU reference can run."""
+    g = rs(700)
+    f4 = ref_ufd.setup_filter([1, 3, 3, 1])
+    out, names = {'f': f4.numpy()}, []
+
+    def h(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.float32)).half()
+
+    cases = [
+        # name, x shape, w shape, up, down, padding, flip_weight
+        ('plain_3x3', (2, 32, 20, 24), (48, 32, 3, 3), 1, 1, 1, True),
+        ('plain_3x3_wide', (1, 64, 17, 24), (160, 64, 3, 3), 1, 1, 1, True),
+        ('plain_3x3_noflip', (2, 16, 12, 12), (24, 16, 3, 3), 1, 1, 1, False),
+        ('plain_1x1', (2, 48, 9, 17), (40, 48, 1, 1), 1, 1, 0, True),
+        ('fromrgb_1x1', (2, 4, 16, 16), (32, 4, 1, 1), 1, 1, 0, True),
+        ('torgb_1x1', (2, 32, 16, 16), (3, 32, 1, 1), 1, 1, 0, True),
+        ('down2_3x3', (2, 32, 32, 32), (48, 32, 3, 3), 1, 2, 1, True),
+        ('down2_3x3_odd', (1, 16, 18, 22), (16, 16, 3, 3), 1, 2, 1, True),
+        ('up2_3x3', (2, 32, 16, 16), (24, 32, 3, 3), 2, 1, 1, False),
+        ('up2_3x3_rect', (1, 48, 9, 20), (64, 48, 3, 3), 2, 1, 1, False),
+        ('down2_1x1', (2, 32, 16, 16), (40, 32, 1, 1), 1, 2, 0, True),
+        ('up2_1x1', (2, 32, 8, 8), (16, 32, 1, 1), 2, 1, 0, True),
+    ]
+    for name, xs, ws, up, down, pad, flipw in cases:
+        x = h(g.standard_normal(xs))
+        w = h(g.standard_normal(ws) / np.sqrt(ws[1] * ws[2] * ws[3]))
+        f = f4 if (up > 1 or down > 1) else None
+        y16 = ref_c2r.conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=pad, flip_weight=flipw)
+        y32 = ref_c2r.conv2d_resample(x=x.float(), w=w.float(), f=f, up=up, down=down, padding=pad, flip_weight=flipw)
+        assert y16.dtype == torch.float16
+        names.append(name)
+        out['c2r__' + name + '__x'], out['c2r__' + name + '__w'] = x.numpy(), w.numpy()
+        out['c2r__' + name + '__cfg'] = np.array([up, down, pad, int(flipw), int(f is not None)], dtype=np.int64)
+        out['c2r__' + name + '__y16'], out['c2r__' + name + '__y32'] = y16.numpy(), y32.numpy()
+    out['c2r_names'] = np.array(names)
+    # upfirdn2d on halves
+    ufd = [('pad2', (2, 16, 12, 14), 1, 1, [2, 2, 2, 2], 1.0), ('post_up', (1, 8, 17, 17), 1, 1, [1, 1, 1, 1], 4.0),
+           ('up2', (2, 8, 8, 8), 2, 1, [2, 1, 2, 1], 4.0), ('down2', (2, 24, 16, 16), 1, 2, [1, 1, 1, 1], 1.0)]
+    for name, xs, up, down, pad, gain in ufd:
+        x = h(g.standard_normal(xs))
+        out['ufd__' + name + '__x'] = x.numpy()
+        out['ufd__' + name + '__cfg'] = np.array([up, down] + pad, dtype=np.int64)
+        out['ufd__' + name + '__gain'] = np.float32(gain)
+        out['ufd__' + name + '__y16'] = ref_ufd.upfirdn2d(x, f4, up=up, down=down, padding=pad, gain=gain).numpy()
+        out['ufd__' + name + '__y32'] = ref_ufd.upfirdn2d(x.float(), f4, up=up, down=down, padding=pad, gain=gain).numpy()
+    out['ufd_names'] = np.array([u[0] for u in ufd])
+    # non-fused modulated convolution on halves incl. the pre-normalisation; weights / styles are float32 parameters as in the layers
+    mc = [('same', (3, 32, 16, 16), (48, 32, 3, 3), 1, True, True), ('up', (2, 32, 8, 8), (24, 32, 3, 3), 2, True, True),
+          ('torgb', (2, 32, 16, 16), (3, 32, 1, 1), 1, False, False)]
+    for name, xs, ws, up, demod, with_noise in mc:
+        x = h(g.standard_normal(xs) * 3.0)
+        w = tn(g.standard_normal(ws))
+        st = tn(g.standard_normal((xs[0], xs[1])) + 1.0)
+        oh = xs[2] * up
+        noise = tn(g.standard_normal((oh, oh)) * 0.1) if with_noise else None
+        k = ws[2]
+        y16 = stylegan.modulated_conv2d(x=x, weight=w, styles=st, noise=noise, up=up, padding=k // 2, resample_filter=f4 if up > 1 else None,
+                                        demodulate=demod, flip_weight=(up == 1), fused_modconv=False)
+        y32 = stylegan.modulated_conv2d(x=x.float(), weight=w, styles=st, noise=noise, up=up, padding=k // 2, resample_filter=f4 if up > 1 else None,
+                                        demodulate=demod, flip_weight=(up == 1), fused_modconv=False)
+        for key, val in (('x', x), ('w', w), ('styles', st), ('y16', y16), ('y32', y32)):
+            out['mc__' + name + '__' + key] = val.numpy()
+        if noise is not None:
+            out['mc__' + name + '__noise'] = noise.numpy()
+        out['mc__' + name + '__cfg'] = np.array([up, int(demod)], dtype=np.int64)
+    out['mc_names'] = np.array([m[0] for m in mc])
+    act = ref_utils.get_unit()(ACT)()
+    xa = h(g.standard_normal((2, 16, 8, 8)) * 200.0)
+    out['act__x'], out['act__y'] = xa.numpy(), act(xa.clone(), gain=np.sqrt(0.5)).numpy()
+
+    # ---- discriminator with fp16 blocks (stylegan.py:660-667,788): R=64, blocks 64 and 32 in half
+    with torch.enable_grad():
+        D = stylegan.Discriminator(resolution=64, ic_n=4, ch_base=1024, ch_max=32, use_fp16_before_res=16, resample_filter=[1, 3, 3, 1],
+                                   activation=ACT, mbstd_group_size=4, mbstd_c_n=1, c_dim=None, cmap_dim=None).train().requires_grad_(True)
+        orc.seeded_fill_(D, seed=71, bias_std=0.1)
+        img = torch.from_numpy(rs(72).standard_normal((4, 4, 64, 64)).astype(np.float32)).requires_grad_(True)
+        logits = D(img, None)
+        loss = torch.nn.functional.softplus(logits).mean()
+        loss.backward()
+    out['D__logits'], out['D__loss'], out['D__grad_img'] = logits.detach().numpy(), np.float64(loss.item()), img.grad.numpy()[:, :, ::2, ::2]      # (img = rs(72) draw)
+    for n_, p_ in D.named_parameters():
+        out['D__grad__' + n_] = p_.grad.numpy()
+    D32 = stylegan.Discriminator(resolution=64, ic_n=4, ch_base=1024, ch_max=32, use_fp16_before_res=None, resample_filter=[1, 3, 3, 1],
+                                 activation=ACT, mbstd_group_size=4, mbstd_c_n=1, c_dim=None, cmap_dim=None).train()
+    D32.load_state_dict(D.state_dict())
+    out['D__logits_fp32'] = D32(img.detach(), None).detach().numpy()
+
+    # ---- SH-GAN generator with fp16 blocks: encoder 256 / 128 (use_fp16_before_res = 64), synthesis 64 / 128 / 256 (use_fp16_after_res = 32)
+    cfg = dict(resolution=256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G32 = build_reference_generator(**cfg)
+    num_ws = 14
+    mp = comodgan.Mapping(z_dim=64, c_dim=0, w_dim=64, num_ws=num_ws, num_layers=8, embed_features=None, layer_features=None, activation=ACT,
+                          lr_multiplier=0.01, w_avg_beta=0.995)
+    enc = shgan.Encoder(resolution=256, ic_n=4, oc_n=128, ch_base=2048, ch_max=32, use_fp16_before_res=64, resample_filter=[1, 3, 3, 1],
+                        activation=ACT, mbstd_group_size=0, mbstd_c_n=0, c_dim=None, cmap_dim=None, use_dropout=True, has_extra_final_layer=False,
+                        shu_channels=32, shu_df_freedom=[2, 3], shu_df_type='piecewise_linear', shu_input_res=64, shu_lowest_res=4,
+                        shu_tail_sigma_mult=3, shu_gaussian_at_input_res=False)
+    syn = comodgan.Synthesis(w_dim=64, w0_dim=128, resolution=256, rgb_n=3, ch_base=2048, ch_max=32, use_fp16_after_res=32,
+                             resample_filter=[1, 3, 3, 1], activation=ACT)
+    G = comodgan.Generator(mp, enc, syn)
+    sd = orc.init_state_dict(256, seed=73, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    G32.load_state_dict(sd, strict=True)
+    real_u8, mask, z = synth_inputs(2, 256, 64, seed=74)
+    x = assemble_x(real_u8, mask)
+    out['G__mask_bits'], out['G__z'] = np.packbits(mask), z               # (real_u8 = the first draw of rs(74), synth_inputs)
+    out['G__seed'] = np.int64(73)
+    for mode in ('eval', 'train'):
+        G = G.eval() if mode == 'eval' else G.train()
+        for m in G.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        G.zero_grad()
+        G.requires_grad_(mode == 'train')
+        with torch.set_grad_enabled(mode == 'train'):
+            img = G(x=x, z=torch.from_numpy(z), c=torch.zeros(2, 0), noise_mode='const')
+            if mode == 'train':
+                r = torch.from_numpy(rs(75).standard_normal((2, 3, 256, 256)).astype(np.float32))
+                ((img * r).sum() / 2).backward()
+        out[f'G__img_{mode}'] = img.detach().numpy()[:, :, ::4, ::4]
+        out[f'G__img_{mode}_stats'] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
+    for n_, p_ in G.named_parameters():
+        gn = p_.grad.reshape(-1)
+        out['G__gnorm__' + n_] = np.array([gn.double().norm().item()])
+        out['G__grad__' + n_] = _sampled(gn.numpy(), 256)
+    out['G__img_fp32'] = G32.eval()(x=x, z=torch.from_numpy(z), c=torch.zeros(2, 0), noise_mode='const').numpy()[:, :, ::4, ::4]
+    # the same gradients from the float32 generator: the yardstick for the half-precision noise of the reference's own fp16 gradients
+    # (broadcast reductions and ~1e4-term cancellations carried out in half)
+    G32 = G32.train().requires_grad_(True)
+    for m in G32.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    with torch.enable_grad():
+        img = G32(x=x, z=torch.from_numpy(z), c=torch.zeros(2, 0), noise_mode='const')
+        ((img * r).sum() / 2).backward()
+    for n_, p_ in G32.named_parameters():
+        out['G__grad32__' + n_] = _sampled(p_.grad.reshape(-1).numpy(), 256)
+    save('fp16', **out)
+
+
 def gen_fid():
     """N1: the reference's own FID tail -- ``base_evaluator.zipzap_arrange`` (eva_base.py:196-230) applied per batch the way
     ``fid_evaluator.add_batch`` arranges the per-rank features after ``sync`` (eva_fid.py:217-237), then ``compute_fid``
@@ -767,7 +914,7 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
-            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step)
+            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
