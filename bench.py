@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # dense fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 matrix peak (same guide; AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec; 6.3 TB/s is what a float4 copy reaches (same guide)
 GFLOP_PER_IMAGE = {256: 181.6, 512: 240.9}        # SURVEY.md appendix A.3 (2*MAC), whole forward, direct form
 
@@ -188,7 +189,7 @@ def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_d
             'ms_per_step_single_stream': round(lat, 3), 'gflop_per_image_direct_form': GFLOP_PER_IMAGE.get(res)}
 
 
-def train_block(a, dev, rank, world, barrier, use_dist, backend):
+def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     """BASELINE config 5: FFHQ-512 G + D training step (stylegan_default_loss.py:53-128 on the co-modulated generator, losses.InpaintingLoss),
     batch ``--train-batch`` per GPU, fp32, Adam, noise_mode='random', style mixing 0.9, gradients in RCCL all-reduce buckets (world > 1).
     A step = Gmain + Dmain (every iteration); the lazy regularisers Greg (every 4th) / Dreg (every 16th) are timed in one full iteration and
@@ -198,8 +199,11 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend):
     from shgan_amd.model_zoo import stylegan
     b, res = a.train_batch, 512
     torch.manual_seed(1234)                              # identical initial weights on every rank
-    G = configs.seeded_init_(configs.build_generator(res), seed=0).to(dev).train().requires_grad_(False)
-    D = stylegan.Discriminator(resolution=res, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=None, mbstd_group_size=4,
+    # fp16: the reference's `use_fp16` blocks on the four highest resolutions (NHWC fp16-MFMA kernels, fp32 accumulation, fp32 master weights);
+    # the encoder keeps its 64^2 block float32 because that feature feeds the float32 SHU
+    G = configs.seeded_init_(configs.build_generator(res, **(dict(use_fp16_before_res=64, use_fp16_after_res=32) if fp16 else {})),
+                             seed=0).to(dev).train().requires_grad_(False)
+    D = stylegan.Discriminator(resolution=res, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=(32 if fp16 else None), mbstd_group_size=4,
                                mbstd_c_n=1).to(dev).train().requires_grad_(False)
     torch.manual_seed(4321 + rank)                       # per-rank data / latents / noise
     real = torch.rand(b, 3, res, res, device=dev) * 2 - 1
@@ -239,8 +243,11 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend):
             e = {'ms_per_step': round(v['ms'], 3), 'launches': v['calls']}
             if k.startswith('conv'):
                 sec = v['ms'] * 1e-3
-                e.update(direct_form_tflops=round(v['work'] / sec / 1e12, 2), executed_tflops=round(v['executed'] / sec / 1e12, 2),
-                         frac_of_fp32_mfma_peak=round(v['executed'] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+                e.update(direct_form_tflops=round(v['work'] / sec / 1e12, 2), executed_tflops=round(v['executed'] / sec / 1e12, 2))
+                if 'f16' in k:
+                    e['frac_of_f16_mfma_peak'] = round(v['executed'] / sec / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
+                else:
+                    e['frac_of_fp32_mfma_peak'] = round(v['executed'] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
             cls[k] = e
     barrier()
     mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
@@ -250,11 +257,12 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend):
     del G, D, L, phases
     torch.cuda.empty_cache()
     # Greg runs every 4th and Dreg every 16th iteration: (ms_all - ms_main) is their joint cost in an iteration where both run
-    return {'workload': f'FFHQ-512 G + D training step (Gmain + Dmain: non-saturating logistic loss, Adam), random-init, batch {b} per GPU, fp32',
+    return {'workload': f'FFHQ-512 G + D training step (Gmain + Dmain: non-saturating logistic loss, Adam), random-init, batch {b} per GPU, '
+                        + ('fp16 blocks at the four highest resolutions (fp16 MFMA, fp32 accumulation / master weights)' if fp16 else 'fp32'),
             'ms_per_step': round(ms_main, 2), 'images_per_s': round(world * b / ms_main * 1e3, 2), 'steps': a.train_steps, 'n_gpus': world,
             'ms_iteration_with_both_lazy_regularisers': round(ms_all, 2),
             'lazy_regularisers': 'Greg (path length, batch/2) every 4th, Dreg (R1) every 16th iteration (stylegan_default.py:304-321)',
-            'dtype': 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
+            'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
             'grad_all_reduce': (backend if world > 1 else None), 'kernel_classes_one_step_rank0': cls,
             'conv_kernel_ms': round(sum(v['ms_per_step'] for k, v in cls.items() if k.startswith('conv')), 2) if cls else None}
 
@@ -362,6 +370,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
         torch.cuda.empty_cache()
         try:
             train = train_block(a, dev, rank, world, barrier, use_dist, backend)
+            train['fp16_blocks'] = train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=True)
         except Exception as e:             # informational block: never lose the headline over it
             if world > 1:
                 raise                      # (a rank that dropped out of a collective would hang the others)

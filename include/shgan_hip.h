@@ -234,10 +234,15 @@ int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, i
  * op is instantiated for half as well, upfirdn2d.cpp:59 AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Layout of every fp16 activation:
  * channels-LAST, [N,H,W,C] IEEE halves (torch.channels_last on a [N,C,H,W] tensor) -- 8 consecutive channels are one 16-byte MFMA
  * operand.  Arithmetic: v_mfma_f32_32x32x16_f16, fp32 accumulation, one rounding to fp16.
- * shg_conv2d_f16: w [k*k][O][I] halves (correlation taps, row-major (ky,kx)), bias fp32 [O] or NULL, I % 16 == 0.
+ * shg_conv2d_f16_pack_weight: w [T][O][I] halves (T = k*k correlation taps, row-major (ky,kx)) -> wp in MFMA operand order
+ *   [ceil(O/32) rounded up to 4][T][I/16][64][8] (shg_conv2d_f16_packed_weight_elems halves, zero beyond O): every operand of the
+ *   kernel is one coalesced, unconditional 1 KiB load.
+ * shg_conv2d_f16: w = that packed tensor, bias fp32 [O] or NULL, I % 32 == 0.
  *   mode 0: y [N,OH,OW,O] = conv2d(x, w, stride, pad);  mode 1: rows / columns [crop, crop+OH) x [crop, crop+OW) of
  *   conv_transpose2d(x, w, stride 2), 3x3, w[t][o][i] = torch weight[i][o][ky][kx] (conv2d_gradfix.py:109-116); entries beyond the
  *   (2H+1) x (2W+1) result are NOT written (shg_conv2d_f16_needs_clear: zero y first). */
+long shg_conv2d_f16_packed_weight_elems(int T, int O, int I);
+int shg_conv2d_f16_pack_weight(const void* w, void* wp, int T, int O, int I, void* stream);
 int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad,
                    int mode, int crop, int OH, int OW, void* stream);
 int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW);

@@ -87,6 +87,8 @@ _SIGS = {
     'shg_minibatch_std_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_f16': [c_fp, c_fp, c_fp, c_fp] + [c_i] * 12 + [c_fp],
     'shg_conv2d_f16_needs_clear': [c_i] * 5,
+    'shg_conv2d_f16_packed_weight_elems': [c_i] * 3,
+    'shg_conv2d_f16_pack_weight': [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_conv2d_wgrad_f16_workspace_bytes': [c_i] * 6,
     'shg_conv2d_wgrad_f16': [c_fp, c_fp, c_fp] + [c_i] * 10 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_upfirdn2d_f16': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],
@@ -126,6 +128,7 @@ def get_lib():
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_f16_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_f16_packed_weight_elems.restype = c_l
     lib.shg_conv_wino4_weight_elems.restype = c_l
     ver = lib.shg_abi_version()
     if ver != ABI_VERSION:

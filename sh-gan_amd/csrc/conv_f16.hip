@@ -33,7 +33,8 @@ constexpr int PSTR = 40;             // halves per staged pixel: 32 + 8 padding 
 
 struct ConvP {
     const _Float16* x;
-    const _Float16* w;               // [ntaps_total][O][I]
+    const _Float16* w;               // MFMA operand order [OB][wslots][I/16][64 lanes][8]: element = W[slot][ob*32 + (lane & 31)][c16*16 + (lane >> 5)*8 + e]
+    int OB, wslots;                  // 32-channel output blocks (O rounded up), tap slots of the weight tensor
     const float* bias;               // optional [O]
     _Float16* y;
     int N, I, O, H, W;               // input tensor
@@ -47,75 +48,128 @@ struct ConvP {
     int PH, PW;                      // patch extent
 };
 
-template <int MB, int NT>
+template <int MB, int NT, int NB>
 __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
+    // tile = TH x (16 NB) output pixels: wave w owns rows 2w, 2w+1; with NB = 1 its 32 lanes-of-a-block are 2 rows x 16 columns, with
+    // NB = 2 block nb is row 2w + nb and the lanes are its 32 columns -- every weight operand then feeds two MFMAs
     extern __shared__ __attribute__((aligned(16))) _Float16 patch[];
+    constexpr int TWK = TW * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
     int tile = blockIdx.x;
     const int tx = tile % p.tiles_x;
     tile /= p.tiles_x;
     const int ty = tile % p.tiles_y, n = tile / p.tiles_y;
-    const int o0 = blockIdx.y * (MB * 32);
-    const int gy = ty * TH + wave * 2 + (j >> 4), gx = tx * TW + (j & 15);          // this lane's pixel in the computed grid
-    const int ly = (wave * 2 + (j >> 4)) * p.s_in, lx = (j & 15) * p.s_in;            // its position in the patch (tap offset added below)
-    const int iy_base = ty * TH * p.s_in + p.org_y, ix_base = tx * TW * p.s_in + p.org_x;
-    f16x acc[MB];
+    const int ob0 = blockIdx.y * MB;                                                   // first 32-channel block of this workgroup
+    const int ry = NB == 1 ? wave * 2 + (j >> 4) : wave * 2, rx = NB == 1 ? (j & 15) : j;   // lane's pixel inside the tile (block 0)
+    const int iy_base = ty * TH * p.s_in + p.org_y, ix_base = tx * TWK * p.s_in + p.org_x;
+    f16x acc[MB][NB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
     const int npix = p.PH * p.PW;
     const _Float16* xn = p.x + (long)n * p.H * p.W * p.I;
+    const int c16n = p.I >> 4;
+    // weights in MFMA operand order: [32-channel block][tap slot][16-channel k-step][lane][8] -- one coalesced 1 KiB load per operand
+    const _Float16* wl = p.w + (long)lane * 8;
+    // Patch staging, software-pipelined: 4 lanes x 16 bytes per pixel; the pixel -> address map does not depend on the channel chunk,
+    // so it is computed once; the loads of chunk c+1 are issued BEFORE the multiply loop of chunk c and land in LDS after it.
+    constexpr int SIT = NB == 2 ? 6 : 9;                            // ceil(max patch pixels / 64): 10 x 34 (NB = 2), 17 x 33 (stride 2)
+    int goff[SIT];
+    const int q8 = (tid & 3) * 8;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int pp = (tid >> 2) + it * 64, py = pp / p.PW, px = pp - py * p.PW;
+        const int iy = iy_base + py, ix = ix_base + px;
+        goff[it] = (pp < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+    }
+    h8 stage[SIT];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (goff[it] >= 0) v = *(const h8*)(xn + (long)goff[it] * p.I + c0 + q8);
+            stage[it] = v;
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < p.I; c0 += KC) {
         __syncthreads();
-        // stage the patch of this channel chunk: 4 lanes x 16 bytes per pixel, zero outside the image / beyond I
-        for (int pp = tid >> 2; pp < npix; pp += 64) {
-            const int q = tid & 3, py = pp / p.PW, px = pp - py * p.PW;
-            const int iy = iy_base + py, ix = ix_base + px;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c0 + q * 8 < p.I)
-                v = *(const h8*)(xn + ((long)iy * p.W + ix) * p.I + c0 + q * 8);
-            *(h8*)(patch + pp * PSTR + q * 8) = v;
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int pp = (tid >> 2) + it * 64;
+            if (pp < npix) *(h8*)(patch + pp * PSTR + q8) = stage[it];
         }
         __syncthreads();
+        if (c0 + KC < p.I) fetch(c0 + KC);
+        // Weight operands: unconditional loads (the packed tensor is zero-padded to whole MB groups of blocks and I % 32 == 0), those of
+        // tap t+1 requested before the MFMAs of tap t -- a conditional load would be waited for on the spot (vmcnt(0) per MFMA pair).
+        const _Float16* wc = wl + ((long)ob0 * p.wslots * c16n + (c0 >> 4)) * 512;
+        h8 a[2][2][MB];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[0][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[0]) * c16n + ks) * 512);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const _Float16* bp = patch + ((ly + p.tdy[t]) * p.PW + lx + p.tdx[t]) * PSTR + kg * 8;
-            const _Float16* wp = p.w + ((long)p.tw[t] * p.O + o0 + j) * p.I + c0 + kg * 8;
+            if (t + 1 < NT) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const h8 b = *(const h8*)(bp + ks * 16);
-                const bool kin = c0 + ks * 16 < p.I;
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    h8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (kin && o0 + m * 32 + j < p.O) a = *(const h8*)(wp + (long)m * 32 * p.I + ks * 16);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m], 0, 0, 0);
-                }
+                    for (int m = 0; m < MB; ++m) a[(t + 1) & 1][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[t + 1]) * c16n + ks) * 512);
             }
+            const _Float16* bp = patch + ((ry * p.s_in + p.tdy[t]) * p.PW + rx * p.s_in + p.tdx[t]) * PSTR + kg * 8;
+            h8 b[2][NB];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) b[ks][q] = *(const h8*)(bp + q * p.s_in * p.PW * PSTR + ks * 16);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][ks][m], b[ks][q], acc[m][q], 0, 0, 0);
         }
     }
-    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    if (gy >= p.GH || gx >= p.GW) return;
-    const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
-    if (oy < 0 || oy >= p.OHt || ox < 0 || ox >= p.OWt) return;
-    _Float16* yp = p.y + (((long)n * p.OHt + oy) * p.OWt + ox) * p.O;
+    // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  A lane holds 4-channel runs of ONE
+    // pixel: stored directly, every store instruction would touch 64 different 128-byte lines with 8 bytes each.  The tile is therefore
+    // transposed through LDS (pixel-major, 16 bytes of padding per pixel) and leaves as whole 16-byte pieces of contiguous channel runs.
+    constexpr int OPS = MB * 32 + 8;
+    __syncthreads();
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int q = 0; q < NB; ++q) {
+        const int pl = NB == 1 ? ry * TW + rx : (ry + q) * TWK + rx;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = o0 + m * 32 + q * 8 + kg * 4;
-            if ((p.O & 3) == 0 && o + 3 < p.O) {
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int ol = m * 32 + qq * 8 + kg * 4, o = ob0 * 32 + ol;
                 h4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q * 4 + e] + (p.bias ? p.bias[o + e] : 0.f));
-                *(h4*)(yp + o) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (o + e < p.O) yp[o + e] = (_Float16)(acc[m][q * 4 + e] + (p.bias ? p.bias[o + e] : 0.f));
+                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][qq * 4 + e] + ((p.bias && o + e < p.O) ? p.bias[o + e] : 0.f));
+                *(h4*)(patch + pl * OPS + ol) = v;
             }
-        }
+    }
+    __syncthreads();
+    constexpr int PCS = MB * 4;                                   // 16-byte pieces per pixel
+    for (int e = tid; e < TH * TWK * PCS; e += 256) {
+        const int pl = e / PCS, pc = e - pl * PCS, row = pl / TWK, col = pl - row * TWK;
+        const int gy = ty * TH + row, gx = tx * TWK + col;
+        if (gy >= p.GH || gx >= p.GW) continue;
+        const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
+        if (oy < 0 || oy >= p.OHt || ox < 0 || ox >= p.OWt) continue;
+        const int o = ob0 * 32 + pc * 8;
+        _Float16* yp = p.y + (((long)n * p.OHt + oy) * p.OWt + ox) * p.O + o;
+        const h8 v = *(const h8*)(patch + pl * OPS + pc * 8);
+        if ((p.O & 7) == 0 && o + 7 < p.O) *(h8*)yp = v;
+        else
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (o + k < p.O) yp[k] = v[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -268,6 +322,59 @@ __global__ __launch_bounds__(256) void upfirdn2d_f16_kernel(const UfdH p) {
     }
 }
 
+// up = down = 1 (the pad-2 pre-filter of the stride-2 layers, the pad-1 post-filter of the transposed convolutions and both their
+// gradients -- all but the x2 resampling of the skip paths): a lane produces 4 horizontally adjacent pixels x 8 channels, so that each
+// loaded input column feeds up to min(fw, 4) outputs (7 x fh loads per 4 outputs instead of 16 each) and nothing is divided.
+__global__ __launch_bounds__(256) void fir_same_f16_kernel(const UfdH p) {
+    __shared__ float sf[64];
+    for (int k = threadIdx.x; k < p.fh * p.fw; k += 256) {
+        const int ky = k / p.fw, kx = k - ky * p.fw;
+        const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
+        sf[k] = p.f[sy * p.fw + sx] * p.gain;
+    }
+    __syncthreads();
+    const int c8n = p.C >> 3, oxg = (p.OW + 3) >> 2;
+    const long total = (long)p.N * p.OH * oxg * c8n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % c8n);
+        long r = e / c8n;
+        const int ox0 = (int)(r % oxg) * 4;
+        r /= oxg;
+        const int oy = (int)(r % p.OH), n = (int)(r / p.OH);
+        float v[4][8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[a][q] = 0.f;
+        for (int ky = 0; ky < p.fh; ++ky) {
+            const int iy = oy + ky - p.py0;
+            if (iy < 0 || iy >= p.H) continue;
+            const _Float16* row = p.x + ((long)n * p.H + iy) * p.W * p.C + c8 * 8;
+            for (int cx = 0; cx < p.fw + 3; ++cx) {                   // input column ox0 + cx - px0 feeds output a with tap kx = cx - a
+                const int ix = ox0 + cx - p.px0;
+                if (ix < 0 || ix >= p.W) continue;
+                const h8 xv = *(const h8*)(row + (long)ix * p.C);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int kx = cx - a;
+                    if (kx < 0 || kx >= p.fw) continue;
+                    const float fk = sf[ky * p.fw + kx];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[a][q] += (float)xv[q] * fk;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (ox0 + a >= p.OW) break;
+            h8 out;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] = (_Float16)v[a][q];
+            *(h8*)(p.y + ((((long)n * p.OH + oy) * p.OW + ox0 + a) * p.C) + c8 * 8) = out;
+        }
+    }
+}
+
 // y = lrelu_agc(x + bias[c]) on NHWC halves (arithmetic in fp32, one rounding), and its gradient from the saved output
 __global__ __launch_bounds__(256) void bias_act_f16_kernel(const _Float16* x, const float* bias, _Float16* y, long total8, int C, int act,
                                                            float alpha, float gain, float clamp) {
@@ -302,15 +409,17 @@ __global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float
     }
 }
 
-template <int MB>
+template <int MB, int NB>
 static int launch_conv(const ConvP& p, hipStream_t st) {
-    const dim3 grid((unsigned)((long)p.N * p.tiles_x * p.tiles_y), (unsigned)shg_cdiv(p.O, MB * 32));
-    const size_t lds = (size_t)p.PH * p.PW * PSTR * sizeof(_Float16);
+    const dim3 grid((unsigned)((long)p.N * p.tiles_x * p.tiles_y), (unsigned)shg_cdiv(p.OB, MB));
+    size_t lds = (size_t)p.PH * p.PW * PSTR * sizeof(_Float16);
+    const size_t out_tile = (size_t)TH * TW * NB * (MB * 32 + 8) * sizeof(_Float16);       // the epilogue's transposed output tile reuses the patch
+    if (out_tile > lds) lds = out_tile;
     switch (p.ntaps) {
-        case 1: hipLaunchKernelGGL((conv_f16_kernel<MB, 1>), grid, dim3(256), lds, st, p); break;
-        case 2: hipLaunchKernelGGL((conv_f16_kernel<MB, 2>), grid, dim3(256), lds, st, p); break;
-        case 4: hipLaunchKernelGGL((conv_f16_kernel<MB, 4>), grid, dim3(256), lds, st, p); break;
-        case 9: hipLaunchKernelGGL((conv_f16_kernel<MB, 9>), grid, dim3(256), lds, st, p); break;
+        case 1: hipLaunchKernelGGL((conv_f16_kernel<MB, 1, NB>), grid, dim3(256), lds, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_f16_kernel<MB, 2, NB>), grid, dim3(256), lds, st, p); break;
+        case 4: hipLaunchKernelGGL((conv_f16_kernel<MB, 4, NB>), grid, dim3(256), lds, st, p); break;
+        case 9: hipLaunchKernelGGL((conv_f16_kernel<MB, 9, NB>), grid, dim3(256), lds, st, p); break;
         default: shg_set_error("conv2d_f16: %d taps", p.ntaps); return SHG_ERR_UNSUPPORTED;
     }
     SHG_CHECK_LAUNCH();
@@ -328,29 +437,38 @@ static int conv_taps(ConvP p, int ntaps, const int* dy, const int* dx, const int
     p.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) { p.tdy[t] = dy[t] - mny; p.tdx[t] = dx[t] - mnx; p.tw[t] = slot[t]; }
     p.org_y = mny; p.org_x = mnx;
+    // wide grids of stride-1 reads: 8 x 32 pixel tiles, two pixel blocks per wave (each weight operand feeds two MFMAs); stride-2 reads
+    // (a 4x larger patch) and narrow grids keep 8 x 16
+    const int nb = (p.s_in == 1 && GW > TW) ? 2 : 1;
     p.PH = (TH - 1) * p.s_in + (mxy - mny) + 1;
-    p.PW = (TW - 1) * p.s_in + (mxx - mnx) + 1;
+    p.PW = (TW * nb - 1) * p.s_in + (mxx - mnx) + 1;
     p.GH = GH; p.GW = GW;
-    p.tiles_y = shg_cdiv(GH, TH); p.tiles_x = shg_cdiv(GW, TW);
-    if (p.O > 128) return launch_conv<4>(p, st);
-    if (p.O > 32) return launch_conv<2>(p, st);
-    return launch_conv<1>(p, st);
+    p.tiles_y = shg_cdiv(GH, TH); p.tiles_x = shg_cdiv(GW, TW * nb);
+    if (nb == 2) {                   // (4 channel blocks x 2 pixel blocks need 290 VGPRs = one wave per SIMD: 2 x 2 keeps three)
+        if (p.OB > 1) return launch_conv<2, 2>(p, st);
+        return launch_conv<1, 2>(p, st);
+    }
+    if (p.OB > 2) return launch_conv<4, 1>(p, st);
+    if (p.OB > 1) return launch_conv<2, 1>(p, st);
+    return launch_conv<1, 1>(p, st);
 }
 
 }  // namespace f16
 
-// x [N,H,W,I] halves, w [kh*kw][O][I] halves (cross-correlation taps in row-major (ky,kx) order), bias fp32 [O] or null, y halves.
+// x [N,H,W,I] halves, bias fp32 [O] or null, y halves.  w: k*k tap slots (cross-correlation taps in row-major (ky,kx) order) packed in MFMA operand
+// order by shg_conv2d_f16_pack_weight: [ceil(O/32)][k*k][I/16][64][8] halves.
 //   mode 0: y[N,OH,OW,O] = conv2d(x, w, stride, pad)                      OH = (H + 2 pad - k) / stride + 1
 //   mode 1: y[N,OH,OW,O] = rows / columns [crop, crop + OH) of conv_transpose2d(x, w, stride 2) (3x3; w[t][o][i] = torch weight[i][o][ky][kx]),
-//           zero where the (2H+1) x (2W+1) result ends earlier.  I % 16 == 0.
+//           zero where the (2H+1) x (2W+1) result ends earlier.  I % 32 == 0.
 extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride,
                               int pad, int mode, int crop, int OH, int OW, void* stream) {
     SHG_CHECK_ARG(x && w && y, "conv2d_f16: null pointer");
-    SHG_CHECK_ARG(N >= 1 && I >= 16 && (I % 16) == 0 && O >= 1 && H >= 1 && W >= 1, "conv2d_f16: bad shape (I must be a multiple of 16)");
+    SHG_CHECK_ARG(N >= 1 && I >= 32 && (I % 32) == 0 && O >= 1 && H >= 1 && W >= 1, "conv2d_f16: bad shape (I must be a multiple of 32)");
     SHG_CHECK_ARG((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= k, "conv2d_f16: 1x1 / 3x3 kernels, stride 1 / 2");
     f16::ConvP p{};
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.y = (_Float16*)y;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OHt = OH; p.OWt = OW;
+    p.OB = (O + 31) / 32; p.wslots = k * k;
     hipStream_t st = (hipStream_t)stream;
     int dy[9], dx[9], slot[9];
     if (mode == 0) {
@@ -376,6 +494,33 @@ extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, v
     return SHG_OK;
 }
 
+
+// w [T][O][I] halves (T tap slots) -> MFMA operand order [ceil(O/32)][T][I/16][64][8], rows beyond O zero
+__global__ __launch_bounds__(256) void pack_weight_f16_kernel(const _Float16* w, _Float16* wp, int T, int O, int I, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int c16n = I >> 4, c16 = (int)(r % c16n);
+        r /= c16n;
+        const int t = (int)(r % T), ob = (int)(r / T);
+        const int o = ob * 32 + (lane & 31), i = c16 * 16 + (lane >> 5) * 8 + el;
+        wp[e] = o < O ? w[((long)t * O + o) * I + i] : (_Float16)0.f;
+    }
+}
+
+// (32-channel blocks rounded up to a multiple of 4: the kernel loads the operands of whole groups of MB <= 4 blocks unconditionally)
+extern "C" long shg_conv2d_f16_packed_weight_elems(int T, int O, int I) { return (long)(((O + 31) / 32 + 3) / 4 * 4) * T * (I / 16) * 512; }
+
+extern "C" int shg_conv2d_f16_pack_weight(const void* w, void* wp, int T, int O, int I, void* stream) {
+    SHG_CHECK_ARG(w && wp && T >= 1 && O >= 1 && I >= 32 && (I % 32) == 0, "conv2d_f16_pack_weight: bad arguments (I must be a multiple of 32)");
+    const long total = shg_conv2d_f16_packed_weight_elems(T, O, I);
+    int grid = shg_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w, (_Float16*)wp, T, O, I, total);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 // the transposed form writes every pixel of its crop window only where the (2H+1) x (2W+1) result exists: callers zero y first when
 // crop + OH > 2H + 1 (shg_conv2d_f16_needs_clear says so)
 extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW) {
@@ -386,7 +531,7 @@ extern "C" size_t shg_conv2d_wgrad_f16_workspace_bytes(int N, int I, int O, int 
     const int OP = (O + 63) / 64 * 64, IP = (I + 63) / 64 * 64;
     const long nblocks = (long)N * shg_cdiv(OH, f16::WR) * shg_cdiv(OW, f16::WC);
     const long tiles = (long)(OP / 64) * (IP / 64);
-    long slices = (2048 + tiles - 1) / tiles;
+    long slices = (512 + tiles - 1) / tiles;
     if (slices > nblocks) slices = nblocks;
     if (slices < 1) slices = 1;
     return (size_t)slices * k * k * OP * IP * sizeof(float);
@@ -407,7 +552,7 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     p.by = shg_cdiv(OH, f16::WR); p.bx = shg_cdiv(OW, f16::WC);
     p.nblocks = (long)N * p.by * p.bx;
     const long tiles = (long)(p.OP / 64) * (p.IP / 64);
-    long slices = (2048 + tiles - 1) / tiles;
+    long slices = (512 + tiles - 1) / tiles;            // ~2 workgroups per CU; more slices only lengthen the reduction
     if (slices > p.nblocks) slices = p.nblocks;
     p.slices = (int)slices;
     p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
@@ -433,10 +578,12 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
     const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx, OH = (H * upy + pady0 + pady1 - fh + downy) / downy;
     SHG_CHECK_ARG(OW >= 1 && OH >= 1, "upfirdn2d_f16: empty output");
     f16::UfdH p{(const _Float16*)x, f, (_Float16*)y, N, C, H, W, OH, OW, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain};
-    const long total = (long)N * OH * OW * (C / 8);
+    const bool same = upx == 1 && upy == 1 && downx == 1 && downy == 1;
+    const long total = (long)N * OH * (same ? (OW + 3) / 4 : OW) * (C / 8);
     int grid = shg_cdiv(total, 256);
     if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(f16::upfirdn2d_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (same) hipLaunchKernelGGL(f16::fir_same_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(f16::upfirdn2d_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

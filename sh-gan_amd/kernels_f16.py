@@ -46,14 +46,20 @@ def _pad_channels(x, mult):
     return y
 
 
-def _taps_weight(w_oihw, i_mult):
-    """[O,I,kh,kw] halves -> [kh*kw][O][Ip] contiguous, input channels zero-padded to a multiple of ``i_mult``."""
+def _taps_weight(L, w_oihw, i_mult):
+    """[O,I,kh,kw] halves -> the MFMA-operand-order tensor shg_conv2d_f16 takes ([ceil(O/32)][kh*kw][Ip/16][64][8], input channels
+    zero-padded to a multiple of ``i_mult``): a [kh*kw][O][Ip] staging copy, then shg_conv2d_f16_pack_weight."""
     o, i, kh, kw = w_oihw.shape
     wt = w_oihw.permute(2, 3, 0, 1)
     ip = (i + i_mult - 1) // i_mult * i_mult
     if ip != i:
         wt = F.pad(wt, (0, ip - i))
-    return wt.contiguous()
+    wt = wt.contiguous()
+    lib = _lib.get_lib()
+    wp = torch.empty(lib.shg_conv2d_f16_packed_weight_elems(kh * kw, o, ip), device=w_oihw.device, dtype=torch.float16)
+    with L:
+        check(lib.shg_conv2d_f16_pack_weight(kernels._ptr(wt), kernels._ptr(wp), kh * kw, o, ip, L.stream()), 'conv2d_f16_pack_weight')
+    return wp
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0):
@@ -70,8 +76,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0):
     oh, ow = (h + 2 * padding - k) // stride + 1, (w + 2 * padding - k) // stride + 1
     if oh < 1 or ow < 1:
         raise _lib.ShgError('conv2d_f16: empty output')
-    xp = _pad_channels(x, 16)
-    wt = _taps_weight(weight.detach(), 16)
+    xp = _pad_channels(x, 32)
+    wt = _taps_weight(L, weight.detach(), 32)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     y = _new_cl(L, n, o, oh, ow)
     with kernels._timed(L, 'conv_f16', 2.0 * n * o * i * k * k * oh * ow):
@@ -91,8 +97,8 @@ def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None):
     n, i, h, w = x.shape
     o = weight.shape[1]
     oh, ow = out_hw if out_hw is not None else (2 * h + 1 - 2 * padding, 2 * w + 1 - 2 * padding)
-    xp = _pad_channels(x, 16)
-    wt = _taps_weight(weight.detach().transpose(0, 1), 16)
+    xp = _pad_channels(x, 32)
+    wt = _taps_weight(L, weight.detach().transpose(0, 1), 32)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     lib = _lib.get_lib()
     y = _new_cl(L, n, o, oh, ow, zero=bool(lib.shg_conv2d_f16_needs_clear(h, w, padding, oh, ow)))

@@ -28,18 +28,19 @@ def _sampled(t, k=512):
     return c(t) if t.numel() <= 2 * k else np.concatenate([c(t[:k]), c(t[-k:])])
 
 
-def build_networks(res, g_seed, d_seed):
+def build_networks(res, g_seed, d_seed, fp16=False):
     import shgan_amd  # noqa: F401
     from shgan_amd import configs
     from shgan_amd.model_zoo import stylegan
     from oracle import shgan_oracle as orc          # checker side only: the seeded initialisers the fixture was generated with
-    G = configs.build_generator(res)
+    G = configs.build_generator(res, **(dict(use_fp16_before_res=64, use_fp16_after_res=32) if fp16 else {}))
     G.load_state_dict(orc.init_state_dict(res, seed=g_seed, noise_strength=0.1, bias_std=0.1), strict=True)
     G = G.to(DEV).train()
     for m in G.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    D = stylegan.Discriminator(resolution=res, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=None, mbstd_group_size=4, mbstd_c_n=1)
+    D = stylegan.Discriminator(resolution=res, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=(32 if fp16 else None), mbstd_group_size=4,
+                               mbstd_c_n=1)
     orc.seeded_fill_(D, seed=d_seed, bias_std=0.1)
     return G, D.to(DEV).train()
 
@@ -184,3 +185,53 @@ def test_config5_batch8_training_iteration_all_phases():
     assert torch.equal(results[0], results[1])
     moved = sum(int((p.detach().cpu() - g0[n].cpu()).abs().max() > 0) for n, p in G.named_parameters())
     assert moved >= len(list(G.parameters())) - 4, moved
+
+
+def test_config5_fp16_blocks_full_width_vs_the_float32_reference():
+    """"fp16 modulated conv MFMA" (BASELINE config 5) at full width: the same Gmain / Dmain phases with the reference's ``use_fp16`` blocks
+    switched on (encoder > 64, synthesis > 32, discriminator > 32 -- the four highest resolutions, the encoder one less because its 64^2
+    feature feeds the float32 SHU) against the FLOAT32 reference fixture.  The reference cannot produce a full-width fp16 fixture on CPU
+    in reasonable time with all blocks (torch.fft rejects half), its reduced-width fp16 runs are pinned in tests/test_gpu_fp16.py; here
+    the bar is fp16 accuracy relative to float32: image / logits within 2e-2 of their range, losses within 2e-2, and the median
+    parameter-gradient distance to the float64 yardstick under 5e-2 (measured values are printed)."""
+    from shgan_amd import losses
+    g = load_golden('config5_step512')
+    res, n = (int(v) for v in g['cfg'])
+    s_g, s_d, s_in, s_pl = (int(v) for v in g['seeds'])
+    G, D = build_networks(res, s_g, s_d, fp16=True)
+    assert G.synthesis.b512.use_fp16 and G.encoder.b512.use_fp16 and D.b512.use_fp16 and D.b64.use_fp16 and not D.b32.use_fp16
+    rs = np.random.RandomState(s_in)
+    real = torch.from_numpy(rs.randint(0, 256, size=(n, 3, res, res)).astype(np.float32)) / 127.5 - 1.0
+    mask = torch.from_numpy(np.unpackbits(g['mask_bits'])[: n * res * res].reshape(n, 1, res, res).astype(np.float32))
+    real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
+    z, cnd = torch.from_numpy(g['z']).to(DEV), torch.zeros(n, 0, device=DEV)
+    L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+    seen = {}
+    run_G = L.run_G
+
+    def spy(zz, cc, sync=True):
+        img, ws = run_G(zz, cc, sync)
+        seen['img'] = img.detach()
+        return img, ws
+    L.run_G = spy
+    G.requires_grad_(True); D.requires_grad_(False)
+    L.accumulate_gradients('Gmain', real4, cnd, z, cnd, sync=True, gain=1)
+    img = seen['img']
+    assert img.dtype == torch.float32
+    e_img, e_log = rel_err(c(img)[:, :, ::8, ::8], g['img_ds']), rel_err(c(L.stats['Loss/scores/fake']), g['gmain_logits'])
+    errs = {}
+    for name, p in G.named_parameters():
+        key = 'gmain64__' + name
+        if key in g.files and p.grad is not None and float(np.abs(g[key]).max()) > 0:
+            errs[name] = rel_err(_sampled(p.grad), g[key])
+    med = float(np.median(list(errs.values())))
+    print(f'[config 5, fp16 blocks] image {e_img:.2e}, logits {e_log:.2e}, G parameter gradients vs float64: median {med:.2e} max {max(errs.values()):.2e}')
+    assert e_img < 2e-2 and e_log < 2e-2
+    assert abs(float(L.stats['Loss/G/loss'].mean()) - float(g['gmain_loss'])) < 2e-2 * abs(float(g['gmain_loss']))
+    assert med < 5e-2
+    G.zero_grad(set_to_none=True); G.requires_grad_(False); D.requires_grad_(True)
+    L.accumulate_gradients('Dmain', real4, cnd, z, cnd, sync=True, gain=1)
+    assert rel_err(c(L.stats['Loss/scores/real']), g['dmain_logits_real']) < 2e-2
+    derr = {name: rel_err(_sampled(p.grad), g['dmain__' + name]) for name, p in D.named_parameters() if float(np.abs(g['dmain__' + name]).max()) > 0}
+    print(f'[config 5, fp16 blocks] D parameter gradients vs reference float32: median {np.median(list(derr.values())):.2e} max {max(derr.values()):.2e}')
+    assert np.median(list(derr.values())) < 5e-2

@@ -14,17 +14,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--resolution', type=int, default=512)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--fp16', action='store_true', help='the use_fp16 blocks of the reference: encoder > 64, synthesis > 32, discriminator > 32')
 ap.add_argument('--direct-convt', action='store_true', help='transposed convolutions on the direct interleaved kernel (A/B)')
 a = ap.parse_args()
 if a.direct_convt:
     from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix as _gf
     _gf.PLANAR_CONVT = False
 dev = 'cuda:0'
-G = configs.seeded_init_(configs.build_generator(a.resolution), seed=0).to(dev).train()
+G = configs.seeded_init_(configs.build_generator(a.resolution, **(dict(use_fp16_before_res=64, use_fp16_after_res=32) if a.fp16 else {})), seed=0).to(dev).train()
 for m in G.modules():                         # dropout of the encoder epilogue stays off: this measures kernels, not RNG
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.0
-D = stylegan.Discriminator(resolution=a.resolution, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=None,
+D = stylegan.Discriminator(resolution=a.resolution, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=(32 if a.fp16 else None),
                            mbstd_group_size=4, mbstd_c_n=1).to(dev).train()
 optG = torch.optim.Adam(G.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8)
 optD = torch.optim.Adam(D.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8)
@@ -80,5 +81,5 @@ g_phase(); d_phase()
 kernels.set_timer(None)
 torch.cuda.synchronize()
 tot = kt.summary()
-for k, v in sorted(tot.items(), key=lambda kv: -kv[1]['ms'])[:12]:
+for k, v in sorted(tot.items(), key=lambda kv: -kv[1]['ms'])[:16]:
     print(f'   {k:16s} {v["ms"]:8.2f} ms  {v["calls"]:4d} launches' + (f'  {v["work"] / v["ms"] / 1e9:7.1f} TFLOP/s' if k.startswith('conv') else ''))
