@@ -364,7 +364,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
     del pipe
     second = train = None
     if not a.no_second_config and res == 512 and a.batch is None:
-        second = forward_block(256, 32, max(10, a.steps // 2), 3, a, dev, rank, world, barrier, use_dist, backend)
+        second = forward_block(256, 32, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend)
     if not a.no_train_step and res == 512 and a.batch is None:
         del G, x, z, out
         torch.cuda.empty_cache()

@@ -235,3 +235,19 @@ def test_generator_fp16_blocks_vs_reference(g):
     for n_, e_ in errs.items():
         assert e_ <= max(10 * ref_errs[n_], 5e-2), (n_, e_, ref_errs[n_])
     assert med <= 1.5 * med_ref + 1e-4, (med, med_ref)
+
+
+def test_fp16_mfma_keeps_denormal_operands():
+    """Half-precision gradients without loss scaling live in the denormal range (< 6.1e-5): the convolution must not flush them."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels_f16
+    x = torch.full((1, 32, 8, 8), 3e-6, device=DEV).half().to(memory_format=CL)            # 3e-6 is a denormal half (50 ulps of 6e-8)
+    assert float(x.float().max()) > 0
+    w = torch.ones(32, 32, 1, 1, device=DEV).half()
+    y = kernels_f16.conv2d(x, w)
+    want = 32 * float(x.float()[0, 0, 0, 0])
+    assert abs(float(y.float().mean()) - want) < 0.02 * want, (float(y.float().mean()), want)
+    ws = torch.full((32, 32, 1, 1), 2e-6, device=DEV).half()                                 # denormal weights, normal activations
+    y2 = kernels_f16.conv2d(torch.ones_like(x), ws)
+    want2 = 32 * float(ws.float()[0, 0, 0, 0])
+    assert abs(float(y2.float().mean()) - want2) < 0.02 * want2, (float(y2.float().mean()), want2)
