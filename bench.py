@@ -126,6 +126,9 @@ def parse():
     ap.add_argument('--cpu-forwards', type=int, default=2)
     ap.add_argument('--no-second-config', action='store_true', help='skip the 256x256 batch-32 block (BASELINE config 2)')
     ap.add_argument('--no-train-step', action='store_true', help='skip the config-5 training-step block')
+    ap.add_argument('--all-blocks', action='store_true',
+                    help='N > 1: also run the informational second_config / train_step blocks (default: N = 1 only, so that a scaling run '
+                         'measures the headline and nothing can stand between it and its JSON line)')
     ap.add_argument('--train-batch', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=3)
     ap.add_argument('--pipeline-depth', type=int, default=None,
@@ -363,9 +366,10 @@ def worker(local_rank, a, spawned_world=None, port=None):
     barrier()
     del pipe
     second = train = None
-    if not a.no_second_config and res == 512 and a.batch is None:
+    extra = world == 1 or a.all_blocks
+    if extra and not a.no_second_config and res == 512 and a.batch is None:
         second = forward_block(256, 32, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend)
-    if not a.no_train_step and res == 512 and a.batch is None:
+    if extra and not a.no_train_step and res == 512 and a.batch is None:
         del G, x, z, out
         torch.cuda.empty_cache()
         try:

@@ -20,7 +20,7 @@ needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GP
 def test_bench_two_ranks_over_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
-                        '--no-second-config', '--train-steps', '1'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+                        '--no-second-config', '--all-blocks', '--train-steps', '1'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['collective_backend'] == 'nccl' and line['config']['ranks_all_reduced'] == 2
