@@ -258,6 +258,14 @@ int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, int C, int 
 /* y = lrelu_agc(x + bias[c]) (act = 0: (x + bias) * gain) over `pixels` x C halves, and dL/dx from dL/dy and the saved OUTPUT y. */
 int shg_bias_act_f16(const void* x, const float* bias, void* y, long pixels, int C, int act, float alpha, float gain, float clamp, void* stream);
 int shg_bias_act_backward_f16(const void* g, const void* y, void* dx, long total, int act, float alpha, float gain, float clamp, void* stream);
+/* modulation tail of a half layer in one pass each way (stylegan.py:173,176-181 + :298-304): y = A(t*d[n,c] + noise + bias[c]); backward from the
+ * saved output: gt = gy*A'(y)*d, part [N][blocks][2][C] = per-workgroup pixel sums of gz*t and gz (caller sums over blocks: deterministic),
+ * gnoise [N,HW] = channel sums of gz.  d fp32 [N,C] / noise fp32 [HW] (mode 1) or [N,HW] (mode 2) / bias fp32 [C], each optional. */
+int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C, int act,
+                    float alpha, float gain, float clamp, void* stream);
+int shg_modtail_backward_f16_blocks(long HW, int C);
+int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, void* gt, float* part, float* gnoise, int N, long HW, int C,
+                             int act, float alpha, float gain, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -409,6 +409,102 @@ __global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Modulation tail of a half layer in ONE pass each way (stylegan.py:176-181 `fma(x, dcoefs, noise)` + :298-304 bias / lrelu_agc, and
+// with act = 0 / no noise / no bias the input scaling `x * styles` of :173):
+//     y = A(t * d[n,c] + noise[n?,h,w] + bias[c])
+// backward (first order): gz = gy * A'(y) read from the saved output, gt = gz * d, and the three reductions of the same pass --
+// sum_{hw} gz t (-> d), sum_{hw} gz (-> bias) per (n, c) as per-workgroup partials [n][block][2][C] (summed in a fixed order by the
+// caller: deterministic), sum_c gz per pixel (-> noise).  A lane holds 8 channels of one pixel; the C/8 lanes of a pixel are adjacent.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct TailP {
+    const _Float16* t; const _Float16* y_in; const _Float16* gy;
+    const float* d; const float* noise; const float* bias;
+    _Float16* out;                    // forward: y; backward: gt
+    float* part; float* gnoise;
+    int N, HW, C, noise_mode, act, nblk;
+    float alpha, gain, clamp;
+};
+
+__global__ __launch_bounds__(256) void modtail_f16_kernel(const TailP p) {
+    const int c8n = p.C >> 3, n = blockIdx.y;
+    const long total = (long)p.HW * c8n;
+    const _Float16* tp = p.t + (long)n * p.HW * p.C;
+    _Float16* yp = p.out + (long)n * p.HW * p.C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % c8n) * 8;
+        const long pix = e / c8n;
+        const h8 v = *(const h8*)(tp + e * 8);
+        const float nz = p.noise_mode == 0 ? 0.f : p.noise[(p.noise_mode == 2 ? (long)n * p.HW : 0) + pix];
+        h8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float z = (float)v[q] * (p.d ? p.d[(long)n * p.C + c + q] : 1.f) + nz + (p.bias ? p.bias[c + q] : 0.f);
+            z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
+            o[q] = (_Float16)z;
+        }
+        *(h8*)(yp + e * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void modtail_backward_f16_kernel(const TailP p) {
+    __shared__ float red[2][256][8];
+    const int c8n = p.C >> 3, n = blockIdx.y, tid = threadIdx.x;
+    const long total = (long)p.HW * c8n, off = (long)n * p.HW * p.C;
+    const float gp = p.gain, gn = p.act ? p.alpha * p.gain : p.gain;
+    float s1[8], s0[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s1[q] = s0[q] = 0.f;
+    // (256 and the grid stride are multiples of C/8 <= 64: a thread keeps its channel group for the whole loop)
+    const int c = (int)(((long)blockIdx.x * 256 + tid) % c8n) * 8;
+    float dd[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dd[q] = p.d ? p.d[(long)n * p.C + c + q] : 1.f;
+    const long stride = (long)gridDim.x * 256;
+    const int iters = (int)((total + stride - 1) / stride);                                        // uniform trip count: whole waves stay in the shuffle
+    for (int it = 0; it < iters; ++it) {
+        const long e = (long)blockIdx.x * 256 + tid + it * stride;
+        const bool ok = e < total;
+        float pix_sum = 0.f;
+        if (ok) {
+            const h8 g = *(const h8*)(p.gy + off + e * 8), yv = *(const h8*)(p.y_in + off + e * 8);
+            h8 tv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.t) tv = *(const h8*)(p.t + off + e * 8);
+            h8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float yq = (float)yv[q];
+                const float slope = (p.act && p.clamp >= 0.f && fabsf(yq) >= p.clamp) ? 0.f : (yq > 0.f || !p.act ? gp : gn);
+                const float gz = (float)g[q] * slope;
+                o[q] = (_Float16)(gz * dd[q]);
+                s1[q] += gz * (float)tv[q];
+                s0[q] += gz;
+                pix_sum += gz;
+            }
+            *(h8*)(p.out + off + e * 8) = o;
+        }
+        if (p.gnoise) {                                           // sum over the C/8 adjacent lanes of this pixel
+            for (int m = 1; m < c8n; m <<= 1) pix_sum += __shfl_xor(pix_sum, m, 64);
+            if (ok && (e % c8n) == 0) p.gnoise[(long)n * p.HW + e / c8n] = pix_sum;
+        }
+    }
+    if (!p.part) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { red[0][tid][q] = s1[q]; red[1][tid][q] = s0[q]; }
+    __syncthreads();
+    // threads tid, tid + c8n, tid + 2 c8n, ... share a channel group
+    if (tid < c8n) {
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float a = 0.f;
+                for (int j = tid; j < 256; j += c8n) a += red[k][j][q];
+                p.part[(((long)n * p.nblk + blockIdx.x) * 2 + k) * p.C + tid * 8 + q] = a;
+            }
+    }
+}
+
 template <int MB, int NB>
 static int launch_conv(const ConvP& p, hipStream_t st) {
     const dim3 grid((unsigned)((long)p.N * p.tiles_x * p.tiles_y), (unsigned)shg_cdiv(p.OB, MB));
@@ -611,6 +707,43 @@ extern "C" int shg_bias_act_backward_f16(const void* g, const void* y, void* dx,
     if (grid > 256 * 32) grid = 256 * 32;
     hipLaunchKernelGGL(f16::bias_act_backward_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)g, (const _Float16*)y,
                        (_Float16*)dx, total / 8, act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// y = A(t * d[n,c] + noise + bias[c]) on NHWC halves: d fp32 [N,C] or NULL, noise fp32 [HW] (noise_mode 1) / [N,HW] (2) / none (0), bias fp32
+// [C] or NULL; act = 0: (..) * gain.  C a multiple of 8.
+extern "C" int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C,
+                               int act, float alpha, float gain, float clamp, void* stream) {
+    SHG_CHECK_ARG(t && y && N >= 1 && HW >= 1 && C >= 8 && (C % 8) == 0, "modtail_f16: bad arguments (C must be a multiple of 8)");
+    f16::TailP p{};
+    p.t = (const _Float16*)t; p.d = d; p.noise = noise_mode ? noise : nullptr; p.noise_mode = noise ? noise_mode : 0; p.bias = bias;
+    p.out = (_Float16*)y; p.N = N; p.HW = (int)HW; p.C = C; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    long blocks = (HW * (C / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(f16::modtail_f16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// workgroups per sample of shg_modtail_backward_f16 (rows of its `part` buffer)
+extern "C" int shg_modtail_backward_f16_blocks(long HW, int C) {
+    long blocks = (HW * (C / 8) + 255) / 256;
+    return (int)(blocks > 256 ? 256 : blocks);
+}
+
+// gt = gy * A'(y) * d (halves); part [N][blocks][2][C] fp32 = per-workgroup sums over pixels of gz*t and gz (NULL: skipped; t may be NULL
+// when only sum gz is wanted); gnoise [N,HW] fp32 = sum over channels of gz (NULL: skipped).  C in {8,16,...,512} with C/8 a power of two.
+extern "C" int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, void* gt, float* part, float* gnoise, int N,
+                                        long HW, int C, int act, float alpha, float gain, float clamp, void* stream) {
+    SHG_CHECK_ARG(gy && y && gt && N >= 1 && HW >= 1, "modtail_backward_f16: null pointer / empty");
+    const int c8n = C / 8;
+    SHG_CHECK_ARG(C >= 8 && (C % 8) == 0 && c8n <= 64 && (c8n & (c8n - 1)) == 0, "modtail_backward_f16: C/8 must be a power of two <= 64");
+    f16::TailP p{};
+    p.gy = (const _Float16*)gy; p.y_in = (const _Float16*)y; p.t = (const _Float16*)t; p.d = d; p.out = (_Float16*)gt; p.part = part;
+    p.gnoise = gnoise; p.N = N; p.HW = (int)HW; p.C = C; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.nblk = shg_modtail_backward_f16_blocks(HW, C);
+    hipLaunchKernelGGL(f16::modtail_backward_f16_kernel, dim3(p.nblk, N), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -174,3 +174,57 @@ def bias_act_backward(g, y, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT
         check(_lib.get_lib().shg_bias_act_backward_f16(kernels._ptr(g), kernels._ptr(y), kernels._ptr(dx), g.numel(), a, al, gn, cl, L.stream()),
               'bias_act_backward_f16')
     return dx
+
+
+def _noise_flat(L, noise, n, hw):
+    """noise: None | [H,W] | [1,1,H,W] (shared) | [N,1,H,W] (per sample), float32 -> (flat tensor, mode)."""
+    if noise is None:
+        return None, 0
+    t = L.req(noise.detach().to(torch.float32), 'noise')
+    if t.numel() == hw:
+        return t.reshape(-1), 1
+    if t.numel() == n * hw:
+        return t.reshape(-1), 2
+    raise _lib.ShgError(f'modtail_f16: noise of {tuple(noise.shape)} does not match {n} x {hw} pixels')
+
+
+def modtail(t, d=None, noise=None, bias=None, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    """y = A(t * d[n,c] + noise + bias[c]) in one pass (csrc/conv_f16.hip modtail_f16_kernel)."""
+    L = kernels._Launch()
+    t = _h(L, t, 't')
+    n, c, h, w = t.shape
+    if c % 8:
+        raise _lib.ShgError('modtail_f16: channel count must be a multiple of 8')
+    d32 = None if d is None else L.req(d.detach().to(torch.float32).reshape(n, c), 'd')
+    b32 = None if bias is None else L.req(bias.detach().to(torch.float32), 'bias')
+    nz, mode = _noise_flat(L, noise, n, h * w)
+    a, al, g, cl = kernels._act_args(act, gain, alpha, act_gain, clamp)
+    y = _new_cl(L, n, c, h, w)
+    with kernels._timed(L, 'modtail_f16', 2.0 * 2 * t.numel()):
+        check(_lib.get_lib().shg_modtail_f16(kernels._ptr(t), kernels._ptr(d32), kernels._ptr(nz), mode, kernels._ptr(b32), kernels._ptr(y), n, h * w, c,
+                                             a, al, g, cl, L.stream()), 'modtail_f16')
+    return y
+
+
+def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    """-> (gt [N,C,H,W] halves, s1 [N,C] fp32 = sum_hw gz*t | None, s0 [N,C] fp32 = sum_hw gz | None, gnoise [N,1,H,W] fp32 | None) with
+    gz = gy * A'(y): the whole first-order backward of ``modtail`` in one pass over gy / y / t."""
+    L = kernels._Launch()
+    gy, y = _h(L, gy, 'gy'), _h(L, y, 'y')
+    t = _h(L, t, 't')
+    n, c, h, w = y.shape
+    d32 = None if d is None else L.req(d.detach().to(torch.float32).reshape(n, c), 'd')
+    lib = _lib.get_lib()
+    nblk = lib.shg_modtail_backward_f16_blocks(h * w, c)
+    part = torch.empty((n, nblk, 2, c), device=L.dev, dtype=torch.float32) if want_sums else None
+    gnoise = torch.empty((n, 1, h, w), device=L.dev, dtype=torch.float32) if want_noise else None
+    a, al, g, cl = kernels._act_args(act, gain, alpha, act_gain, clamp)
+    gt = _new_cl(L, n, c, h, w)
+    with kernels._timed(L, 'modtail_bwd_f16', 2.0 * (3 + (t is not None)) * y.numel()):
+        check(lib.shg_modtail_backward_f16(kernels._ptr(gy), kernels._ptr(y), kernels._ptr(t), kernels._ptr(d32), kernels._ptr(gt), kernels._ptr(part),
+                                           kernels._ptr(gnoise), n, h * w, c, a, al, g, cl, L.stream()), 'modtail_backward_f16')
+    s1 = s0 = None
+    if want_sums:
+        sums = part.sum(1)                    # fixed order over the workgroup partials: deterministic
+        s1, s0 = sums[:, 0], sums[:, 1]
+    return gt, s1, s0, gnoise

@@ -151,7 +151,7 @@ class dense(nn.Module):
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
-                     flip_weight=True, fused_modconv=True, _prepped=None, _epilogue=None):
+                     flip_weight=True, fused_modconv=True, _prepped=None, _epilogue=None, _tail=None):
     """Modulated (and demodulated) convolution, signature of stylegan.py:103-113.
 
     x [N,I,H,W], weight [O,I,k,k], styles [N,I], noise broadcastable to the output ([H',W'] or
@@ -168,7 +168,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     if grad_ops.generic_route(x, weight, styles, noise):
         if _epilogue:
             raise NotImplementedError('modulated_conv2d: the fused epilogue is an inference-path extension')
-        return _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight)
+        return _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, _tail)
     ep = dict(_epilogue or {})
     if noise is not None and noise.ndim == 4 and noise.shape[0] == 1:
         noise = noise[0, 0]
@@ -204,7 +204,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                             residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
 
 
-def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight):
+def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, tail=None):
     """Training rows and every float16 layer: the non-fused form of stylegan.py:172-181 (what the reference runs while training, and
     for fp16 batches in eval: ``fused_modconv = (not training) and (fp32 or N == 1)``, :490) on differentiable operators -- activations
     scaled by the styles, ONE shared-weight convolution (HIP forward / backward), demodulation coefficient and noise applied
@@ -222,8 +222,24 @@ def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resampl
         weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
         styles = styles * styles.square().mean().rsqrt()                                   # :147
         dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
-    x = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+    fuse = FUSED_F16_TAIL and grad_ops.modtail_supported(x)
+    x = grad_ops.modconv_tail(x, d=styles) if fuse else x * styles.to(x.dtype).reshape(n, -1, 1, 1)       # (one pass each way incl. d/ds)
     x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+    if tail is not None:
+        # `tail` = (bias, activation kwargs) of the calling layer: demodulation, noise, bias and lrelu_agc in ONE pass each way
+        # (grad_ops.modconv_tail) where the fused half kernels apply; else the per-operation form below + the layer's own bias_act
+        bias, ak = tail
+        if FUSED_F16_TAIL and grad_ops.modtail_supported(x) and ak is not None:
+            return grad_ops.modconv_tail(x, d=dcoefs, noise=noise, bias=bias, **ak)
+        y = _modulated_tail_unfused(x, n, dcoefs, noise, demodulate)
+        return grad_ops.bias_act(y, bias, **ak)
+    return _modulated_tail_unfused(x, n, dcoefs, noise, demodulate)
+
+
+FUSED_F16_TAIL = True        # (A/B switch: False = one tensor pass per operation, the round-3 first form)
+
+
+def _modulated_tail_unfused(x, n, dcoefs, noise, demodulate):
     if x.dtype == torch.float16:
         # (tensor ops that keep the NHWC layout of x: the product first, the broadcast noise added in place)
         if demodulate:
@@ -354,8 +370,8 @@ class synthesis_layer(conv2d_layer):
             # training rows and float16 layers (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
             # non-fused modulated convolution, bias + activation; the skip tensor (extension) is added last
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w), noise=None if noise is None else noise * self.noise_strength,
-                                 up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
-            y = grad_ops.bias_act(y, self.bias, **ak)
+                                 up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1),
+                                 _tail=(self.bias, ak))
             return y if residual is None else y + residual
         ns = self._noise_strength_host() if noise is not None else 0.0
         pw = self.prepped()

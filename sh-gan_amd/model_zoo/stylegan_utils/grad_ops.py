@@ -87,3 +87,62 @@ def bias_act(x, bias=None, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2
         return _BiasActFn.apply(x, bias, bool(act), float(gain), float(alpha), float(act_gain), clamp)
     x4 = x.reshape(shape[0], shape[1], -1, 1) if x.ndim != 4 else x
     return _BiasActFn.apply(x4.contiguous(), bias, bool(act), float(gain), float(alpha), float(act_gain), clamp).reshape(shape)
+
+
+class _ModTailFn(torch.autograd.Function):
+    """y = A(t * d[n,c] + noise + bias[c]) on a float16 NHWC activation in ONE kernel, and its first-order backward in ONE kernel + three
+    tiny reductions (csrc/conv_f16.hip modtail kernels) -- instead of one tensor pass per operation and per gradient (the training-route
+    fusion of stylegan.py:173,176-181,298-304).  Under ``create_graph`` (R1 / path-length regularisers) the backward is composed from the
+    differentiable operators instead, so second derivatives keep working."""
+
+    @staticmethod
+    def forward(ctx, t, d, noise, bias, cfg):
+        act, gain, alpha, act_gain, clamp = cfg
+        y = kernels_f16.modtail(t.detach(), None if d is None else d.detach(), None if noise is None else noise.detach(),
+                                None if bias is None else bias.detach(), act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        ctx.save_for_backward(t, y, d, noise, bias)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, y, d, noise, bias = ctx.saved_tensors
+        act, gain, alpha, act_gain, clamp = ctx.cfg
+        need_t, need_d, need_n, need_b = ctx.needs_input_grad[:4]
+        n, c = y.shape[0], y.shape[1]
+        if torch.is_grad_enabled():
+            # create_graph: the same quantities from differentiable pieces (gz is linear in gy, piecewise constant in y)
+            gz = _BiasActBwdFn.apply(gy, y, ctx.cfg)
+            gt = gd = gn = gb = None
+            if need_t:
+                gt = gz if d is None else gz * d.to(gz.dtype).reshape(n, c, 1, 1)
+            if d is not None and need_d:
+                gd = (gz.float() * t.float()).sum([2, 3]).reshape(d.shape).to(d.dtype)
+            if noise is not None and need_n:
+                gn = gz.float().sum(1, keepdim=True)
+                gn = (gn.sum(0) if noise.numel() != gn.numel() else gn).reshape(noise.shape).to(noise.dtype)
+            if bias is not None and need_b:
+                gb = gz.sum([0, 2, 3], dtype=torch.float32).to(bias.dtype)
+            return gt, gd, gn, gb, None
+        want_sums = (d is not None and need_d) or (bias is not None and need_b)
+        gt, s1, s0, gnz = kernels_f16.modtail_backward(gy.detach().to(torch.float16), y, t if (d is not None and need_d) else None, d,
+                                                       want_sums=want_sums, want_noise=(noise is not None and need_n), act=act, gain=gain,
+                                                       alpha=alpha, act_gain=act_gain, clamp=clamp)
+        gd = s1.reshape(d.shape).to(d.dtype) if (d is not None and need_d) else None
+        gb = s0.sum(0).to(bias.dtype) if (bias is not None and need_b) else None
+        gn = None
+        if gnz is not None:
+            gn = (gnz.sum(0) if noise.numel() != gnz.numel() else gnz).reshape(noise.shape).to(noise.dtype)
+        return (gt if need_t else None), gd, gn, gb, None
+
+
+def modconv_tail(t, d=None, noise=None, bias=None, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    """Fused modulation tail of a float16 layer: ``lrelu_agc(t * d[n,c] + noise + bias[c])`` (or ``(..) * gain`` without activation).
+    t [N,C,H,W] float16 (channels_last); d [N,C], noise [H,W] / [N,1,H,W], bias [C] float32, each optional; C a multiple of 8 with C/8 a
+    power of two <= 64 (callers fall back to the per-operation form otherwise)."""
+    return _ModTailFn.apply(t, d, noise, bias, (bool(act), float(gain), float(alpha), float(act_gain), clamp))
+
+
+def modtail_supported(t):
+    c8 = t.shape[1] // 8
+    return t.dtype == torch.float16 and t.ndim == 4 and t.shape[1] % 8 == 0 and 1 <= c8 <= 64 and (c8 & (c8 - 1)) == 0

@@ -251,3 +251,43 @@ def test_fp16_mfma_keeps_denormal_operands():
     y2 = kernels_f16.conv2d(torch.ones_like(x), ws)
     want2 = 32 * float(ws.float()[0, 0, 0, 0])
     assert abs(float(y2.float().mean()) - want2) < 0.02 * want2, (float(y2.float().mean()), want2)
+
+
+@pytest.mark.parametrize('c,shared_noise', [(64, True), (128, False), (512, True), (8, False)])
+def test_fused_modulation_tail_forward_backward(c, shared_noise):
+    """grad_ops.modconv_tail: y = lrelu_agc(t*d + noise + bias) in one pass, its one-pass backward (gt, d/dd, d/dnoise, d/dbias) against
+    float32 autograd of the same expression on the half-rounded operands, and the composed create_graph form against the fast one."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    rs = np.random.RandomState(c)
+    n, h, w = 3, 12, 20
+    t = torch.from_numpy(rs.standard_normal((n, c, h, w)).astype(np.float32) * 40).half()
+    d = torch.from_numpy((rs.rand(n, c) + 0.5).astype(np.float32))
+    nz = torch.from_numpy(rs.standard_normal((h, w) if shared_noise else (n, 1, h, w)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(c).astype(np.float32))
+    gy = torch.from_numpy(rs.standard_normal((n, c, h, w)).astype(np.float32)).half()
+    with torch.enable_grad():
+        tr, dr, nr, br = (v.float().clone().requires_grad_(True) for v in (t, d, nz, b))
+        yr = (F.leaky_relu(tr * dr.reshape(n, c, 1, 1) + nr + br.reshape(1, c, 1, 1), 0.2) * np.sqrt(2)).clamp(-256, 256)
+        yr.backward(gy.float())
+    td, dd_, nd, bd = (v.to(DEV).requires_grad_(True) for v in (t.to(memory_format=CL), d, nz, b))
+    with torch.enable_grad():
+        y = grad_ops.modconv_tail(td, d=dd_, noise=nd, bias=bd, act=True, gain=1.0, alpha=0.2, act_gain=float(np.sqrt(2)), clamp=256.0)
+        y.backward(gy.to(DEV).to(memory_format=CL))
+    assert rel_err(c_(y), yr.detach().numpy()) < 1e-3
+    # (elements whose unclamped value rounds onto the clamp are the sliver described in test_bias_act_halves)
+    bad = np.abs(c_(td.grad) - tr.grad.numpy()) > 2e-3 * np.abs(tr.grad.numpy()).max()
+    assert bad.mean() < 2e-3
+    assert rel_err(c_(dd_.grad), dr.grad.numpy()) < 5e-3 and rel_err(c_(nd.grad), nr.grad.numpy()) < 5e-3 and rel_err(c_(bd.grad), br.grad.numpy()) < 5e-3
+    # create_graph: the composed backward must give the same first derivatives and be differentiable again
+    td2, dd2 = t.to(DEV).to(memory_format=CL).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        y2 = grad_ops.modconv_tail(td2, d=dd2, noise=nd.detach(), bias=bd.detach(), act=True, gain=1.0, alpha=0.2, act_gain=float(np.sqrt(2)), clamp=256.0)
+        (g1, g2) = torch.autograd.grad([(y2.float() * gy.to(DEV).float()).sum()], [td2, dd2], create_graph=True)
+        assert rel_err(c_(g1), c_(td.grad)) < 2e-3 and rel_err(c_(g2), c_(dd_.grad)) < 5e-3
+        g1.float().square().sum().backward()             # d/dd of |gz * d|^2 exists (gz is constant in t)
+    assert dd2.grad is not None and torch.isfinite(dd2.grad).all() and float(dd2.grad.abs().max()) > 0
+
+
+def c_(a):
+    return a.detach().float().cpu().numpy()
