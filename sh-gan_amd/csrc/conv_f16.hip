@@ -13,10 +13,12 @@
 //                        no multiplies by inserted zeros).  Implicit GEMM: M = output channels (A = weights, global/L2 -> registers),
 //                        N = a tile of 8x16 output pixels (B = the input patch of a 32-channel chunk in LDS, one ds_read_b128 per
 //                        operand, pixel stride 80 B = conflict-free), K = taps x channels.
-//   conv_wgrad_f16       dw[t][o][i] = sum_{n,oy,ox} g[n,oy,ox,o] * x[n, oy*s + dy_t, ox*s + dx_t, i]: K = pixels, so both operands
-//                        are read from [pixel][channel] LDS tiles with the pixel index varying inside a lane's 8 values (2-byte LDS
-//                        gathers); 64 x 64 (o,i) tile per workgroup, all taps per wave, split over pixel slices with fp32 partials +
-//                        a fixed-order reduction (deterministic).
+//   conv_wgrad_f16       dw[t][o][i] = sum_{n,oy,ox} g[n,oy,ox,o] * x[n, oy*s + dy_t, ox*s + dx_t, i]: K = pixels, so an operand is 8
+//                        consecutive pixels of ONE channel -- the NHWC tiles are transposed while they are staged ([channel][pixel]
+//                        LDS images) and every operand is an aligned ds_read_b128; the three kx taps of a row share their reads
+//                        (shift by one half = v_alignbit, by two = registers; stride 2: even / odd column halves); 64 x 64 (o,i) tile
+//                        per workgroup, all taps per wave, split over pixel slices with fp32 partials + a fixed-order reduction
+//                        (deterministic).
 //   upfirdn2d_f16        the generic gather of upfirdn2d.cu:29-92 on NHWC halves, 8 channels per lane, fp32 accumulation.
 //   bias_act_f16 (+bwd)  x + bias[c] -> lrelu_agc, and its gradient from the saved output (common/utils.py:135-143).
 #include "shg_common.h"
@@ -177,7 +179,6 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int WR = 4;                // output rows per staged block
 constexpr int WC = 16;               // output columns per staged block = one MFMA k-step
-constexpr int WPS = 72;              // halves per staged pixel (64 channels + 8 padding: 144-byte stride)
 
 struct WgradP {
     const _Float16* x;               // [N,H,W,I]
@@ -191,11 +192,23 @@ struct WgradP {
     int XR, XC;                      // staged input rows / columns per block
 };
 
-template <int NT>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS images are TRANSPOSED while staging ([channel][pixel], 2-byte scatter writes of the 16-byte NHWC loads), so that an MFMA operand --
+// 8 consecutive pixels of one channel -- is ONE aligned ds_read_b128 instead of eight 2-byte gathers:
+//   gT[64 o][4 rows x 16 px (+8)]                       A operand of row r, k-group kg: gT[o][r*16 + kg*8 ..]
+//   xT[64 i][XR rows][RP (+8 per channel)]              stride 1: RP = 24, columns as they come (18 used); the three kx taps of a row are
+//                                                        the aligned 8 columns, the same shifted by one half (v_alignbit) and by two (registers)
+//                                                        from one b128 + one b32 read;  stride 2: RP = 48 = even columns | odd columns,
+//                                                        kx = 0 / 2 from the even half (aligned / shifted by one), kx = 1 from the odd half.
+// Channel pitches (144 / 304 / 880 / 208 bytes) put the 16 lanes of a b128 group on 16 different 16-byte slots: conflict-free.
+template <int K, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
+    constexpr int NT = K * K;
+    constexpr int XR = (WR - 1) * S + K, XC = (WC - 1) * S + K, RP = S == 1 ? 24 : 48, GP = WR * WC + 8, XP = XR * RP + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
-    _Float16* sg = sm;                               // [WR*WC][WPS]   g tile: pixel-major, 64 output channels
-    _Float16* sx = sm + WR * WC * WPS;               // [XR*XC][WPS]   x tile: pixel-major, 64 input channels
+    _Float16* gT = sm;                               // [64][GP]
+    _Float16* xT = sm + 64 * GP;                     // [64][XP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
     const int it = blockIdx.x % (p.IP / 64), ot = blockIdx.x / (p.IP / 64);
     const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;                 // this wave's 32 x 32 corner of the 64 x 64 tile
@@ -204,45 +217,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int K = p.k;
-    for (long blk = blockIdx.y; blk < p.nblocks; blk += p.slices) {
+    // staging is software-pipelined: the NHWC loads of block b+1 are issued before the multiply loop of block b and are scattered
+    // (transposed) into LDS after it
+    constexpr int GIT = WR * WC * 8 / 256, XIT = (XR * XC * 8 + 255) / 256;
+    h8 gv[GIT], xv[XIT];
+    auto fetch = [&](long blk) __attribute__((always_inline)) {
         const int bxi = (int)(blk % p.bx);
         const long rest = blk / p.bx;
         const int byi = (int)(rest % p.by), n = (int)(rest / p.by);
         const int oy0 = byi * WR, ox0 = bxi * WC;
-        __syncthreads();
-        // g tile: WR x WC pixels x 64 channels (8 lanes x 16 bytes per pixel)
-        for (int e = tid; e < WR * WC * 8; e += 256) {
-            const int q = e & 7, pp = e >> 3, r = pp / WC, c = pp - r * WC;
+#pragma unroll
+        for (int u = 0; u < GIT; ++u) {
+            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / WC, c = pp - r * WC;
             const int oy = oy0 + r, ox = ox0 + c, ch = ot * 64 + q * 8;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (oy < p.OH && ox < p.OW && ch < p.O) v = *(const h8*)(p.g + (((long)n * p.OH + oy) * p.OW + ox) * p.O + ch);
-            *(h8*)(sg + pp * WPS + q * 8) = v;
+            gv[u] = v;
         }
-        const int iy0 = oy0 * p.s - p.pad, ix0 = ox0 * p.s - p.pad;
-        for (int e = tid; e < p.XR * p.XC * 8; e += 256) {
-            const int q = e & 7, pp = e >> 3, r = pp / p.XC, c = pp - r * p.XC;
+        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+#pragma unroll
+        for (int u = 0; u < XIT; ++u) {
+            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / XC, c = pp - r * XC;
             const int iy = iy0 + r, ix = ix0 + c, ch = it * 64 + q * 8;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.I) v = *(const h8*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.I + ch);
-            *(h8*)(sx + pp * WPS + q * 8) = v;
+            if (pp < XR * XC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.I) v = *(const h8*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.I + ch);
+            xv[u] = v;
+        }
+    };
+    if ((long)blockIdx.y < p.nblocks) fetch(blockIdx.y);
+    for (long blk = blockIdx.y; blk < p.nblocks; blk += p.slices) {
+        __syncthreads();
+        // LDS row = (ch % 8) * 8 + ch / 8: the 8 lanes of a pixel hit 8 different banks
+#pragma unroll
+        for (int u = 0; u < GIT; ++u) {
+            const int e = tid + u * 256, q = e & 7, pp = e >> 3;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gT[(k * 8 + q) * GP + pp] = gv[u][k];
+        }
+#pragma unroll
+        for (int u = 0; u < XIT; ++u) {
+            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / XC, c = pp - r * XC;
+            if (pp < XR * XC) {
+                const int pos = r * RP + (S == 1 ? c : (c & 1) * 24 + (c >> 1));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xT[(k * 8 + q) * XP + pos] = xv[u][k];
+            }
         }
         __syncthreads();
+        if (blk + p.slices < p.nblocks) fetch(blk + p.slices);
 #pragma unroll 1
         for (int r = 0; r < WR; ++r) {
-            // A[o][k]: 8 consecutive pixels of row r for output channel wo + j
-            h8 a;
-            const _Float16* ap = sg + (r * WC + kg * 8) * WPS + wo + j;
+            const h8 a = *(const h8*)(gT + (wo + j) * GP + r * WC + kg * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = ap[e * WPS];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int ky = t / K, kx = t - ky * K;
-                const _Float16* bp = sx + ((r * p.s + ky) * p.XC + kg * 8 * p.s + kx) * WPS + wi + j;
-                h8 b;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b[e] = bp[e * p.s * WPS];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+            for (int ky = 0; ky < K; ++ky) {
+                const _Float16* row = xT + (wi + j) * XP + (r * S + ky) * RP + kg * 8;
+                const u32x4 e0 = *(const u32x4*)row;
+                if constexpr (K == 1) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, e0), acc[0], 0, 0, 0);
+                } else {
+                    const unsigned e4 = *(const unsigned*)(row + 8);
+                    u32x4 sh;                                              // the same 8 pixels shifted by one
+                    sh[0] = __builtin_amdgcn_alignbit(e0[1], e0[0], 16); sh[1] = __builtin_amdgcn_alignbit(e0[2], e0[1], 16);
+                    sh[2] = __builtin_amdgcn_alignbit(e0[3], e0[2], 16); sh[3] = __builtin_amdgcn_alignbit(e4, e0[3], 16);
+                    u32x4 third;
+                    if constexpr (S == 1) { third[0] = e0[1]; third[1] = e0[2]; third[2] = e0[3]; third[3] = e4; }       // shifted by two
+                    else third = *(const u32x4*)(row + 24);                                                             // the odd columns
+                    const h8 b0 = __builtin_bit_cast(h8, e0), b1 = __builtin_bit_cast(h8, S == 1 ? sh : third), b2 = __builtin_bit_cast(h8, S == 1 ? third : sh);
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, acc[ky * 3 + 2], 0, 0, 0);
+                }
             }
         }
     }
@@ -252,7 +296,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = ot * 64 + wo + (r & 3) + 8 * (r >> 2) + 4 * kg, i = it * 64 + wi + j;
+            // (LDS row R of a tile holds channel (R % 8) * 8 + R / 8, see the staging)
+            const int ro = wo + (r & 3) + 8 * (r >> 2) + 4 * kg, ri = wi + j;
+            const int o = ot * 64 + (ro & 7) * 8 + (ro >> 3), i = it * 64 + (ri & 7) * 8 + (ri >> 3);
             pp[((long)t * p.OP + o) * p.IP + i] = acc[t][r];
         }
 }
@@ -651,12 +697,14 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     long slices = (512 + tiles - 1) / tiles;            // ~2 workgroups per CU; more slices only lengthen the reduction
     if (slices > p.nblocks) slices = p.nblocks;
     p.slices = (int)slices;
+    SHG_CHECK_ARG(!(k == 1 && stride == 2), "conv2d_wgrad_f16: 1x1 stride-2 (the forward decimates with upfirdn2d first)");
     p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
-    const size_t lds = ((size_t)f16::WR * f16::WC + (size_t)p.XR * p.XC) * f16::WPS * sizeof(_Float16);
+    const size_t lds = ((size_t)64 * (f16::WR * f16::WC + 8) + (size_t)64 * (p.XR * (stride == 1 ? 24 : 48) + 8)) * sizeof(_Float16);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)slices);
-    if (k == 3) hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<9>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<1>), grid, dim3(256), lds, st, p);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<3, 1>), grid, dim3(256), lds, st, p);
+    else if (k == 3) hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<3, 2>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<1, 1>), grid, dim3(256), lds, st, p);
     SHG_CHECK_LAUNCH();
     const long total = (long)k * k * O * I;
     hipLaunchKernelGGL(f16::wgrad_reduce_kernel, dim3(shg_cdiv(total, 256) > 2048 ? 2048 : shg_cdiv(total, 256)), dim3(256), 0, st,
