@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # with the default three-stream pipeline (kernels of different batches overlap: longer individual durations, shorter wall time)
 for MODE in single pipelined; do
   D=1; [ $MODE = pipelined ] && D=3
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --no-cpu-baseline > $OUT/prof_stdout_$MODE.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step > $OUT/prof_stdout_$MODE.log 2>&1 )
   cd $GRAFT_REPO_ROOT
   F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   SUF=""; [ $MODE = pipelined ] && SUF="_pipelined"
@@ -22,6 +22,17 @@ done
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 40 --warmup 6 ${BENCH_ARGS} > $OUT/${TAG}_bench512x16.json.log 2> $OUT/bench512.err
 python bench.py --steps 40 --warmup 6 --resolution 256 --no-cpu-baseline > $OUT/${TAG}_bench256x32.json.log 2> $OUT/bench256.err
+# BASELINE config 5: kernel stats of the training step, float32 and with fp16 blocks (tools/train_step_bench.py: 1 warm-up + 2 timed +
+# 1 instrumented step = 4 steps: the divisor), and the per-shape table of the fp16 convolution family
+for MODE in fp32 fp16; do
+  FL=""; [ $MODE = fp16 ] && FL="--fp16"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tprof -o step -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --steps 2 $FL > $OUT/${TAG}_train_${MODE}_stdout.log 2>&1 )
+  F=$(find $OUT/tprof -name "*kernel_stats.csv" | head -1)
+  cp "$F" $OUT/${TAG}_train512x8_${MODE}_kernel_stats.csv
+  python tools/prof_summary.py "$F" 4 > $OUT/${TAG}_train_${MODE}_summary.txt
+  rm -rf $OUT/tprof
+done
+python tools/conv_f16_bench.py > $OUT/${TAG}_conv_f16_bench.txt 2>/dev/null
 python tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>/dev/null
 python tools/conv_bench_down.py > $OUT/${TAG}_conv_bench_down.txt 2>/dev/null
 python tools/fir_bench.py > $OUT/${TAG}_fir_bench.txt 2>/dev/null
