@@ -386,6 +386,86 @@ extern "C" int shg_planes_to_image_f32(const float* mid, const float* bias, floa
     return SHG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// First-order backward of the modulation tail y = A(t * d[n,c] + noise + bias[c]) of a float32 NCHW layer in ONE pass (training rows:
+// stylegan.py:173,176-181 + :298-304 under autograd; the forward is bias_act_kernel with scale / noise / bias):
+//   gz = gy * A'(y) from the saved output;  gt = gz * d;  per-(n,c) pixel sums of gz*t (-> d) and gz (-> bias);  per-pixel channel
+//   sums of gz (-> noise).  A lane owns 4 adjacent pixels (16-byte accesses) and walks over ALL channels: the channel sum stays in its
+//   registers, the pixel sums are reduced per wave (DPP) and per workgroup (LDS) into part[n][block][2][C] -- summed by the caller in
+//   a fixed order (deterministic, no atomics).  HW % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modtail_backward_f32_kernel(const float* gy, const float* y, const float* t, const float* d, float* gt,
+                                                                    float* part, float* gnoise, int C, int HW, int nblk, int act, float alpha,
+                                                                    float gain, float clamp) {
+    __shared__ float red[2][4][512];                                // per-wave sums of every channel: one barrier at the end (C <= 512)
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float gp = gain, gn = act ? alpha * gain : gain;
+    const int p4 = (blockIdx.x * 256 + tid) * 4;                    // first of this lane's 4 pixels
+    const bool ok = p4 < HW;
+    float4 nsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // small images: the channels are split over gridDim.z workgroups (each writes its own slice of the noise-gradient partials)
+    const int cpc = (C + gridDim.z - 1) / gridDim.z, c_lo = blockIdx.z * cpc, c_hi = c_lo + cpc < C ? c_lo + cpc : C;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const long off = ((long)n * C + c) * HW + p4;
+        float s1 = 0.f, s0 = 0.f;
+        if (ok) {
+            const float4 g = *(const float4*)(gy + off), yv = *(const float4*)(y + off);
+            float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t) tv = *(const float4*)(t + off);
+            const float dd = d ? d[(long)n * C + c] : 1.f;
+            const float gq[4] = {g.x, g.y, g.z, g.w}, yq[4] = {yv.x, yv.y, yv.z, yv.w}, tq[4] = {tv.x, tv.y, tv.z, tv.w};
+            float gz[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float slope = (act && clamp >= 0.f && fabsf(yq[q]) >= clamp) ? 0.f : ((yq[q] > 0.f || !act) ? gp : gn);
+                gz[q] = gq[q] * slope;
+                s1 += gz[q] * tq[q];
+                s0 += gz[q];
+            }
+            nsum.x += gz[0]; nsum.y += gz[1]; nsum.z += gz[2]; nsum.w += gz[3];
+            *(float4*)(gt + off) = make_float4(gz[0] * dd, gz[1] * dd, gz[2] * dd, gz[3] * dd);
+        }
+        if (part) {                                                 // (uniform branch: whole waves take part in the shuffles)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s0 += __shfl_xor(s0, m, 64); }
+            if (lane == 0) { red[0][wave][c - c_lo] = s1; red[1][wave][c - c_lo] = s0; }
+        }
+    }
+    if (part) {
+        __syncthreads();
+        const int cn = c_hi - c_lo;
+        for (int e = tid; e < 2 * cn; e += 256) {
+            const int k = e / cn, c = e - k * cn;
+            part[(((long)n * nblk + blockIdx.x) * 2 + k) * C + c_lo + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
+        }
+    }
+    if (gnoise && ok) *(float4*)(gnoise + ((long)blockIdx.z * gridDim.y + n) * HW + p4) = nsum;
+}
+
+extern "C" int shg_modtail_backward_f32_blocks(long HW) { return (int)((HW / 4 + 255) / 256); }
+// channel slices the launch is split into (rows of the gnoise partial buffer): enough workgroups for the small images
+extern "C" int shg_modtail_backward_f32_cslices(int N, int C, long HW) {
+    const long wg = (long)shg_modtail_backward_f32_blocks(HW) * N;
+    long z = (512 + wg - 1) / wg;
+    if (z > C / 8) z = C / 8;
+    return (int)(z < 1 ? 1 : z);
+}
+
+// gt = gy * A'(y) * d; part [N][blocks][2][C] = per-workgroup pixel sums of gz*t and gz (NULL: skipped; t may be NULL); gnoise [cslices][N,HW] = channel
+// sums of gz per channel slice (NULL: skipped; the caller adds the slices).  NCHW float32, HW % 4 == 0, 16-byte aligned tensors.
+extern "C" int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, float* gt, float* part, float* gnoise,
+                                        int N, int C, long HW, int act, float alpha, float gain, float clamp, void* stream) {
+    SHG_CHECK_ARG(gy && y && gt && N >= 1 && C >= 1 && C <= 512 && HW >= 4 && (HW % 4) == 0, "modtail_backward_f32: bad arguments (C <= 512, HW a multiple of 4)");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gt) |
+                    reinterpret_cast<uintptr_t>(gnoise)) & 15) == 0, "modtail_backward_f32: tensors must be 16-byte aligned");
+    const int nblk = shg_modtail_backward_f32_blocks(HW);
+    hipLaunchKernelGGL(modtail_backward_f32_kernel, dim3(nblk, N, shg_modtail_backward_f32_cslices(N, C, HW)), dim3(256), 0, (hipStream_t)stream, gy, y,
+                       t, d, gt, part, gnoise, C, (int)HW, nblk, act, alpha, gain, clamp);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // x[n,i,:] *= s[n,i]   (non-fused modulation, stylegan.py:173)
 // ---------------------------------------------------------------------------------------------

@@ -236,7 +236,7 @@ def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resampl
     return _modulated_tail_unfused(x, n, dcoefs, noise, demodulate)
 
 
-FUSED_F16_TAIL = True        # (A/B switch: False = one tensor pass per operation, the round-3 first form)
+FUSED_F16_TAIL = True        # (A/B switch: False = one tensor pass per operation, the round-3 first form; float16 and float32 training routes)
 
 
 def _modulated_tail_unfused(x, n, dcoefs, noise, demodulate):

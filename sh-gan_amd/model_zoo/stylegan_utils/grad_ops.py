@@ -90,16 +90,21 @@ def bias_act(x, bias=None, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2
 
 
 class _ModTailFn(torch.autograd.Function):
-    """y = A(t * d[n,c] + noise + bias[c]) on a float16 NHWC activation in ONE kernel, and its first-order backward in ONE kernel + three
-    tiny reductions (csrc/conv_f16.hip modtail kernels) -- instead of one tensor pass per operation and per gradient (the training-route
-    fusion of stylegan.py:173,176-181,298-304).  Under ``create_graph`` (R1 / path-length regularisers) the backward is composed from the
+    """y = A(t * d[n,c] + noise + bias[c]) in ONE kernel, and its first-order backward in ONE kernel + three tiny reductions -- float16
+    NHWC activations (csrc/conv_f16.hip modtail kernels) and float32 NCHW ones (forward: the fused bias_act kernel; backward:
+    modtail_backward_f32_kernel) -- instead of one tensor pass per operation and per gradient (the training-route fusion of
+    stylegan.py:173,176-181,298-304).  Under ``create_graph`` (R1 / path-length regularisers) the backward is composed from the
     differentiable operators instead, so second derivatives keep working."""
 
     @staticmethod
     def forward(ctx, t, d, noise, bias, cfg):
         act, gain, alpha, act_gain, clamp = cfg
-        y = kernels_f16.modtail(t.detach(), None if d is None else d.detach(), None if noise is None else noise.detach(),
-                                None if bias is None else bias.detach(), act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        if t.dtype == torch.float16:
+            y = kernels_f16.modtail(t.detach(), None if d is None else d.detach(), None if noise is None else noise.detach(),
+                                    None if bias is None else bias.detach(), act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        else:
+            y = kernels.bias_act(t.detach(), bias=None if bias is None else bias.detach(), scale=None if d is None else d.detach().reshape(-1),
+                                 noise=None if noise is None else noise.detach(), act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
         ctx.save_for_backward(t, y, d, noise, bias)
         ctx.cfg = cfg
         return y
@@ -125,9 +130,14 @@ class _ModTailFn(torch.autograd.Function):
                 gb = gz.sum([0, 2, 3], dtype=torch.float32).to(bias.dtype)
             return gt, gd, gn, gb, None
         want_sums = (d is not None and need_d) or (bias is not None and need_b)
-        gt, s1, s0, gnz = kernels_f16.modtail_backward(gy.detach().to(torch.float16), y, t if (d is not None and need_d) else None, d,
-                                                       want_sums=want_sums, want_noise=(noise is not None and need_n), act=act, gain=gain,
-                                                       alpha=alpha, act_gain=act_gain, clamp=clamp)
+        if y.dtype == torch.float16:
+            gt, s1, s0, gnz = kernels_f16.modtail_backward(gy.detach().to(torch.float16), y, t if (d is not None and need_d) else None, d,
+                                                           want_sums=want_sums, want_noise=(noise is not None and need_n), act=act, gain=gain,
+                                                           alpha=alpha, act_gain=act_gain, clamp=clamp)
+        else:
+            gt, s1, s0, gnz = kernels.modtail_backward(gy.detach(), y, t if (d is not None and need_d) else None, d, want_sums=want_sums,
+                                                       want_noise=(noise is not None and need_n), act=act, gain=gain, alpha=alpha,
+                                                       act_gain=act_gain, clamp=clamp)
         gd = s1.reshape(d.shape).to(d.dtype) if (d is not None and need_d) else None
         gb = s0.sum(0).to(bias.dtype) if (bias is not None and need_b) else None
         gn = None
@@ -137,12 +147,19 @@ class _ModTailFn(torch.autograd.Function):
 
 
 def modconv_tail(t, d=None, noise=None, bias=None, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
-    """Fused modulation tail of a float16 layer: ``lrelu_agc(t * d[n,c] + noise + bias[c])`` (or ``(..) * gain`` without activation).
-    t [N,C,H,W] float16 (channels_last); d [N,C], noise [H,W] / [N,1,H,W], bias [C] float32, each optional; C a multiple of 8 with C/8 a
-    power of two <= 64 (callers fall back to the per-operation form otherwise)."""
+    """Fused modulation tail: ``lrelu_agc(t * d[n,c] + noise + bias[c])`` (or ``(..) * gain`` without activation).
+    t [N,C,H,W] float16 (channels_last; C a multiple of 8 with C/8 a power of two <= 64) or float32 (NCHW; H*W a multiple of 4, C <= 512);
+    d [N,C], noise [H,W] / [N,1,H,W], bias [C] float32, each optional (``modtail_supported`` tells; callers fall back to the
+    per-operation form otherwise)."""
+    if t.dtype == torch.float32:
+        t = t.contiguous()
     return _ModTailFn.apply(t, d, noise, bias, (bool(act), float(gain), float(alpha), float(act_gain), clamp))
 
 
 def modtail_supported(t):
+    if t.ndim != 4:
+        return False
+    if t.dtype == torch.float32:            # NCHW kernel: 4 pixels per lane, <= 512 channels
+        return (t.shape[2] * t.shape[3]) % 4 == 0 and t.shape[1] <= 512 and t.is_cuda
     c8 = t.shape[1] // 8
-    return t.dtype == torch.float16 and t.ndim == 4 and t.shape[1] % 8 == 0 and 1 <= c8 <= 64 and (c8 & (c8 - 1)) == 0
+    return t.dtype == torch.float16 and t.shape[1] % 8 == 0 and 1 <= c8 <= 64 and (c8 & (c8 - 1)) == 0

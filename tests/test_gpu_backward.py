@@ -324,3 +324,38 @@ def test_stylegan2_loss_phases_match_hand_written_autograd(gf):
         L.accumulate_gradients('Gall', real, cnd, z, cnd)
     with pytest.raises(NotImplementedError):
         losses.StyleGAN2Loss(DEV, G.mapping, G.synthesis, D, augment_pipe=object())
+
+
+@pytest.mark.parametrize('ch,shared_noise,act', [(64, True, True), (37, False, True), (512, True, True), (24, True, False)])
+def test_fused_modulation_tail_float32(gf, ch, shared_noise, act):
+    """grad_ops.modconv_tail on float32 NCHW tensors: y = A(t*d + noise + bias) (the fused bias_act kernel) and its one-pass first-order
+    backward (modtail_backward_f32_kernel: gt, d/dd, d/dnoise, d/dbias with in-kernel reductions) against torch autograd of the same
+    expression; under create_graph the composed form must give the same first derivatives and be differentiable again."""
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    rs = np.random.RandomState(ch)
+    n, h, w = 3, 12, 20
+    t = torch.from_numpy(rs.standard_normal((n, ch, h, w)).astype(np.float32) * 40)
+    d = torch.from_numpy((rs.rand(n, ch) + 0.5).astype(np.float32))
+    nz = torch.from_numpy(rs.standard_normal((h, w) if shared_noise else (n, 1, h, w)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(ch).astype(np.float32))
+    gy = torch.from_numpy(rs.standard_normal((n, ch, h, w)).astype(np.float32))
+    with torch.enable_grad():
+        tr, dr, nr, br = (v.clone().requires_grad_(True) for v in (t, d, nz, b))
+        z = tr * dr.reshape(n, ch, 1, 1) + nr + br.reshape(1, ch, 1, 1)
+        yr = (F.leaky_relu(z, 0.2) * np.sqrt(2)).clamp(-256, 256) if act else z
+        yr.backward(gy)
+    td, dd_, nd, bd = (v.to(DEV).requires_grad_(True) for v in (t, d, nz, b))
+    kw = dict(act=act, gain=1.0, alpha=0.2, act_gain=float(np.sqrt(2)), clamp=256.0)
+    with torch.enable_grad():
+        y = grad_ops.modconv_tail(td, d=dd_, noise=nd, bias=bd, **kw)
+        y.backward(gy.to(DEV))
+    assert rel_err(c(y), yr.detach().numpy()) < 1e-6
+    assert rel_err(c(td.grad), tr.grad.numpy()) < 1e-6
+    assert rel_err(c(dd_.grad), dr.grad.numpy()) < 1e-5 and rel_err(c(nd.grad), nr.grad.numpy()) < 1e-5 and rel_err(c(bd.grad), br.grad.numpy()) < 1e-5
+    td2, dd2 = t.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        y2 = grad_ops.modconv_tail(td2, d=dd2, noise=nd.detach(), bias=bd.detach(), **kw)
+        g1, g2 = torch.autograd.grad([(y2 * gy.to(DEV)).sum()], [td2, dd2], create_graph=True)
+        assert rel_err(c(g1), c(td.grad)) < 1e-6 and rel_err(c(g2), c(dd_.grad)) < 1e-5
+        g1.square().sum().backward()
+    assert dd2.grad is not None and torch.isfinite(dd2.grad).all() and float(dd2.grad.abs().max()) > 0
