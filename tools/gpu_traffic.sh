@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_$C
   rm -rf $OUT; mkdir -p $OUT
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o t -- python bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline > $OUT/stdout.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o t -- python bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step > $OUT/stdout.log 2>&1 )
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
