@@ -202,6 +202,22 @@ def test_full_batch_512x16_vs_oracle_four_images(mods):
         assert elementwise_rel(got, ref, floor=1e-2 * float(np.abs(ref).max())) < 1e-3, i
 
 
+def test_full_batch_256x32_vs_oracle_four_images(mods):
+    """BASELINE config 2 at full size (FFHQ-256, batch 32): the same four-image oracle comparison as 512 x 16 above, global-max and
+    element-wise criteria, on images from both ends and the middle of the batch."""
+    orc, hz, cfgs = mods['orc'], mods['harness'], mods['configs']
+    G = cfgs.seeded_init_(cfgs.build_generator(256), seed=83, noise_strength=0.05)
+    sd = {k_: v.detach().clone() for k_, v in G.state_dict().items()}
+    G = G.eval().requires_grad_(False).to(DEV)
+    x, z, _, _ = hz.synthetic_items(list(range(32)), 256, 512, seed=84, device=DEV)
+    img = G(x=x, z=z, c=torch.zeros(32, 0, device=DEV), noise_mode='const')
+    for i in (0, 11, 20, 31):
+        ref = orc.generator_forward(sd, x[i:i + 1].cpu(), z[i:i + 1].cpu(), 256, noise_mode='const').numpy()
+        got = c(img[i:i + 1])
+        assert rel_err(got, ref) < 1e-4, i
+        assert elementwise_rel(got, ref, floor=1e-2 * float(np.abs(ref).max())) < 1e-3, i
+
+
 def test_sharded_eval_full_width_512_batch16(mods):
     """One rank's share of BASELINE config 4 (full-width 512, batch 16 per GPU): 2 emulated ranks x 16 images against the
     unsharded run of the same 32-item dataset; the known pixels are bit-identical, the holes differ by <= 1 LSB."""
