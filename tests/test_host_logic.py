@@ -129,6 +129,40 @@ def test_bad_arguments_are_reported_by_the_c_abi():
     assert lib.shg_conv2d_workspace_bytes(16, 64, 64, 512, 512, 3, 3, 0, 1, 1) == 0
 
 
+def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
+    """The fp16 route of the C ABI (include/shgan_hip.h, ABI 23): argument checks are host code and run here -- null pointers, channel
+    counts the operand layout cannot take, unsupported geometry; the pure planning functions are exercised as well."""
+    lib = _lib.get_lib()
+    P = ctypes.c_void_p(16)
+    assert lib.shg_conv2d_f16(None, None, None, None, 1, 32, 32, 8, 8, 3, 1, 1, 0, 0, 8, 8, None) == -1 and b'null' in lib.shg_last_error()
+    assert lib.shg_conv2d_f16(P, P, None, P, 1, 24, 32, 8, 8, 3, 1, 1, 0, 0, 8, 8, None) == -1 and b'multiple of 32' in lib.shg_last_error()
+    assert lib.shg_conv2d_f16(P, P, None, P, 1, 32, 32, 8, 8, 5, 1, 2, 0, 0, 8, 8, None) == -1                  # 5x5 kernel
+    assert lib.shg_conv2d_f16(P, P, None, P, 1, 32, 32, 8, 8, 3, 1, 1, 0, 0, 7, 8, None) == -1 and b'extent' in lib.shg_last_error()
+    assert lib.shg_conv2d_f16(P, P, None, P, 1, 32, 32, 8, 8, 3, 1, 0, 1, 0, 17, 17, None) == -1                # transposed form is stride 2
+    assert lib.shg_conv2d_f16_pack_weight(P, P, 9, 64, 40, None) == -1
+    # packed weights: 32-channel blocks rounded up to whole groups of four, [blocks][taps][I/16][64 lanes][8]
+    assert lib.shg_conv2d_f16_packed_weight_elems(9, 64, 64) == 4 * 9 * 4 * 512
+    assert lib.shg_conv2d_f16_packed_weight_elems(1, 3, 32) == 4 * 1 * 2 * 512
+    assert lib.shg_conv2d_f16_needs_clear(16, 16, 0, 33, 33) == 0 and lib.shg_conv2d_f16_needs_clear(16, 16, 1, 33, 33) == 1
+    assert lib.shg_conv2d_wgrad_f16(P, P, P, 1, 20, 32, 8, 8, 8, 8, 3, 1, 1, P, 1 << 30, None) == -1 and b'multiples of 8' in lib.shg_last_error()
+    assert lib.shg_conv2d_wgrad_f16(P, P, P, 1, 32, 32, 8, 8, 8, 8, 3, 1, 1, P, 16, None) == -1 and b'workspace' in lib.shg_last_error()
+    assert lib.shg_conv2d_wgrad_f16(P, P, P, 1, 32, 32, 8, 8, 4, 4, 1, 2, 0, P, 1 << 30, None) == -1              # 1x1 stride 2
+    ws = lib.shg_conv2d_wgrad_f16_workspace_bytes(8, 64, 64, 512, 512, 3)
+    assert ws == 512 * 9 * 64 * 64 * 4                                                                           # one (o,i) tile -> 512 pixel slices
+    assert lib.shg_upfirdn2d_f16(P, P, P, 1, 12, 8, 8, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 0, 1.0, None) == -1 and b'multiple of 8' in lib.shg_last_error()
+    assert lib.shg_bias_act_f16(P, None, P, 64, 12, 1, 0.2, 1.0, 256.0, None) == -1
+    assert lib.shg_modtail_backward_f16(P, P, None, None, P, None, None, 1, 64, 24, 1, 0.2, 1.0, 256.0, None) == -1 and b'power of two' in lib.shg_last_error()
+    assert lib.shg_modtail_backward_f16_blocks(64 * 64, 64) == 128 and lib.shg_modtail_backward_f16_blocks(512 * 512, 64) == 256
+    assert lib.shg_modtail_backward_f32(P, P, None, None, P, None, None, 1, 64, 30, 1, 0.2, 1.0, 256.0, None) == -1
+    assert lib.shg_modtail_backward_f32_cslices(8, 512, 16) == 64 and lib.shg_modtail_backward_f32_cslices(8, 64, 512 * 512) == 1
+    # and the Python wrappers refuse CPU tensors (no fallback)
+    from shgan_amd import kernels_f16
+    with pytest.raises(_lib.ShgError):
+        kernels_f16.conv2d(torch.zeros(1, 32, 8, 8, dtype=torch.float16), torch.zeros(32, 32, 3, 3, dtype=torch.float16))
+    with pytest.raises(_lib.ShgError):
+        kernels_f16.upfirdn2d(torch.zeros(1, 8, 8, 8, dtype=torch.float16), torch.ones(4, 4))
+
+
 def test_configs_build_and_seeded_init_are_deterministic():
     """The product constructs the shipped generators by itself (registry configs = the flattened YAML of SURVEY A.1) and
     initialises them identically in every process: same seed -> bit-identical state dict, reference initialiser statistics."""
