@@ -18,6 +18,20 @@ int orc_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, in
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); return 2; } } while (0)
 #define SHG(e) do { int _r = (e); if (_r != 0) { printf("shg error %d (%s) at line %d\n", _r, shg_last_error(), __LINE__); return 3; } } while (0)
 
+/* IEEE half <-> float for values that are exactly representable (small integers, powers of two): enough for a consumer without __fp16 */
+static uint16_t f2h(float v) {
+    union { float f; uint32_t u; } c; c.f = v;
+    const uint32_t s = (c.u >> 16) & 0x8000u, e = (c.u >> 23) & 0xffu, m = c.u & 0x7fffffu;
+    if (e == 0) return (uint16_t)s;
+    return (uint16_t)(s | ((e - 127 + 15) << 10) | (m >> 13));
+}
+static float h2f(uint16_t h) {
+    union { float f; uint32_t u; } c;
+    const uint32_t s = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    c.u = e == 0 ? s : (s | ((e - 15 + 127) << 23) | (m << 13));
+    return c.f;
+}
+
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return (float)((*s >> 8) & 0xffff) / 65536.f - 0.5f; }
 
 int main(void) {
@@ -85,6 +99,53 @@ int main(void) {
         printf("conv2d_wino4 of ones: max abs err %.2e (values up to %d)\n", err, 9 * I);
         if (!(err < 1e-3)) ++fails;
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(ds)); CK(hipFree(dy)); CK(hipFree(du)); free(hx); free(hw); free(hs); free(hy);
+    }
+    /* 4. the fp16 route (NHWC halves): pack a 3x3 weight tensor in MFMA operand order, convolve (stride 1, pad 1, fp32 bias), then the
+     *    weight gradient of the same geometry -- small integers, so every fp32 accumulation is exact and the check is equality */
+    {
+        const int N = 2, I = 32, O = 40, H = 9, W = 20, T = 9;
+        const size_t nx = (size_t)N * H * W * I, ny = (size_t)N * H * W * O, nw = (size_t)T * O * I;
+        uint16_t *hx = malloc(nx * 2), *hw = malloc(nw * 2), *hy = malloc(ny * 2);
+        float *xf = malloc(nx * 4), *wf = malloc(nw * 4), *hb = malloc(O * 4), *hdw = malloc(nw * 4);
+        for (size_t i = 0; i < nx; ++i) { xf[i] = (float)((int)(frand(&seed) * 8.f)); hx[i] = f2h(xf[i]); }          /* -4 .. 3 */
+        for (size_t i = 0; i < nw; ++i) { wf[i] = (float)((int)(frand(&seed) * 4.f)); hw[i] = f2h(wf[i]); }          /* -2 .. 1 */
+        for (int o = 0; o < O; ++o) hb[o] = (float)(o % 5 - 2);
+        void *dx, *dw, *dwp, *dy, *dws; float *db, *ddw;
+        const long npk = shg_conv2d_f16_packed_weight_elems(T, O, I);
+        const size_t wsb = shg_conv2d_wgrad_f16_workspace_bytes(N, I, O, H, W, 3);
+        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dwp, (size_t)npk * 2)); CK(hipMalloc(&dy, ny * 2));
+        CK(hipMalloc((void**)&db, O * 4)); CK(hipMalloc((void**)&ddw, nw * 4)); CK(hipMalloc(&dws, wsb));
+        CK(hipMemcpy(dx, hx, nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw, nw * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb, O * 4, hipMemcpyHostToDevice));
+        SHG(shg_conv2d_f16_pack_weight(dw, dwp, T, O, I, NULL));
+        SHG(shg_conv2d_f16(dx, dwp, db, dy, N, I, O, H, W, 3, 1, 1, 0, 0, H, W, NULL));
+        SHG(shg_conv2d_wgrad_f16(dx, dy, ddw, N, I, O, H, W, H, W, 3, 1, 1, dws, wsb, NULL));      /* g := y (any half tensor of the output extent) */
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hy, dy, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdw, ddw, nw * 4, hipMemcpyDeviceToHost));
+        int bad = 0, badw = 0;
+        for (int n = 0; n < N; ++n) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) for (int o = 0; o < O; ++o) {
+            float acc = hb[o];
+            for (int t = 0; t < T; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                for (int i = 0; i < I; ++i) acc += wf[((size_t)t * O + o) * I + i] * xf[(((size_t)n * H + iy) * W + ix) * I + i];
+            }
+            if (h2f(hy[(((size_t)n * H + y) * W + x) * O + o]) != acc) ++bad;                     /* |acc| <= 9*32*8 = 2304 < 2048+..: exact in half up to 2048 */
+        }
+        for (int t = 0; t < T; ++t) for (int o = 0; o < O; ++o) for (int i = 0; i < I; ++i) {
+            double acc = 0;
+            for (int n = 0; n < N; ++n) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                acc += (double)h2f(hy[(((size_t)n * H + y) * W + x) * O + o]) * xf[(((size_t)n * H + iy) * W + ix) * I + i];
+            }
+            if (fabs(hdw[((size_t)t * O + o) * I + i] - acc) > 1e-6 * (fabs(acc) + 1.0)) ++badw;
+        }
+        printf("fp16 conv2d (NHWC, packed weights): %d of %zu outputs differ; weight gradient: %d of %zu differ\n", bad, ny, badw, nw);
+        if (bad || badw) ++fails;
+        if (shg_conv2d_f16(dx, dwp, NULL, dy, N, 24, O, H, W, 3, 1, 1, 0, 0, H, W, NULL) == 0) { printf("I = 24 accepted\n"); ++fails; }
+        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dwp)); CK(hipFree(dy)); CK(hipFree(db)); CK(hipFree(ddw)); CK(hipFree(dws));
+        free(hx); free(hw); free(hy); free(xf); free(wf); free(hb); free(hdw);
     }
     printf(fails ? "FAILED (%d)\n" : "consumer ok\n", fails);
     return fails ? 4 : 0;
