@@ -155,11 +155,12 @@ def max_over_ranks(dt, use_dist, backend, dev):
     return dt
 
 
-def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_dist, backend):
+def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     """The headline loop on another configuration (BASELINE config 2: FFHQ-256 batch 32): same pipeline, same barrier / max-over-ranks timing."""
     import torch
     from shgan_amd import configs, eval_harness
-    G = configs.seeded_init_(configs.build_generator(res), seed=0).eval().requires_grad_(False).to(dev)
+    kw = dict(use_fp16_before_res=64, use_fp16_after_res=32) if fp16 else {}
+    G = configs.seeded_init_(configs.build_generator(res, **kw), seed=0).eval().requires_grad_(False).to(dev)
     ids = [rank + world * k for k in range(batch)]
     x, z, _, _ = eval_harness.synthetic_items(ids, res, G.z_dim, seed=1000, device=dev)
 
@@ -187,7 +188,10 @@ def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_d
     barrier()
     del G, x, z
     torch.cuda.empty_cache()
-    return {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU', 'value': round(world * batch * steps / dt, 3),
+    return {'workload': f'FFHQ-{res} generator forward + u8 composite, random-init, batch {batch} per GPU'
+                        + (', the reference\'s use_fp16 blocks on (encoder > 64, synthesis > 32: NHWC fp16-MFMA kernels, fused layer tails); NOT the '
+                           'shipped configuration (use_fp16_*: null) and not the headline' if fp16 else ''),
+            'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'value': round(world * batch * steps / dt, 3),
             'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warmup, 'n_gpus': world,
             'ms_per_step_single_stream': round(lat, 3), 'gflop_per_image_direct_form': GFLOP_PER_IMAGE.get(res)}
 
@@ -365,10 +369,11 @@ def worker(local_rank, a, spawned_world=None, port=None):
         tsum = timer.summary()
     barrier()
     del pipe
-    second = train = None
+    second = train = fp16_eval = None
     extra = world == 1 or a.all_blocks
     if extra and not a.no_second_config and res == 512 and a.batch is None:
         second = forward_block(256, 32, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend)
+        fp16_eval = forward_block(512, 16, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend, fp16=True)
     if extra and not a.no_train_step and res == 512 and a.batch is None:
         del G, x, z, out
         torch.cuda.empty_cache()
@@ -456,6 +461,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
             'roofline': roof,
             'hbm': {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'classes': hbm},
             'second_config': second,
+            'fp16_blocks_eval': fp16_eval,
             'train_step': train,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -246,6 +246,11 @@ int shg_conv2d_f16_pack_weight(const void* w, void* wp, int T, int O, int I, voi
 int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad,
                    int mode, int crop, int OH, int OW, void* stream);
 int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW);
+/* the same with the layer tail of the inference route fused: x*in_scale[n,i] at staging (both modes); mode 0 additionally
+ * y = A(conv*out_scale[n,o] + noise*noise_strength + bias[o]) + residual on the half-rounded result (stylegan.py:173-181,298-304). */
+int shg_conv2d_f16_fused(const void* x, const void* w, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad, int mode, int crop,
+                         int OH, int OW, const float* in_scale, const float* out_scale, const float* noise, int noise_mode, float noise_strength,
+                         const float* bias, int act, float alpha, float gain, float clamp, const void* residual, void* stream);
 /* weight gradient (replaces the cuDNN backward-weight call of conv2d_gradfix.py:140-146 for halves): dw [k*k][O][I] FP32 =
  * sum_{n,oy,ox} g[n,oy,ox,o] * x[n, oy*stride-pad+ky, ox*stride-pad+kx, i]; x [N,H,W,I], g [N,OH,OW,O] halves; I, O % 8 == 0;
  * deterministic (fp32 partial sums per pixel slice in `workspace`, reduced in a fixed order). */

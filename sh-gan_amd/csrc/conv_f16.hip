@@ -48,6 +48,11 @@ struct ConvP {
     int tdy[9], tdx[9], tw[9];       // input offset of tap t (already minus the patch origin) and its weight slot
     int org_y, org_x;                // patch origin: input row of patch row 0 for grid row 0 = org_y
     int PH, PW;                      // patch extent
+    // fused layer tail of the inference route (all optional): x * in_scale[n,i] while the patch is staged; then
+    // y = A(conv * out_scale[n,o] + noise * noise_strength + bias[o]) + residual in the store pass
+    const float* in_scale; const float* out_scale; const float* noise; const _Float16* residual;
+    int noise_mode, act, tail;       // noise: 0 none, 1 [OH,OW], 2 [N,OH,OW]; tail: any of the epilogue operands present
+    float noise_strength, alpha, gain, clamp;
 };
 
 template <int MB, int NT, int NB>
@@ -94,6 +99,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (goff[it] >= 0) v = *(const h8*)(xn + (long)goff[it] * p.I + c0 + q8);
             stage[it] = v;
+        }
+        if (p.in_scale) {                                           // `x * styles.to(x.dtype)` (stylegan.py:173): half x half -> half
+            const float* sp = p.in_scale + (long)n * p.I + c0 + q8;
+            _Float16 sh[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sh[k] = (_Float16)sp[k];
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) stage[it][k] = stage[it][k] * sh[k];
         }
     };
     fetch(0);
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
                 const int ol = m * 32 + qq * 8 + kg * 4, o = ob0 * 32 + ol;
                 h4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][qq * 4 + e] + ((p.bias && o + e < p.O) ? p.bias[o + e] : 0.f));
+                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][qq * 4 + e] + ((p.bias && !p.tail && o + e < p.O) ? p.bias[o + e] : 0.f));
                 *(h4*)(patch + pl * OPS + ol) = v;
             }
     }
@@ -165,7 +180,37 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
         if (oy < 0 || oy >= p.OHt || ox < 0 || ox >= p.OWt) continue;
         const int o = ob0 * 32 + pc * 8;
         _Float16* yp = p.y + (((long)n * p.OHt + oy) * p.OWt + ox) * p.O + o;
-        const h8 v = *(const h8*)(patch + pl * OPS + pc * 8);
+        h8 v = *(const h8*)(patch + pl * OPS + pc * 8);
+        if (p.tail) {                                               // the layer tail on the half-rounded convolution result, as the reference applies it
+            const long pix = (long)oy * p.OWt + ox;
+            const float nz = p.noise_mode == 0 ? 0.f : p.noise[(p.noise_mode == 2 ? (long)n * p.OHt * p.OWt : 0) + pix] * p.noise_strength;
+            const bool full = (p.O & 7) == 0 && o + 7 < p.O;
+            float dd[8], bb[8];
+            h8 rs = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (full) {                                             // 8 consecutive channels: vector loads of the per-channel operands
+                const float4 d0 = p.out_scale ? *(const float4*)(p.out_scale + (long)n * p.O + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 d1 = p.out_scale ? *(const float4*)(p.out_scale + (long)n * p.O + o + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 b0 = p.bias ? *(const float4*)(p.bias + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b1 = p.bias ? *(const float4*)(p.bias + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dd[0] = d0.x; dd[1] = d0.y; dd[2] = d0.z; dd[3] = d0.w; dd[4] = d1.x; dd[5] = d1.y; dd[6] = d1.z; dd[7] = d1.w;
+                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+                if (p.residual) rs = *(const h8*)(p.residual + (yp - p.y));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int oc = o + k < p.O ? o + k : p.O - 1;
+                    dd[k] = p.out_scale ? p.out_scale[(long)n * p.O + oc] : 1.f;
+                    bb[k] = p.bias ? p.bias[oc] : 0.f;
+                    if (p.residual && o + k < p.O) rs[k] = p.residual[(yp - p.y) + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float z = (float)v[k] * dd[k] + nz + bb[k];
+                z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
+                v[k] = (_Float16)((float)(_Float16)z + (float)rs[k]);
+            }
+        }
         if ((p.O & 7) == 0 && o + 7 < p.O) *(h8*)yp = v;
         else
 #pragma unroll
@@ -658,8 +703,10 @@ static int conv_taps(ConvP p, int ntaps, const int* dy, const int* dx, const int
 //   mode 0: y[N,OH,OW,O] = conv2d(x, w, stride, pad)                      OH = (H + 2 pad - k) / stride + 1
 //   mode 1: y[N,OH,OW,O] = rows / columns [crop, crop + OH) of conv_transpose2d(x, w, stride 2) (3x3; w[t][o][i] = torch weight[i][o][ky][kx]),
 //           zero where the (2H+1) x (2W+1) result ends earlier.  I % 32 == 0.
-extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride,
-                              int pad, int mode, int crop, int OH, int OW, void* stream) {
+struct shg_f16_tail_ { const float* in_scale; const float* out_scale; const float* noise; int noise_mode; float noise_strength; int act; float alpha, gain, clamp; const void* residual; };
+
+static int conv2d_f16_impl(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride,
+                           int pad, int mode, int crop, int OH, int OW, const shg_f16_tail_* tl, void* stream) {
     SHG_CHECK_ARG(x && w && y, "conv2d_f16: null pointer");
     SHG_CHECK_ARG(N >= 1 && I >= 32 && (I % 32) == 0 && O >= 1 && H >= 1 && W >= 1, "conv2d_f16: bad shape (I must be a multiple of 32)");
     SHG_CHECK_ARG((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= k, "conv2d_f16: 1x1 / 3x3 kernels, stride 1 / 2");
@@ -667,6 +714,13 @@ extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, v
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.y = (_Float16*)y;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OHt = OH; p.OWt = OW;
     p.OB = (O + 31) / 32; p.wslots = k * k;
+    if (tl) {
+        p.in_scale = tl->in_scale; p.out_scale = tl->out_scale; p.noise = tl->noise_mode ? tl->noise : nullptr; p.noise_mode = tl->noise ? tl->noise_mode : 0;
+        p.noise_strength = tl->noise_strength; p.act = tl->act; p.alpha = tl->alpha; p.gain = tl->gain; p.clamp = tl->clamp;
+        p.residual = (const _Float16*)tl->residual;
+        p.tail = (tl->out_scale || p.noise_mode || tl->act || tl->gain != 1.f || tl->residual) ? 1 : 0;
+    }
+    p.gain = p.tail ? p.gain : 1.f;
     hipStream_t st = (hipStream_t)stream;
     int dy[9], dx[9], slot[9];
     if (mode == 0) {
@@ -692,6 +746,24 @@ extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, v
     return SHG_OK;
 }
 
+
+extern "C" int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride,
+                              int pad, int mode, int crop, int OH, int OW, void* stream) {
+    return conv2d_f16_impl(x, w, bias, y, N, I, O, H, W, k, stride, pad, mode, crop, OH, OW, nullptr, stream);
+}
+
+// The same convolution with the layer tail of the INFERENCE route fused (half layers under no_grad): x * in_scale[n,i] (half x half) while the
+// patch is staged -- both modes --, and for mode 0: y = A(conv * out_scale[n,o] + noise * noise_strength + bias[o]) + residual applied to the
+// half-rounded convolution result in the store pass (stylegan.py:173-181,298-304; comodgan.py:320-327).  in_scale [N,I], out_scale [N,O], noise
+// [OH,OW] (noise_mode 1) / [N,OH,OW] (2), bias [O]: fp32, each optional; residual: halves like y; act = 0: (..) * gain.
+extern "C" int shg_conv2d_f16_fused(const void* x, const void* w, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad, int mode,
+                                    int crop, int OH, int OW, const float* in_scale, const float* out_scale, const float* noise, int noise_mode,
+                                    float noise_strength, const float* bias, int act, float alpha, float gain, float clamp, const void* residual,
+                                    void* stream) {
+    SHG_CHECK_ARG(mode == 0 || !(out_scale || noise || act || residual || gain != 1.f), "conv2d_f16_fused: the transposed form takes in_scale only (its tail follows the FIR)");
+    const shg_f16_tail_ tl{in_scale, out_scale, noise, noise_mode, noise_strength, act, alpha, gain, clamp, residual};
+    return conv2d_f16_impl(x, w, bias, y, N, I, O, H, W, k, stride, pad, mode, crop, OH, OW, &tl, stream);
+}
 
 // w [T][O][I] halves (T tap slots) -> MFMA operand order [ceil(O/32)][T][I/16][64][8], rows beyond O zero
 __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const _Float16* w, _Float16* wp, int T, int O, int I, long total) {

@@ -62,8 +62,12 @@ def _taps_weight(L, w_oihw, i_mult):
     return wp
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0):
-    """F.conv2d(x, weight, bias, stride, padding) on halves: x [N,I,H,W], weight [O,I,k,k] (k = 1 | 3) -> [N,O,OH,OW]."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, in_scale=None, out_scale=None, noise=None, noise_strength=1.0, act=None, gain=1.0,
+           alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0, residual=None):
+    """F.conv2d(x, weight, bias, stride, padding) on halves: x [N,I,H,W], weight [O,I,k,k] (k = 1 | 3) -> [N,O,OH,OW].
+    Inference-route extension (shg_conv2d_f16_fused): ``in_scale`` [N,I] multiplies x while it is staged; ``out_scale`` [N,O], ``noise``
+    ([OH,OW] / [N,1,OH,OW]) * ``noise_strength``, ``bias``, the activation (``act`` True / False; None = no tail) and ``residual`` form
+    y = A(conv * out_scale + noise + bias) + residual in the store pass."""
     L = kernels._Launch()
     x = _h(L, x, 'x')
     if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
@@ -80,15 +84,33 @@ def conv2d(x, weight, bias=None, stride=1, padding=0):
     wt = _taps_weight(L, weight.detach(), 32)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     y = _new_cl(L, n, o, oh, ow)
+    fused = in_scale is not None or out_scale is not None or noise is not None or act is not None or residual is not None
     with kernels._timed(L, 'conv_f16', 2.0 * n * o * i * k * k * oh * ow):
-        check(_lib.get_lib().shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, k,
-                                            stride, padding, 0, 0, oh, ow, L.stream()), 'conv2d_f16')
+        if not fused:
+            check(_lib.get_lib().shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, k,
+                                                stride, padding, 0, 0, oh, ow, L.stream()), 'conv2d_f16')
+            return y
+        s_in = None
+        if in_scale is not None:
+            s_in = L.req(in_scale.detach().to(torch.float32).reshape(n, i), 'in_scale')
+            if xp.shape[1] != i:
+                s_in = F.pad(s_in, (0, xp.shape[1] - i)).contiguous()
+        s_out = None if out_scale is None else L.req(out_scale.detach().to(torch.float32).reshape(n, o), 'out_scale')
+        nz, mode = _noise_flat(L, noise, n, oh * ow)
+        res = _h(L, residual, 'residual')
+        if res is not None and tuple(res.shape) != (n, o, oh, ow):
+            raise _lib.ShgError('conv2d_f16: residual shape mismatch')
+        a, al, g, cl = kernels._act_args(bool(act), gain, alpha, act_gain, clamp)
+        check(_lib.get_lib().shg_conv2d_f16_fused(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(y), n, xp.shape[1], o, h, w, k, stride, padding, 0, 0,
+                                                  oh, ow, kernels._ptr(s_in), kernels._ptr(s_out), kernels._ptr(nz), mode, float(noise_strength),
+                                                  kernels._ptr(b), a, al, g, cl, kernels._ptr(res), L.stream()), 'conv2d_f16_fused')
     return y
 
 
-def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None):
+def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None, in_scale=None):
     """Rows / columns [padding, padding + oh) of F.conv_transpose2d(x, weight [Cin,Cout,3,3], stride 2) on halves, zero where the
-    (2H+1) x (2W+1) result ends earlier (the ``output_padding`` rule of conv2d_gradfix.py:96-105 when used as an input gradient)."""
+    (2H+1) x (2W+1) result ends earlier (the ``output_padding`` rule of conv2d_gradfix.py:96-105 when used as an input gradient).
+    ``in_scale`` [N,Cin] (inference route): x * in_scale while the patch is staged."""
     L = kernels._Launch()
     x = _h(L, x, 'x')
     if weight.dtype != torch.float16 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[0] != x.shape[1]:
@@ -103,8 +125,16 @@ def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None):
     lib = _lib.get_lib()
     y = _new_cl(L, n, o, oh, ow, zero=bool(lib.shg_conv2d_f16_needs_clear(h, w, padding, oh, ow)))
     with kernels._timed(L, 'conv_f16_up', 2.0 * n * o * i * 9 * h * w):
-        check(lib.shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, 3, 2, 0, 1,
-                                 padding, oh, ow, L.stream()), 'conv_transpose2d_f16')
+        if in_scale is None:
+            check(lib.shg_conv2d_f16(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(b), kernels._ptr(y), n, xp.shape[1], o, h, w, 3, 2, 0, 1,
+                                     padding, oh, ow, L.stream()), 'conv_transpose2d_f16')
+        else:
+            s_in = L.req(in_scale.detach().to(torch.float32).reshape(n, i), 'in_scale')
+            if xp.shape[1] != i:
+                s_in = F.pad(s_in, (0, xp.shape[1] - i)).contiguous()
+            check(lib.shg_conv2d_f16_fused(kernels._ptr(xp), kernels._ptr(wt), kernels._ptr(y), n, xp.shape[1], o, h, w, 3, 2, 0, 1, padding, oh, ow,
+                                           kernels._ptr(s_in), None, None, 0, 0.0, kernels._ptr(b), 0, 0.0, 1.0, -1.0, None, L.stream()),
+                  'conv_transpose2d_f16_fused')
     return y
 
 

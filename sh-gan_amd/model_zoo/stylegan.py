@@ -204,6 +204,46 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                             residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
 
 
+def _modulation_factors(half, weight, styles, demodulate):
+    """(normalised weight, normalised styles, demodulation coefficients [N,O] | None) of stylegan.py:136-155."""
+    dcoefs = None
+    if half and demodulate:
+        o, i, kh, kw = weight.shape
+        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))       # max_Ikk, :137
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I, :138
+    if demodulate:
+        weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
+        styles = styles * styles.square().mean().rsqrt()                                   # :147
+        dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
+    return weight, styles, dcoefs
+
+
+F16_INFER_FUSED = True       # half layers without autograd: modulation / tail fused into the fp16 convolution (False: the composed route)
+
+
+def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual):
+    """Inference route of a float16 modulated layer (no autograd): the same algebra as ``_modulated_conv2d_train`` with the passes fused
+    into the NHWC fp16 convolution -- ``x * styles`` while the patch is staged, demodulation / noise / bias / lrelu_agc / skip-add in its
+    store pass (up = 1); the transposed form (up = 2) takes the style scale at staging, its tail follows the FIR in one modtail pass.
+    Returns None when the geometry is not one of the layer forms (caller falls back to the composed route)."""
+    from .. import kernels_f16
+    k = weight.shape[2]
+    if ak is None or weight.shape[2] != weight.shape[3] or k not in (1, 3) or padding != k // 2 or up not in (1, 2):
+        return None
+    if up == 2 and not (k == 3 and resample_filter is not None and resample_filter.ndim == 2 and tuple(resample_filter.shape) == (4, 4)):
+        return None
+    wn, sn, d = _modulation_factors(True, weight, styles, demodulate)
+    if up == 1:
+        wh = (wn if flip_weight else wn.flip([2, 3])).to(torch.float16)
+        return kernels_f16.conv2d(x, wh, bias, 1, padding, in_scale=sn, out_scale=d, noise=noise, residual=residual, **ak)
+    # conv2d_resample.py:122-142 with up = 2, padding = 1, a 4x4 filter: conv_transpose2d(stride 2, padding 0) -> FIR pad [1,1,1,1], gain 4
+    wt = (wn.flip([2, 3]) if flip_weight else wn).transpose(0, 1).to(torch.float16)
+    mid = kernels_f16.conv_transpose2d(x, wt, None, 0, None, in_scale=sn)
+    mid = kernels_f16.upfirdn2d(mid, resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0)
+    y = kernels_f16.modtail(mid, d=d, noise=noise, bias=bias, **ak)
+    return y if residual is None else y + residual
+
+
 def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, tail=None):
     """Training rows and every float16 layer: the non-fused form of stylegan.py:172-181 (what the reference runs while training, and
     for fp16 batches in eval: ``fused_modconv = (not training) and (fp32 or N == 1)``, :490) on differentiable operators -- activations
@@ -213,15 +253,7 @@ def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resampl
     max-norm and 1/sqrt(fan-in), styles by their max-norm -- it cancels under demodulation and keeps x*s and the accumulators inside
     the fp16 range), then styles / weights / coefficients / noise are cast to the activation dtype exactly where the reference casts."""
     n = x.shape[0]
-    dcoefs = None
-    if x.dtype == torch.float16 and demodulate:
-        o, i, kh, kw = weight.shape
-        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))       # max_Ikk
-        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I
-    if demodulate:
-        weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
-        styles = styles * styles.square().mean().rsqrt()                                   # :147
-        dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
+    weight, styles, dcoefs = _modulation_factors(x.dtype == torch.float16, weight, styles, demodulate)
     fuse = FUSED_F16_TAIL and grad_ops.modtail_supported(x)
     x = grad_ops.modconv_tail(x, d=styles) if fuse else x * styles.to(x.dtype).reshape(n, -1, 1, 1)       # (one pass each way incl. d/ds)
     x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
@@ -288,7 +320,29 @@ class conv2d_layer(nn.Module):
             return self.activation(y, gain=gain) if self.activation is not None else y * gain
         return grad_ops.bias_act(y, self.bias, **ak)
 
+    def _forward_half_infer(self, x, gain):
+        """float16 activations without autograd: bias + lrelu_agc fused into the store pass of the fp16 convolution (plain and FIR-filtered
+        stride-2 3x3 forms, 1x1); None for the other geometries (the composed route takes them)."""
+        from .. import kernels_f16
+        ak = _act_kwargs(self.activation, gain)
+        k = self.weight.shape[2]
+        if ak is None or self.up != 1 or k not in (1, 3) or self.weight.shape[0] % 8:
+            return None
+        w = (self.weight.detach() * self.weight_gain).to(torch.float16)
+        b = None if self.bias is None else self.bias.detach()
+        if self.down == 1:
+            return kernels_f16.conv2d(x, w, b, 1, self.padding, **ak)
+        f = self.resample_filter
+        if self.down == 2 and k == 3 and self.padding == 1 and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4):
+            y = kernels_f16.upfirdn2d(x, f, padx0=2, padx1=2, pady0=2, pady1=2)             # conv2d_resample.py:116-120
+            return kernels_f16.conv2d(y, w, b, 2, 0, **ak)
+        return None
+
     def forward(self, x, gain=1):
+        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, self.weight, self.bias):
+            y = self._forward_half_infer(x, gain)
+            if y is not None:
+                return y
         if grad_ops.generic_route(x, self.weight, self.bias):
             return self._forward_train(x, gain)
         ak = _act_kwargs(self.activation, gain)
@@ -366,6 +420,11 @@ class synthesis_layer(conv2d_layer):
         ak = _act_kwargs(self.activation, gain)
         if ak is None or self.up not in (1, 2) or self.weight.shape[2] != 3:
             raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
+        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, residual):
+            y = _modulated_conv2d_half_infer(x, self.weight.detach(), self.affine(w), None if noise is None else noise * self.noise_strength.detach(),
+                                             self.up, self.padding, self.resample_filter, True, self.up == 1, self.bias.detach(), ak, residual)
+            if y is not None:
+                return y
         if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight):
             # training rows and float16 layers (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
             # non-fused modulated convolution, bias + activation; the skip tensor (extension) is added last
@@ -400,6 +459,11 @@ class torgb_layer(conv2d_layer):
     def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None, styles_sd=None):
         if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
             raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
+        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, base_img):
+            from .. import kernels_f16
+            y = kernels_f16.conv2d(x, self.weight.detach().to(torch.float16), self.bias.detach(), 1, 0, in_scale=self.affine(w) * self.weight_gain)
+            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
         if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight, base_img):
             # training rows and float16 blocks (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338);
             # the RGB branch itself is float32 (`y.to(torch.float32)`, comodgan.py:337)

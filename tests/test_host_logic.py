@@ -130,7 +130,7 @@ def test_bad_arguments_are_reported_by_the_c_abi():
 
 
 def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
-    """The fp16 route of the C ABI (include/shgan_hip.h, ABI 23): argument checks are host code and run here -- null pointers, channel
+    """The fp16 route of the C ABI (include/shgan_hip.h, ABI 24): argument checks are host code and run here -- null pointers, channel
     counts the operand layout cannot take, unsupported geometry; the pure planning functions are exercised as well."""
     lib = _lib.get_lib()
     P = ctypes.c_void_p(16)
