@@ -48,6 +48,7 @@ struct ConvP {
     int tdy[9], tdx[9], tw[9];       // input offset of tap t (already minus the patch origin) and its weight slot
     int org_y, org_x;                // patch origin: input row of patch row 0 for grid row 0 = org_y
     int PH, PW;                      // patch extent
+    int wlds_off;                    // halves: start of the staged weight slab behind the patch / output tile (WLDS kernels)
     // fused layer tail of the inference route (all optional): x * in_scale[n,i] while the patch is staged; then
     // y = A(conv * out_scale[n,o] + noise * noise_strength + bias[o]) + residual in the store pass
     const float* in_scale; const float* out_scale; const float* noise; const _Float16* residual;
@@ -55,7 +56,7 @@ struct ConvP {
     float noise_strength, alpha, gain, clamp;
 };
 
-template <int MB, int NT, int NB>
+template <int MB, int NT, int NB, bool WLDS>
 __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
     // tile = TH x (16 NB) output pixels: wave w owns rows 2w, 2w+1; with NB = 1 its 32 lanes-of-a-block are 2 rows x 16 columns, with
     // NB = 2 block nb is row 2w + nb and the lanes are its 32 columns -- every weight operand then feeds two MFMAs
@@ -111,7 +112,28 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
                 for (int k = 0; k < 8; ++k) stage[it][k] = stage[it][k] * sh[k];
         }
     };
+    // WLDS: the weight slab of a chunk ([MB blocks][NT taps][2 k-steps] pieces of 1 KiB, already in operand order) is staged ONCE per
+    // workgroup through the same register pipeline and read from LDS lane-linearly (conflict-free) -- instead of every wave loading every
+    // operand from L2 one tap ahead (half the wave cycles parked on those loads, profiles/r03_f16_pmc_summary.txt)
+    constexpr int WPC = MB * NT * 2, WIT = WLDS ? (WPC + 3) / 4 : 1;      // pieces per chunk; a pass of the 256 threads moves 4 pieces
+    _Float16* wlds = patch + p.wlds_off;
+    h8 wstage[WIT];
+    auto fetch_w = [&](int c0) __attribute__((always_inline)) {
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pi = it * 4 + wave;                          // piece = (m * NT + t) * 2 + ks
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (pi < WPC) {
+                    const int ks = pi & 1, mt = pi >> 1, m = mt / NT, t = mt - m * NT;
+                    v = *(const h8*)(wl + ((((long)(ob0 + m) * p.wslots + p.tw[t]) * c16n + (c0 >> 4) + ks) << 9));
+                }
+                wstage[it] = v;
+            }
+        }
+    };
     fetch(0);
+    fetch_w(0);
     for (int c0 = 0; c0 < p.I; c0 += KC) {
         __syncthreads();
 #pragma unroll
@@ -119,19 +141,33 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
             const int pp = (tid >> 2) + it * 64;
             if (pp < npix) *(h8*)(patch + pp * PSTR + q8) = stage[it];
         }
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int pi = it * 4 + wave;
+                if (pi < WPC) *(h8*)(wlds + pi * 512 + lane * 8) = wstage[it];
+            }
+        }
         __syncthreads();
-        if (c0 + KC < p.I) fetch(c0 + KC);
+        if (c0 + KC < p.I) { fetch(c0 + KC); fetch_w(c0 + KC); }
         // Weight operands: unconditional loads (the packed tensor is zero-padded to whole MB groups of blocks and I % 32 == 0), those of
         // tap t+1 requested before the MFMAs of tap t -- a conditional load would be waited for on the spot (vmcnt(0) per MFMA pair).
         const _Float16* wc = wl + ((long)ob0 * p.wslots * c16n + (c0 >> 4)) * 512;
         h8 a[2][2][MB];
+        if constexpr (!WLDS) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < MB; ++m) a[0][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[0]) * c16n + ks) * 512);
+                for (int m = 0; m < MB; ++m) a[0][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[0]) * c16n + ks) * 512);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) {
+            if constexpr (WLDS) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a[t & 1][ks][m] = *(const h8*)(wlds + ((m * NT + t) * 2 + ks) * 512 + lane * 8);
+            } else if (t + 1 < NT) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -653,16 +689,25 @@ __global__ __launch_bounds__(256) void modtail_backward_f16_kernel(const TailP p
 }
 
 template <int MB, int NB>
-static int launch_conv(const ConvP& p, hipStream_t st) {
+static int launch_conv(ConvP p, hipStream_t st) {
     const dim3 grid((unsigned)((long)p.N * p.tiles_x * p.tiles_y), (unsigned)shg_cdiv(p.OB, MB));
     size_t lds = (size_t)p.PH * p.PW * PSTR * sizeof(_Float16);
     const size_t out_tile = (size_t)TH * TW * NB * (MB * 32 + 8) * sizeof(_Float16);       // the epilogue's transposed output tile reuses the patch
     if (out_tile > lds) lds = out_tile;
+    // Thick 3x3 layers (I >= 384: >= 12 chunks per tile) stage their weight slab in LDS (MB * 9 * 2 KiB behind the patch): 206 -> 181 us at
+    // 512 channels.  Thin layers lose (64 ch: 256 -> 312 us, 128 ch: 196 -> 214: two chunks cannot amortise the second staging stream and the
+    // 232-register kernel), MB = 4 would need 72 KB + the patch: both keep the L2 route with one-tap-ahead operand prefetch.
+    const bool wl = p.ntaps == 9 && MB <= 2 && p.I >= 384;
+    p.wlds_off = (int)(lds / sizeof(_Float16));
+    if (wl) lds += (size_t)MB * 9 * 2 * 1024;
     switch (p.ntaps) {
-        case 1: hipLaunchKernelGGL((conv_f16_kernel<MB, 1, NB>), grid, dim3(256), lds, st, p); break;
-        case 2: hipLaunchKernelGGL((conv_f16_kernel<MB, 2, NB>), grid, dim3(256), lds, st, p); break;
-        case 4: hipLaunchKernelGGL((conv_f16_kernel<MB, 4, NB>), grid, dim3(256), lds, st, p); break;
-        case 9: hipLaunchKernelGGL((conv_f16_kernel<MB, 9, NB>), grid, dim3(256), lds, st, p); break;
+        case 1: hipLaunchKernelGGL((conv_f16_kernel<MB, 1, NB, false>), grid, dim3(256), lds, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_f16_kernel<MB, 2, NB, false>), grid, dim3(256), lds, st, p); break;
+        case 4: hipLaunchKernelGGL((conv_f16_kernel<MB, 4, NB, false>), grid, dim3(256), lds, st, p); break;
+        case 9:
+            if (wl) hipLaunchKernelGGL((conv_f16_kernel<MB, 9, NB, (MB <= 2)>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((conv_f16_kernel<MB, 9, NB, false>), grid, dim3(256), lds, st, p);
+            break;
         default: shg_set_error("conv2d_f16: %d taps", p.ntaps); return SHG_ERR_UNSUPPORTED;
     }
     SHG_CHECK_LAUNCH();
