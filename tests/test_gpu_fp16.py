@@ -318,3 +318,13 @@ def test_fused_inference_route_of_half_layers_matches_the_composed_route(g):
     assert not torch.equal(outs[True][0], outs[False][0])                     # two different routes really ran
     assert rel_err(c(outs[True][0]), c(outs[False][0])) < 3e-3
     assert torch.isfinite(outs[True][1]).all() and outs[True][1].dtype == torch.float32
+
+
+def test_randomised_shapes_of_the_fp16_entry_points():
+    """tools/fuzz_f16.py: 150 random geometries (ragged extents, thin / odd channel counts, crops and zero-extensions of the transposed form,
+    the fused tail, FIR factors and paddings, weight gradients, the modulation tail) against float64 on the same half operands: 3e-3 bar,
+    4e-4 ... 5e-4 measured (one half rounding)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_f16.py'), '150', '7'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
