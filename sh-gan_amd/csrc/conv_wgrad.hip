@@ -29,11 +29,14 @@ struct WgradParams {
     int nslice;
 };
 
-template <int KH, int KW, int S>
+// ROWS = 2 (stride 1, OW == 32): a chunk is TWO whole output rows of 32 pixels (the same 64 operand columns; a one-row chunk would leave half
+// of them empty: 990 us for the 512-channel 32^2 layers) -- the window is then KH + 1 rows of 34 columns, a staging line = two window rows.
+template <int KH, int KW, int S, int ROWS = 1>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
-    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, XW = PX * S + KW - 1, CP = 65;    // CP: channel pitch (odd)
+    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, RW = PX / ROWS, XW = RW * S + KW - 1, WROWS = KH + ROWS - 1, CP = 65;    // CP: channel pitch (odd)
+    static_assert(ROWS == 1 || S == 1, "two-row chunks are a stride-1 form");
     __shared__ float Gs[PX * CP];                                // [pixel][o]
-    __shared__ float Xs[KH * XW * CP];                           // [row][col][i]
+    __shared__ float Xs[WROWS * XW * CP];                        // [row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int grp = wave >> 2, mo = (wave >> 1) & 1, nt = wave & 1;   // grp: the two k-step groups (two waves per SIMD)
     const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, slice = blockIdx.z;
@@ -52,19 +55,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     // address add and one select per element.  The KW-1 halo columns of all lines follow, one lane per element.
     // (Tried and slower: keeping the loaded values raw and masking them when they are written to LDS, 68 vs 77 TFLOP/s at
     // 512 channels; an explicit LDS-operand prefetch in the MFMA loop, 64.)
-    constexpr int NLINE = 64 * KH, LPW = NLINE / 8;             // x lines, per wave
-    constexpr int HC = XW - 64;                                  // halo columns of a line (KW - 1)
-    constexpr int NHE = NLINE * HC, NHT = (NHE + 511) / 512;     // halo elements, per thread
+    constexpr int NLINE = 64 * WROWS / ROWS, LPW = NLINE / 8;    // x lines (ROWS window rows each), per wave
+    constexpr int HC = XW - RW * S;                              // halo columns of a window row (KW - 1)
+    constexpr int NHE = 64 * WROWS * HC, NHT = (NHE + 511) / 512;   // halo elements, per thread
     constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (a 64-lane instruction = 64 / PX lines)
-    static_assert(PX * S == 64, "a window line is 64 columns + halo");
+    static_assert(RW * S * ROWS == 64, "a staging line is 64 columns (+ halo)");
     float rg[GL], rx[LPW + (NHT ? NHT : 1)];
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        const int cx = c % p.chunks_x, oy = (c / p.chunks_x) % p.OH, n = c / (p.chunks_x * p.OH);
-        const int ox0 = cx * PX;
+        const int cx = ROWS == 1 ? c % p.chunks_x : 0;
+        const int oy = ROWS == 1 ? (c / p.chunks_x) % p.OH : ROWS * (c % (p.OH / ROWS)), n = ROWS == 1 ? c / (p.chunks_x * p.OH) : c / (p.OH / ROWS);
+        const int ox0 = cx * PX;                                 // (ROWS = 2: the chunk's 64 pixels are rows oy, oy + 1 -- contiguous in g)
         {
             const int gpx = lane % PX, gsub = lane / PX;         // pixel, line within the instruction
-            const bool pok = ox0 + gpx < p.OW;
+            const bool pok = ROWS > 1 || ox0 + gpx < p.OW;      // (ROWS = 2: pixel gpx of rows oy, oy + 1 -- 64 contiguous floats)
             const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0 + (pok ? gpx : 0);
 #pragma unroll
             for (int j = 0; j < GL; ++j) {
@@ -74,14 +78,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
                 rg[j] = ok ? v : 0.f;
             }
         }
-        const int ixl = ox0 * S - p.pad + lane;
+        const int lcol = ROWS == 1 ? lane : (lane & (RW - 1)), lrow = ROWS == 1 ? 0 : lane / RW;     // column / row of this lane inside a line
+        const int ixl = ox0 * S - p.pad + lcol;
         const bool cok = ixl >= 0 && ixl < p.W;
         const float* xn = p.x + ((long)n * p.I + i0) * xplane;
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
-            const int L = wv + 8 * j, i = L / KH, r = L - i * KH;        // uniform
+            const int L = wv + 8 * j, i = L / (WROWS / ROWS), r = (L - i * (WROWS / ROWS)) * ROWS + lrow;        // uniform up to lrow
             const int iy = oy * S - p.pad + r;
-            const bool rok = iy >= 0 && iy < p.H && i0 + i < p.I;       // uniform
+            const bool rok = iy >= 0 && iy < p.H && i0 + i < p.I;
             const bool ok = rok && cok;
             const float v = xn[ok ? (long)i * xplane + (long)iy * p.W + ixl : 0];
             rx[j] = ok ? v : 0.f;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int t = 0; t < NHT; ++t) {
             const int e = tid + 512 * t;
-            const int L = e / (HC ? HC : 1), hc = 64 + e - L * (HC ? HC : 1), i = L / KH, r = L - i * KH;
+            const int L = e / (HC ? HC : 1), hc = RW * S + e - L * (HC ? HC : 1), i = L / WROWS, r = L - i * WROWS;
             const int iy = oy * S - p.pad + r, ix = ox0 * S - p.pad + hc;
             const bool ok = e < NHE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + i < p.I;
             const float v = xn[ok ? (long)i * xplane + (long)iy * p.W + ix : 0];
@@ -102,15 +107,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int j = 0; j < GL; ++j) Gs[gpx * CP + (wv + 8 * j) * (64 / PX) + gsub] = rg[j];
         }
+        const int lcol = ROWS == 1 ? lane : (lane & (RW - 1)), lrow = ROWS == 1 ? 0 : lane / RW;
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
-            const int L = wv + 8 * j, i = L / KH, r = L - i * KH;
-            Xs[(r * XW + lane) * CP + i] = rx[j];
+            const int L = wv + 8 * j, i = L / (WROWS / ROWS), r = (L - i * (WROWS / ROWS)) * ROWS + lrow;
+            Xs[(r * XW + lcol) * CP + i] = rx[j];
         }
 #pragma unroll
         for (int t = 0; t < NHT; ++t) {
             const int e = tid + 512 * t;
-            const int L = e / (HC ? HC : 1), hc = 64 + e - L * (HC ? HC : 1), i = L / KH, r = L - i * KH;
+            const int L = e / (HC ? HC : 1), hc = RW * S + e - L * (HC ? HC : 1), i = L / WROWS, r = L - i * WROWS;
             if (e < NHE) Xs[(r * XW + hc) * CP + i] = rx[LPW + t];
         }
     };
@@ -125,28 +131,31 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             const float a = Gs[k * CP + mo * 32 + l31];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[((t / KW) * XW + k * S + (t % KW)) * CP + nt * 32 + l31], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[((t / KW + (ROWS == 1 ? 0 : k / RW)) * XW + (ROWS == 1 ? k : (k & (RW - 1))) * S + (t % KW)) * CP + nt * 32 + l31],
+                                                              acc[t], 0, 0, 0);
         }
     }
     // the second wave group hands its partial sums to the first through LDS (three taps at a time: 48 KB over the window buffer)
     float* red = Xs;
-    static_assert(sizeof(Xs) >= sizeof(float) * 4 * (TAPS < 3 ? TAPS : 3) * 1024, "reduction buffer");
-    constexpr int TB = TAPS < 3 ? TAPS : 3;
+    constexpr int TB = sizeof(Xs) >= sizeof(float) * 4 * 3 * 1024 ? (TAPS < 3 ? TAPS : 3) : (sizeof(Xs) >= sizeof(float) * 4 * 2 * 1024 ? (TAPS < 2 ? TAPS : 2) : 1);
+    static_assert(sizeof(Xs) >= sizeof(float) * 4 * TB * 1024, "reduction buffer");
 #pragma unroll
     for (int t0 = 0; t0 < TAPS; t0 += TB) {
         __syncthreads();
         if (grp == 1) {
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt)
+                if (t0 + tt < TAPS)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane] = acc[t0 + tt][r];
+                    for (int r = 0; r < 16; ++r) red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane] = acc[t0 + tt][r];
         }
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt)
+                if (t0 + tt < TAPS)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t0 + tt][r] += red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) acc[t0 + tt][r] += red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane];
         }
     }
     if (grp == 1) return;
@@ -314,8 +323,9 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     WgradParams p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
     const bool packed = wgrad_packed(OW, W, kh, stride, pad);
+    const bool two_rows = !packed && kh == 3 && stride == 1 && OW == 32 && (OH % 2) == 0 && W == 32 + 2 - 2 * pad;      // 32-pixel rows: two per chunk
     p.chunks_x = shg_cdiv(OW, stride == 1 ? 64 : 32);
-    p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : NB * OH * p.chunks_x;
+    p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : (two_rows ? NB * (OH / 2) : NB * OH * p.chunks_x);
     p.nslice = wgrad_slices(NB, I, O, OH, OW, kh * kw);
     if (p.nslice > p.nchunk) p.nslice = p.nchunk;
     const size_t need = p.nslice > 1 ? (size_t)p.nslice * O * I * kh * kw * sizeof(float) : 0;
@@ -325,6 +335,7 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     hipStream_t s = (hipStream_t)stream;
     if (packed && stride == 1) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (packed) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
+    else if (two_rows) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 2>), grid, dim3(512), 0, s, p);
     else if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);

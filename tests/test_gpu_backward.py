@@ -32,6 +32,8 @@ CONV_CASES = [
     # small images: several output rows per chunk (packed form), incl. a partial last chunk and rows of several images in one chunk
     (3, 24, 70, 4, 4, 3, 1, 1), (5, 64, 64, 8, 8, 3, 1, 1), (3, 40, 33, 32, 32, 3, 1, 1), (7, 16, 16, 9, 9, 3, 2, 0), (3, 70, 24, 17, 17, 3, 2, 0),
     (2, 32, 32, 33, 33, 3, 2, 0), (3, 16, 24, 8, 8, 3, 2, 1),
+    # 32-pixel output rows: two rows per chunk of the weight-gradient kernel (pad 1 and pad 0), and an odd row count (one-row chunks)
+    (2, 24, 40, 34, 34, 3, 1, 0), (3, 70, 64, 32, 32, 3, 1, 1), (2, 16, 24, 33, 32, 3, 1, 1),
 ]
 
 
