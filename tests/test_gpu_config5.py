@@ -154,12 +154,13 @@ def test_config5_full_width_phases_vs_reference_autograd():
     compare_grads(G, g, 'greg', None, None, yardstick='greg64', floor=1e-2)
 
 
-def test_config5_batch8_training_iteration_all_phases():
+@pytest.mark.parametrize('fp16', [False, True])
+def test_config5_batch8_training_iteration_all_phases(fp16):
     """The configuration's own size: FFHQ-512, batch 8 on this GPU, Gmain + Greg + Dmain + Dreg with Adam through
     ``train_stage.run_phases`` (gradients in the all-reduce buckets, sanitised); two iterations from the same state are bit-identical."""
     import copy
     from shgan_amd import losses, train_stage as ts
-    G, D = build_networks(512, 61, 62)
+    G, D = build_networks(512, 61, 62, fp16=fp16)          # fp16: the second-order phases (R1, path length) differentiate the half kernels twice
     G.requires_grad_(False); D.requires_grad_(False)
     g0, d0 = copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict())
     rs = np.random.RandomState(63)
