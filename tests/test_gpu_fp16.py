@@ -328,3 +328,30 @@ def test_randomised_shapes_of_the_fp16_entry_points():
     from conftest import ROOT
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_f16.py'), '150', '7'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
+def test_fp16_blocks_full_width_512_batch16_properties():
+    """The reference's use_fp16 option at BASELINE size (FFHQ-512, batch 16, full width) -- no fp16 fixture exists at this size (CPU hours), so
+    size-independent properties: the fp16-block generator stays within half precision of the float32 one on the same weights and inputs
+    (2e-2 of the image range, measured 1.0e-3), is bit-identical run to run, shard-invariant (a 2-image shard = rows of the full batch within one
+    half rounding: the batch-global style norm), and the known pixels of the uint8 composite are exact."""
+    from shgan_amd import configs, eval_harness
+    G32 = configs.seeded_init_(configs.build_generator(512), seed=91, noise_strength=0.05).eval().requires_grad_(False).to(DEV)
+    G16 = configs.build_generator(512, use_fp16_before_res=64, use_fp16_after_res=32)
+    G16.load_state_dict(G32.state_dict(), strict=True)
+    G16 = G16.eval().requires_grad_(False).to(DEV)
+    x, z, real_u8, mask = eval_harness.synthetic_batch(16, 512, 512, seed=92, device=DEV, masks='bernoulli')
+    cnd = torch.zeros(16, 0, device=DEV)
+    with torch.no_grad():
+        a = G16(x=x, z=z, c=cnd, noise_mode='const')
+        b = G16(x=x, z=z, c=cnd, noise_mode='const')
+        ref = G32(x=x, z=z, c=cnd, noise_mode='const')
+        sub = G16(x=x[:2], z=z[:2], c=cnd[:2], noise_mode='const')
+        u8 = eval_harness.run_generator(G16, x, z, noise_mode='const')
+    assert torch.equal(a, b) and torch.isfinite(a).all() and a.dtype == torch.float32
+    e = rel_err(c(a), c(ref))
+    print(f'fp16 blocks vs float32, 512 x 16 full width: {e:.2e}')
+    assert e < 2e-2
+    assert rel_err(c(sub), c(a[:2])) < 5e-3
+    m = mask.astype(bool)
+    assert np.array_equal(np.where(m, u8.cpu().numpy(), 0), np.where(m, real_u8, 0))
