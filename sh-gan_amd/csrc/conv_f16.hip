@@ -27,6 +27,28 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
+#ifndef SHG_F16_ADEPTH
+#define SHG_F16_ADEPTH 1
+#endif
+#ifndef SHG_F16_EG
+#define SHG_F16_EG 4
+#endif
+#ifndef SHG_F16_ABL
+#define SHG_F16_ABL 0   // timing-study builds only (tools/_variants, tools/f16_abl.sh): 1 no B reads, 2 no A loads, 4 no staging, 8 no epilogue, 16 no loop barriers
+#endif
+
+#ifdef SHG_F16_TRACE
+// timeline study (python sh-gan_amd/build.py --variant=f16trace -DSHG_F16_TRACE=1, tools/f16_trace.py): every 61st workgroup of channel group 0
+// records clock64() of wave 0 at: entry | first chunk in LDS | first chunk multiplied | all chunks multiplied | stores issued | stores drained
+__device__ long long shg_f16_trace_buf[256 * 8];
+extern "C" int shg_f16_trace_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shg_f16_trace_buf), sizeof(shg_f16_trace_buf));
+}
+#define F16_TRACE(slot) do { if (blockIdx.y == 0 && blockIdx.x % 61 == 0 && blockIdx.x / 61 < 256 && threadIdx.x == 0) shg_f16_trace_buf[(blockIdx.x / 61) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define F16_TRACE(slot) do { } while (0)
+#endif
+
 namespace f16 {
 
 constexpr int TH = 8, TW = 16;       // output-pixel tile of a workgroup (4 waves x 2 rows x 16 columns)
@@ -132,10 +154,12 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
             }
         }
     };
+    F16_TRACE(0);
     fetch(0);
     fetch_w(0);
     for (int c0 = 0; c0 < p.I; c0 += KC) {
-        __syncthreads();
+        if (!(SHG_F16_ABL & 16)) __syncthreads();
+        if (!(SHG_F16_ABL & 4) || c0 == 0)
 #pragma unroll
         for (int it = 0; it < SIT; ++it) {
             const int pp = (tid >> 2) + it * 64;
@@ -148,17 +172,21 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
                 if (pi < WPC) *(h8*)(wlds + pi * 512 + lane * 8) = wstage[it];
             }
         }
-        __syncthreads();
-        if (c0 + KC < p.I) { fetch(c0 + KC); fetch_w(c0 + KC); }
+        if (!(SHG_F16_ABL & 16)) __syncthreads();
+        if (c0 == 0) F16_TRACE(1);
+        if (c0 + KC < p.I && !(SHG_F16_ABL & 4)) { fetch(c0 + KC); fetch_w(c0 + KC); }
         // Weight operands: unconditional loads (the packed tensor is zero-padded to whole MB groups of blocks and I % 32 == 0), those of
         // tap t+1 requested before the MFMAs of tap t -- a conditional load would be waited for on the spot (vmcnt(0) per MFMA pair).
         const _Float16* wc = wl + ((long)ob0 * p.wslots * c16n + (c0 >> 4)) * 512;
-        h8 a[2][2][MB];
+        constexpr int AD = SHG_F16_ADEPTH;                          // operand prefetch distance in taps (ring of AD + 1 slots)
+        h8 a[AD + 1][2][MB];
         if constexpr (!WLDS) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int t = 0; t < AD && t < NT; ++t)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) a[0][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[0]) * c16n + ks) * 512);
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a[t][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[t]) * c16n + ks) * 512);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -166,32 +194,58 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) a[t & 1][ks][m] = *(const h8*)(wlds + ((m * NT + t) * 2 + ks) * 512 + lane * 8);
-            } else if (t + 1 < NT) {
+                    for (int m = 0; m < MB; ++m) a[t % (AD + 1)][ks][m] = *(const h8*)(wlds + ((m * NT + t) * 2 + ks) * 512 + lane * 8);
+            } else if (t + AD < NT && !((SHG_F16_ABL & 2) && c0)) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) a[(t + 1) & 1][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[t + 1]) * c16n + ks) * 512);
+                    for (int m = 0; m < MB; ++m) a[(t + AD) % (AD + 1)][ks][m] = *(const h8*)(wc + (((long)m * p.wslots + p.tw[t + AD]) * c16n + ks) * 512);
             }
+            // the compiler otherwise sinks the operand requests to just before their use (measured: 3-8 % on the 128 / 256-channel layers)
+            __builtin_amdgcn_sched_barrier(0);
             const _Float16* bp = patch + ((ry * p.s_in + p.tdy[t]) * p.PW + rx * p.s_in + p.tdx[t]) * PSTR + kg * 8;
             h8 b[2][NB];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int q = 0; q < NB; ++q) b[ks][q] = *(const h8*)(bp + q * p.s_in * p.PW * PSTR + ks * 16);
+                for (int q = 0; q < NB; ++q) b[ks][q] = (SHG_F16_ABL & 1) ? a[0][ks][0] : *(const h8*)(bp + q * p.s_in * p.PW * PSTR + ks * 16);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][ks][m], b[ks][q], acc[m][q], 0, 0, 0);
+                    for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t % (AD + 1)][ks][m], b[ks][q], acc[m][q], 0, 0, 0);
         }
+        if (c0 == 0) F16_TRACE(2);
     }
+    F16_TRACE(3);
     // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  A lane holds 4-channel runs of ONE
     // pixel: stored directly, every store instruction would touch 64 different 128-byte lines with 8 bytes each.  The tile is therefore
     // transposed through LDS (pixel-major, 16 bytes of padding per pixel) and leaves as whole 16-byte pieces of contiguous channel runs.
     constexpr int OPS = MB * 32 + 8;
+    if (SHG_F16_ABL & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[m][q][r];
+        if (sacc != 1234.5f) return;
+    }
+    float bv[MB][4][4];                                             // bias of a lane's channels (no-tail launches), requested before the barrier
+    const bool pre_bias = p.bias && !p.tail;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = ob0 * 32 + m * 32 + qq * 8 + kg * 4 + e;
+                bv[m][qq][e] = pre_bias ? p.bias[o < p.O ? o : p.O - 1] : 0.f;
+            }
     __syncthreads();
+    F16_TRACE(6);
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int pl = NB == 1 ? ry * TW + rx : (ry + q) * TWK + rx;
@@ -199,15 +253,56 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const int ol = m * 32 + qq * 8 + kg * 4, o = ob0 * 32 + ol;
+                const int ol = m * 32 + qq * 8 + kg * 4;
                 h4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][qq * 4 + e] + ((p.bias && !p.tail && o + e < p.O) ? p.bias[o + e] : 0.f));
+                for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][qq * 4 + e] + bv[m][qq][e]);
                 *(h4*)(patch + pl * OPS + ol) = v;
             }
     }
     __syncthreads();
+    F16_TRACE(7);
     constexpr int PCS = MB * 4;                                   // 16-byte pieces per pixel
+    if ((p.O & 7) == 0) {
+        // whole 8-channel pieces: all LDS reads first, every operand load unconditional (clamped address), only the store predicated -- a
+        // rolled loop with early exits spent 550 cycles per piece (tools/f16_trace.py: LDS latency + address arithmetic in series)
+        constexpr int EIT = TH * TWK * PCS / 256, EG = EIT < SHG_F16_EG ? EIT : SHG_F16_EG;    // pieces per thread, in groups of EG (registers)
+        for (int i0 = 0; i0 < EIT; i0 += EG) {
+        h8 vv[EG];
+#pragma unroll
+        for (int it = 0; it < EG; ++it) {
+            const int e = tid + (i0 + it) * 256, pl = e / PCS, pc = e - pl * PCS;
+            vv[it] = *(const h8*)(patch + pl * OPS + pc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < EG; ++it) {
+            const int e = tid + (i0 + it) * 256, pl = e / PCS, pc = e - pl * PCS, row = pl / TWK, col = pl - row * TWK;
+            const int gy = ty * TH + row, gx = tx * TWK + col;
+            const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0, o = ob0 * 32 + pc * 8;
+            const bool ok = gy < p.GH && gx < p.GW && oy >= 0 && oy < p.OHt && ox >= 0 && ox < p.OWt && o < p.O;
+            const int oyc = oy < 0 ? 0 : (oy < p.OHt ? oy : p.OHt - 1), oxc = ox < 0 ? 0 : (ox < p.OWt ? ox : p.OWt - 1), oc = o < p.O ? o : p.O - 8;
+            const long pix = (long)oyc * p.OWt + oxc, off = ((long)n * p.OHt * p.OWt + pix) * p.O + oc;
+            h8 v = vv[it];
+            if (p.tail) {
+                const float nz = p.noise_mode == 0 ? 0.f : p.noise[(p.noise_mode == 2 ? (long)n * p.OHt * p.OWt : 0) + pix] * p.noise_strength;
+                const float4 d0 = p.out_scale ? *(const float4*)(p.out_scale + (long)n * p.O + oc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 d1 = p.out_scale ? *(const float4*)(p.out_scale + (long)n * p.O + oc + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 b0 = p.bias ? *(const float4*)(p.bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b1 = p.bias ? *(const float4*)(p.bias + oc + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                h8 rs = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.residual) rs = *(const h8*)(p.residual + off);
+                const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float z = (float)v[k] * dd[k] + nz + bb[k];
+                    z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
+                    v[k] = (_Float16)((float)(_Float16)z + (float)rs[k]);
+                }
+            }
+            if (ok) *(h8*)(p.y + off) = v;
+        }
+        }
+    } else
     for (int e = tid; e < TH * TWK * PCS; e += 256) {
         const int pl = e / PCS, pc = e - pl * PCS, row = pl / TWK, col = pl - row * TWK;
         const int gy = ty * TH + row, gx = tx * TWK + col;
@@ -253,6 +348,11 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const ConvP p) {
             for (int k = 0; k < 8; ++k)
                 if (o + k < p.O) yp[k] = v[k];
     }
+#ifdef SHG_F16_TRACE
+    F16_TRACE(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    F16_TRACE(5);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -3,6 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import shgan_amd
+from shgan_amd import _lib
+if os.environ.get('SHG_VARIANT'):        # A/B knobs: python sh-gan_amd/build.py --variant=<tag> -D...
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import kernels_f16 as kf
 
 dev = 'cuda:0'
@@ -23,6 +26,7 @@ def timeit(fn, reps=10):
 
 
 N = 8
+FWD_ONLY = bool(os.environ.get('SHG_F16_FWD_ONLY'))     # ablation runs (tools/f16_abl.sh): forward shapes only
 for (i, o, r, k, s) in [(64, 64, 512, 3, 1), (128, 128, 256, 3, 1), (256, 256, 128, 3, 1), (512, 512, 64, 3, 1), (64, 128, 513, 3, 2), (128, 256, 257, 3, 2),
                          (64, 64, 512, 1, 1), (512, 512, 64, 1, 1)]:
     x = torch.randn(N, i, r, r, device=dev).half().to(memory_format=CL)
@@ -33,8 +37,10 @@ for (i, o, r, k, s) in [(64, 64, 512, 3, 1), (128, 128, 256, 3, 1), (256, 256, 1
     by = 2.0 * (x.numel() + y.numel())
     t = timeit(lambda: kf.conv2d(x, w, None, s, pad))
     g = torch.randn_like(y)
-    tw = timeit(lambda: kf.conv2d_wgrad(x, g, k, s, pad))
-    print(f'conv {i:4d}->{o:4d} {r:4d}^2 k{k} s{s}: fwd {t:8.1f} us {fl / t / 1e6:7.1f} TFLOP/s {by / t / 1e3:7.1f} GB/s | wgrad {tw:8.1f} us {fl / tw / 1e6:7.1f} TFLOP/s')
+    tw = 0.0 if FWD_ONLY else timeit(lambda: kf.conv2d_wgrad(x, g, k, s, pad))
+    print(f'conv {i:4d}->{o:4d} {r:4d}^2 k{k} s{s}: fwd {t:8.1f} us {fl / t / 1e6:7.1f} TFLOP/s {by / t / 1e3:7.1f} GB/s | wgrad {tw:8.1f} us {fl / max(tw, 1e-9) / 1e6:7.1f} TFLOP/s')
+if FWD_ONLY:
+    sys.exit(0)
 for (i, o, r) in [(128, 64, 256), (256, 128, 128), (512, 256, 64)]:
     x = torch.randn(N, i, r, r, device=dev).half().to(memory_format=CL)
     w = (torch.randn(i, o, 3, 3, device=dev) / (i * 9) ** 0.5).half()

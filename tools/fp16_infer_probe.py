@@ -1,6 +1,9 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, shgan_amd
+from shgan_amd import _lib
+if os.environ.get('SHG_VARIANT'):        # A/B: python sh-gan_amd/build.py --variant=<tag> [-D...]
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import configs, eval_harness, kernels
 dev='cuda:0'
 for fp16 in (False, True):

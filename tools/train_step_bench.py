@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 import shgan_amd
+from shgan_amd import _lib
+if os.environ.get('SHG_VARIANT'):        # A/B: python sh-gan_amd/build.py --variant=<tag> [-D...]
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import configs, eval_harness, kernels
 from shgan_amd.grad_sync import BucketedAllReduce
 from shgan_amd.model_zoo import stylegan

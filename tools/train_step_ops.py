@@ -9,4 +9,4 @@ g_phase, d_phase = ns['g_phase'], ns['d_phase']
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     g_phase(); d_phase()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=40, max_name_column_width=60, max_shapes_column_width=90))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=int(os.environ.get('SHG_OPS_ROWS', '40')), max_name_column_width=60, max_shapes_column_width=90))
