@@ -659,23 +659,52 @@ __global__ __launch_bounds__(256) void fir_same_f16_kernel(const UfdH p) {
 }
 
 // y = lrelu_agc(x + bias[c]) on NHWC halves (arithmetic in fp32, one rounding), and its gradient from the saved output
+// Streaming passes: the per-channel operands are read as two float4 ONCE per thread when 256 % (C/8) == 0 (a thread then keeps its channels for
+// the whole grid-stride loop) -- eight scalar operand loads and a 64-bit modulo per 16-byte piece ran at 2.0-3.1 TB/s of read + write traffic, this
+// form at 5.4-6.3 (tools/conv_f16_bench.py).  EU > 1 requests several pieces before the first use: no gain (4.8 TB/s at 4), the pass is not
+// short of loads in flight.
+#ifndef SHG_F16_EU
+#define SHG_F16_EU 1
+#endif
+constexpr int EU = SHG_F16_EU;
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// CONSTC: 256 % (C/8) == 0 -- a thread keeps its 8 channels for the whole grid-stride loop and holds their bias in registers
+template <bool CONSTC>
 __global__ __launch_bounds__(256) void bias_act_f16_kernel(const _Float16* x, const float* bias, _Float16* y, long total8, int C, int act,
                                                            float alpha, float gain, float clamp) {
     const int c8n = C >> 3;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long)gridDim.x * 256) {
-        const int c = (int)(e % c8n) * 8;
-        const h8 v = *(const h8*)(x + e * 8);
-        h8 out;
+    const long stride = (long)gridDim.x * 256, e0 = (long)blockIdx.x * 256 + threadIdx.x;
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (CONSTC && bias) load8f(bias + (int)(e0 % c8n) * 8, bb);
+    for (long eb = e0; eb < total8; eb += EU * stride) {
+        h8 v[EU];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float t = (float)v[q] + (bias ? bias[c + q] : 0.f);
-            t = act ? shg_lrelu_agc(t, alpha, gain, clamp) : t * gain;
-            out[q] = (_Float16)t;
+        for (int u = 0; u < EU; ++u) {
+            const long e = eb + u * stride;
+            v[u] = *(const h8*)(x + (e < total8 ? e : total8 - 1) * 8);
         }
-        *(h8*)(y + e * 8) = out;
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const long e = eb + u * stride;
+            if (!CONSTC && bias) load8f(bias + (int)((e < total8 ? e : total8 - 1) % c8n) * 8, bb);
+            h8 out;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float t = (float)v[u][q] + bb[q];
+                t = act ? shg_lrelu_agc(t, alpha, gain, clamp) : t * gain;
+                out[q] = (_Float16)t;
+            }
+            if (e < total8) *(h8*)(y + e * 8) = out;
+        }
     }
 }
 
+// (three streams and no per-channel operand: the plain loop already runs at 5+ TB/s, grouping the loads measured 5 % slower)
 __global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float16* g, const _Float16* y, _Float16* dx, long total8, int act,
                                                                     float alpha, float gain, float clamp) {
     const float gp = gain, gn = act ? alpha * gain : gain;
@@ -691,7 +720,6 @@ __global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float
         *(h8*)(dx + e * 8) = out;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Modulation tail of a half layer in ONE pass each way (stylegan.py:176-181 `fma(x, dcoefs, noise)` + :298-304 bias / lrelu_agc, and
@@ -710,24 +738,46 @@ struct TailP {
     float alpha, gain, clamp;
 };
 
+template <bool CONSTC>
 __global__ __launch_bounds__(256) void modtail_f16_kernel(const TailP p) {
     const int c8n = p.C >> 3, n = blockIdx.y;
     const long total = (long)p.HW * c8n;
     const _Float16* tp = p.t + (long)n * p.HW * p.C;
     _Float16* yp = p.out + (long)n * p.HW * p.C;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c = (int)(e % c8n) * 8;
-        const long pix = e / c8n;
-        const h8 v = *(const h8*)(tp + e * 8);
-        const float nz = p.noise_mode == 0 ? 0.f : p.noise[(p.noise_mode == 2 ? (long)n * p.HW : 0) + pix];
-        h8 o;
+    const float* np_ = p.noise_mode == 0 ? nullptr : p.noise + (p.noise_mode == 2 ? (long)n * p.HW : 0);
+    const long stride = (long)gridDim.x * 256, e0 = (long)blockIdx.x * 256 + threadIdx.x;
+    float dd[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (CONSTC) {
+        const int c = (int)(e0 % c8n) * 8;
+        if (p.d) load8f(p.d + (long)n * p.C + c, dd);
+        if (p.bias) load8f(p.bias + c, bb);
+    }
+    for (long eb = e0; eb < total; eb += EU * stride) {
+        h8 v[EU];
+        float nz[EU];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float z = (float)v[q] * (p.d ? p.d[(long)n * p.C + c + q] : 1.f) + nz + (p.bias ? p.bias[c + q] : 0.f);
-            z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
-            o[q] = (_Float16)z;
+        for (int u = 0; u < EU; ++u) {
+            const long e = eb + u * stride, ec = e < total ? e : total - 1;
+            v[u] = *(const h8*)(tp + ec * 8);
+            nz[u] = np_ ? np_[ec / c8n] : 0.f;
         }
-        *(h8*)(yp + e * 8) = o;
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const long e = eb + u * stride;
+            if (!CONSTC) {
+                const int c = (int)((e < total ? e : total - 1) % c8n) * 8;
+                if (p.d) load8f(p.d + (long)n * p.C + c, dd);
+                if (p.bias) load8f(p.bias + c, bb);
+            }
+            h8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float z = (float)v[u][q] * dd[q] + nz[u] + bb[q];
+                z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
+                o[q] = (_Float16)z;
+            }
+            if (e < total) *(h8*)(yp + e * 8) = o;
+        }
     }
 }
 
@@ -1013,10 +1063,14 @@ extern "C" int shg_bias_act_f16(const void* x, const float* bias, void* y, long 
     SHG_CHECK_ARG(pixels >= 0 && C >= 8 && (C % 8) == 0, "bias_act_f16: C must be a multiple of 8");
     const long total8 = pixels * (C / 8);
     if (total8 == 0) return SHG_OK;
-    int grid = shg_cdiv(total8, 256);
-    if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(f16::bias_act_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, bias, (_Float16*)y, total8, C,
-                       act, alpha, gain, clamp);
+    int grid = (int)shg_cdiv(total8, 256L * f16::EU);
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (256 % (C / 8) == 0)
+        hipLaunchKernelGGL(f16::bias_act_f16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, bias, (_Float16*)y, total8, C,
+                           act, alpha, gain, clamp);
+    else
+        hipLaunchKernelGGL(f16::bias_act_f16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, bias, (_Float16*)y, total8, C,
+                           act, alpha, gain, clamp);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
@@ -1042,9 +1096,10 @@ extern "C" int shg_modtail_f16(const void* t, const float* d, const float* noise
     f16::TailP p{};
     p.t = (const _Float16*)t; p.d = d; p.noise = noise_mode ? noise : nullptr; p.noise_mode = noise ? noise_mode : 0; p.bias = bias;
     p.out = (_Float16*)y; p.N = N; p.HW = (int)HW; p.C = C; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
-    long blocks = (HW * (C / 8) + 255) / 256;
+    long blocks = (HW * (C / 8) + 256 * f16::EU - 1) / (256 * f16::EU);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(f16::modtail_f16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, p);
+    if (256 % (C / 8) == 0) hipLaunchKernelGGL(f16::modtail_f16_kernel<true>, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(f16::modtail_f16_kernel<false>, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -71,6 +71,16 @@ class _BiasActFn(torch.autograd.Function):
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         act, gain, alpha, act_gain, clamp, has_bias = ctx.cfg
+        if has_bias and ctx.needs_input_grad[1] and not torch.is_grad_enabled() and modtail_supported(y):
+            # first order: dx and the per-(n, c) sums of the SAME pass (the tail kernel without scale / noise) instead of a second trip over
+            # dx for the bias gradient -- 25 half / 100 float reductions of 70 us per training step
+            if y.dtype == torch.float16:
+                dx, _, s0, _ = kernels_f16.modtail_backward(g.detach().to(torch.float16), y, None, None, want_sums=True, want_noise=False, act=act,
+                                                            gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+            else:
+                dx, _, s0, _ = kernels.modtail_backward(g.detach().contiguous(), y, None, None, want_sums=True, want_noise=False, act=act, gain=gain,
+                                                        alpha=alpha, act_gain=act_gain, clamp=clamp)
+            return dx, s0.sum(0), None, None, None, None, None
         dx = _BiasActBwdFn.apply(g, y, (act, gain, alpha, act_gain, clamp))
         db = None
         if has_bias and ctx.needs_input_grad[1]:

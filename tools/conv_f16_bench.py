@@ -53,5 +53,19 @@ f = torch.tensor([1., 3., 3., 1.], device=dev)
 f = torch.outer(f, f) / 64
 t = timeit(lambda: kf.upfirdn2d(x, f, padx0=2, padx1=2, pady0=2, pady1=2))
 print(f'upfirdn2d pad2 64ch 513^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
-t = timeit(lambda: kf.bias_act(x, torch.zeros(64, device=dev)))
-print(f'bias_act 64ch 513^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
+for (c, r) in [(64, 513), (128, 257), (256, 128)]:
+    x = torch.randn(N, c, r, r, device=dev).half().to(memory_format=CL)
+    b, d = torch.randn(c, device=dev), torch.rand(N, c, device=dev) + 0.5
+    nz = torch.randn(N, 1, r, r, device=dev)
+    t = timeit(lambda: kf.bias_act(x, b))
+    print(f'bias_act {c}ch {r}^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
+    y = kf.bias_act(x, b)
+    t = timeit(lambda: kf.bias_act_backward(x, y))
+    print(f'bias_act_backward {c}ch {r}^2: {t:8.1f} us {2.0 * 3 * x.numel() / t / 1e3:7.1f} GB/s')
+    t = timeit(lambda: kf.modtail(x, d, nz, b, act=True))
+    print(f'modtail {c}ch {r}^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
+    y = kf.modtail(x, d, nz, b, act=True)
+    t = timeit(lambda: kf.modtail_backward(x, y, x, d, want_sums=True, want_noise=True, act=True))
+    print(f'modtail_backward {c}ch {r}^2: {t:8.1f} us {2.0 * 4 * x.numel() / t / 1e3:7.1f} GB/s')
+    t = timeit(lambda: kf.upfirdn2d(x, f, padx0=2, padx1=1, pady0=2, pady1=1))
+    print(f'upfirdn2d same-size {c}ch {r}^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
