@@ -21,6 +21,7 @@
 //                        (deterministic).
 //   upfirdn2d_f16        the generic gather of upfirdn2d.cu:29-92 on NHWC halves, 8 channels per lane, fp32 accumulation.
 //   bias_act_f16 (+bwd)  x + bias[c] -> lrelu_agc, and its gradient from the saved output (common/utils.py:135-143).
+#include <type_traits>
 #include "shg_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -484,18 +485,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
         }
 }
 
-// dw[t][o][i] = sum over slices, fixed order
+// dw[t][o][i] = sum over slices in a fixed order: G slice groups per workgroup (256 / G elements each), thread (g, el) adds slices g, g + G, ...
+// in four interleaved accumulators, the groups are combined in group order through LDS (deterministic for a given shape).  With one thread per
+// element over all slices a 64-channel layer (36 864 weights x 512 slices) ran on 144 workgroups of serial strided loads.
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, int slices, int NT, int O, int I, int OP, int IP) {
-    const long total = (long)NT * O * I;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    __shared__ float red[256];
+    constexpr int EL = 256 / G;
+    const int el = threadIdx.x % EL, g = threadIdx.x / EL;
+    const long total = (long)NT * O * I, e = (long)blockIdx.x * EL + el, sl = (long)NT * OP * IP;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (e < total) {
         const int i = (int)(e % I);
         const long r = e / I;
         const int o = (int)(r % O), t = (int)(r / O);
-        const long src = ((long)t * OP + o) * IP + i, sl = (long)NT * OP * IP;
-        float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += part[k * sl + src];
-        dw[e] = s;
+        const float* pe = part + ((long)t * OP + o) * IP + i;
+        int k = g;
+        for (; k + 3 * G < slices; k += 4 * G) {
+            v0 += pe[k * sl]; v1 += pe[(k + G) * sl]; v2 += pe[(k + 2 * G) * sl]; v3 += pe[(k + 3 * G) * sl];
+        }
+        for (; k < slices; k += G) v0 += pe[k * sl];
     }
+    float v = (v0 + v1) + (v2 + v3);
+    if (G > 1) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (g == 0)
+            for (int k = 1; k < G; ++k) v += red[k * EL + el];
+    }
+    if (g == 0 && e < total) dw[e] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -655,6 +673,128 @@ __global__ __launch_bounds__(256) void fir_same_f16_kernel(const UfdH p) {
                 *(h8*)(p.y + ((((long)n * p.OH + oy0 + b) * p.OW + ox0 + a) * p.C) + c8 * 8) = out;
             }
         }
+    }
+}
+
+// Same-size 4x4 FIR, marching: a lane owns TWO adjacent output columns x 8 channels and walks down `rows` output rows.  Per input row it loads
+// 5 pixels (2.5 sixteen-byte loads per output piece instead of 4.4), forms the two horizontal 4-tap sums in fp32 and keeps the last four of them in
+// registers; an output row is the vertical 4-tap sum of that ring -- 8 multiply-adds per output value instead of 16, written on float2 so that the
+// compiler emits packed fp32 math.  The 4x4 filter of the model is an outer product (upfirdn2d.setup_filter of [1,3,3,1]); every thread factors the
+// taps itself (pivot row / column) and a filter that is NOT rank one takes the plain 16-tap loop below, same launch.  Column masks are folded into the
+// horizontal coefficients once per lane, out-of-range rows are loaded from a clamped address and multiplied by zero.  The 2 x 4-output
+// lanes of fir_same_f16_kernel spent 206 VALU operations per output piece (105 us of pure issue at 64 ch x 513^2 x 8) and ran at 2.3 TB/s.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void fir4_march_f16_kernel(const UfdH p, int rows) {
+    const int c8n = p.C >> 3, oxg = (p.OW + 1) >> 1, nstrip = (p.OH + rows - 1) / rows;
+    const unsigned total = (unsigned)p.N * nstrip * oxg * c8n;
+    unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= total) return;
+    const int c8 = e % c8n;
+    e /= c8n;
+    const int ox0 = (e % oxg) * 2;
+    e /= oxg;
+    const int oy0 = (e % nstrip) * rows, n = e / nstrip;
+    // taps as the gather form uses them: output (oy, ox) = sum_k t[ky][kx] * x[oy + ky - py0][ox + kx - px0]
+    float t[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) t[ky][kx] = p.f[(p.flip ? ky : 3 - ky) * 4 + (p.flip ? kx : 3 - kx)] * p.gain;
+    int pky = 0, pkx = 0;
+    float piv = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+            if (fabsf(t[ky][kx]) > fabsf(piv)) { piv = t[ky][kx]; pky = ky; pkx = kx; }
+    float fr[4], fc[4];
+    bool sep = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { fr[k] = t[pky][k]; fc[k] = piv != 0.f ? t[k][pkx] / piv : 0.f; }
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) sep = sep && fabsf(t[ky][kx] - fc[ky] * fr[kx]) <= 1e-6f * fabsf(piv);
+    const _Float16* xb = p.x + (long)n * p.H * p.W * p.C + c8 * 8;
+    _Float16* yb = p.y + (long)n * p.OH * p.OW * p.C + c8 * 8;
+    if (!sep) {                                                     // not an outer product: 16 guarded taps per output
+        for (int oy = oy0; oy < oy0 + rows && oy < p.OH; ++oy)
+            for (int a = 0; a < 2 && ox0 + a < p.OW; ++a) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int ky = 0; ky < 4; ++ky)
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int iy = oy + ky - p.py0, ix = ox0 + a + kx - p.px0;
+                        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+                        const h8 xv = *(const h8*)(xb + ((long)iy * p.W + ix) * p.C);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q] += (float)xv[q] * t[ky][kx];
+                    }
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = (_Float16)acc[q];
+                *(h8*)(yb + ((long)oy * p.OW + ox0 + a) * p.C) = o;
+            }
+        return;
+    }
+    float cx[2][4];
+    int ixc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int ix = ox0 + j - p.px0;
+        ixc[j] = (ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix)) * p.C;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ix = ox0 + a + k - p.px0;
+            cx[a][k] = (ix >= 0 && ix < p.W) ? fr[k] : 0.f;
+        }
+    f2 h[4][2][4];                                                  // ring of horizontal sums: [input row & 3][column][channel pair]
+    auto step = [&](int rr, auto SLOT) __attribute__((always_inline)) {
+        constexpr int S = decltype(SLOT)::value;
+        const int iy = oy0 + rr - p.py0;
+        const float my = (iy >= 0 && iy < p.H) ? 1.f : 0.f;
+        const _Float16* row = xb + (long)(iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy)) * p.W * p.C;
+        h8 xv[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) xv[j] = *(const h8*)(row + ixc[j]);
+        f2 xf[5][4];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hh2 v = {xv[j][2 * q], xv[j][2 * q + 1]}; xf[j][q] = __builtin_convertvector(v, f2); }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f2 sum = xf[a][q] * cx[a][0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) sum += xf[a + k][q] * cx[a][k];
+                h[S][a][q] = sum * my;
+            }
+        const int oy = oy0 + rr - 3;                                // rows oy - py0 + 0..3 = ring slots S+1, S+2, S+3, S
+        if (rr >= 3 && oy < p.OH) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f2 v = h[(S + 1) & 3][a][q] * fc[0] + h[(S + 2) & 3][a][q] * fc[1] + h[(S + 3) & 3][a][q] * fc[2] + h[S][a][q] * fc[3];
+                    const hh2 r = __builtin_convertvector(v, hh2);
+                    o[2 * q] = r[0]; o[2 * q + 1] = r[1];
+                }
+                if (ox0 + a < p.OW) *(h8*)(yb + ((long)oy * p.OW + ox0 + a) * p.C) = o;
+            }
+        }
+    };
+    for (int rb = 0; rb < rows + 3; rb += 4) {                      // rows % 4 == 0: the last group has three steps
+        step(rb, std::integral_constant<int, 0>{});
+        step(rb + 1, std::integral_constant<int, 1>{});
+        step(rb + 2, std::integral_constant<int, 2>{});
+        if (rb + 3 < rows + 3) step(rb + 3, std::integral_constant<int, 3>{});
     }
 }
 
@@ -1030,8 +1170,17 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     else hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<1, 1>), grid, dim3(256), lds, st, p);
     SHG_CHECK_LAUNCH();
     const long total = (long)k * k * O * I;
-    hipLaunchKernelGGL(f16::wgrad_reduce_kernel, dim3(shg_cdiv(total, 256) > 2048 ? 2048 : shg_cdiv(total, 256)), dim3(256), 0, st,
-                       (const float*)workspace, dw, p.slices, k * k, O, I, p.OP, p.IP);
+    int G = 1;
+    while (G < 16 && (total + 256 / G - 1) / (256 / G) < 2048 && p.slices >= 8 * G) G *= 2;
+    const dim3 rgrid((unsigned)((total + 256 / G - 1) / (256 / G)));
+    const float* part = (const float*)workspace;
+    switch (G) {
+        case 1: hipLaunchKernelGGL(f16::wgrad_reduce_kernel<1>, rgrid, dim3(256), 0, st, part, dw, p.slices, k * k, O, I, p.OP, p.IP); break;
+        case 2: hipLaunchKernelGGL(f16::wgrad_reduce_kernel<2>, rgrid, dim3(256), 0, st, part, dw, p.slices, k * k, O, I, p.OP, p.IP); break;
+        case 4: hipLaunchKernelGGL(f16::wgrad_reduce_kernel<4>, rgrid, dim3(256), 0, st, part, dw, p.slices, k * k, O, I, p.OP, p.IP); break;
+        case 8: hipLaunchKernelGGL(f16::wgrad_reduce_kernel<8>, rgrid, dim3(256), 0, st, part, dw, p.slices, k * k, O, I, p.OP, p.IP); break;
+        default: hipLaunchKernelGGL(f16::wgrad_reduce_kernel<16>, rgrid, dim3(256), 0, st, part, dw, p.slices, k * k, O, I, p.OP, p.IP); break;
+    }
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
@@ -1050,7 +1199,14 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
     const long total = same ? (long)N * ((OH + rb - 1) / rb) * ((OW + 3) / 4) * (C / 8) : (long)N * OH * OW * (C / 8);
     int grid = shg_cdiv(total, 256);
     if (grid > 256 * 32) grid = 256 * 32;
-    if (same && fh == 4 && fw == 4) hipLaunchKernelGGL((f16::fir_same_f16_kernel<4, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (same && fh == 4 && fw == 4 && !getenv("SHG_F16_FIR_OLD")) {
+        // marching strips: the longest of 32 / 16 / 8 / 4 rows that still leaves >= 8 workgroups per CU
+        int rows = 32;
+        auto lanes = [&](int r) { return (long)N * ((OH + r - 1) / r) * ((OW + 1) / 2) * (C / 8); };
+        while (rows > 4 && lanes(rows) < 256L * 256 * 8) rows /= 2;
+        SHG_CHECK_ARG(lanes(rows) < (1L << 31), "upfirdn2d_f16: tensor too large");
+        hipLaunchKernelGGL(f16::fir4_march_f16_kernel, dim3((unsigned)shg_cdiv(lanes(rows), 256)), dim3(256), 0, (hipStream_t)stream, p, rows);
+    } else if (same && fh == 4 && fw == 4) hipLaunchKernelGGL((f16::fir_same_f16_kernel<4, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else if (same) hipLaunchKernelGGL((f16::fir_same_f16_kernel<0, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(f16::upfirdn2d_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();

@@ -277,12 +277,45 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradPa
         }
 }
 
+// G slice groups per workgroup (256 / G elements each): thread (g, el) sums slices g, g + G, ... of its element in four interleaved
+// accumulators, the groups are added in group order through LDS -- a fixed order for a given shape (deterministic).  One thread per element
+// over ALL slices left a 64-channel layer (36 864 weights x 1 024 slices = 151 MB) to 144 workgroups of serial strided loads.
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, long n, int nslice) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float v = 0.f;
-    for (int s = 0; s < nslice; ++s) v += part[(long)s * n + e];
-    dw[e] = v;
+    __shared__ float red[256];
+    constexpr int EL = 256 / G;
+    const int el = threadIdx.x % EL, g = threadIdx.x / EL;
+    const long e = (long)blockIdx.x * EL + el;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (e < n) {
+        const float* pe = part + e;
+        int sl = g;
+        for (; sl + 3 * G < nslice; sl += 4 * G) {
+            v0 += pe[(long)sl * n]; v1 += pe[(long)(sl + G) * n]; v2 += pe[(long)(sl + 2 * G) * n]; v3 += pe[(long)(sl + 3 * G) * n];
+        }
+        for (; sl < nslice; sl += G) v0 += pe[(long)sl * n];
+    }
+    float v = (v0 + v1) + (v2 + v3);
+    if (G > 1) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (g == 0)
+            for (int k = 1; k < G; ++k) v += red[k * EL + el];
+    }
+    if (g == 0 && e < n) dw[e] = v;
+}
+
+static void launch_wgrad_reduce(const float* part, float* dw, long n, int nslice, hipStream_t s) {
+    int G = 1;
+    while (G < 16 && (n + 256 / G - 1) / (256 / G) < 2048 && nslice >= 8 * G) G *= 2;
+    const dim3 grid((unsigned)((n + 256 / G - 1) / (256 / G)));
+    switch (G) {
+        case 1: hipLaunchKernelGGL(wgrad_reduce_kernel<1>, grid, dim3(256), 0, s, part, dw, n, nslice); break;
+        case 2: hipLaunchKernelGGL(wgrad_reduce_kernel<2>, grid, dim3(256), 0, s, part, dw, n, nslice); break;
+        case 4: hipLaunchKernelGGL(wgrad_reduce_kernel<4>, grid, dim3(256), 0, s, part, dw, n, nslice); break;
+        case 8: hipLaunchKernelGGL(wgrad_reduce_kernel<8>, grid, dim3(256), 0, s, part, dw, n, nslice); break;
+        default: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, grid, dim3(256), 0, s, part, dw, n, nslice); break;
+    }
 }
 
 // small-image form: 3x3, OW a power of two of at most a quarter of a chunk (whole rows per chunk), x rows fully inside the window
@@ -343,7 +376,7 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     SHG_CHECK_LAUNCH();
     if (p.nslice > 1) {
         const long n = (long)O * I * kh * kw;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(shg_cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nslice);
+        launch_wgrad_reduce((const float*)workspace, dw, n, p.nslice, s);
         SHG_CHECK_LAUNCH();
     }
     return SHG_OK;

@@ -60,6 +60,31 @@ def test_upfirdn2d_halves_vs_reference(g):
         assert rel_err(c(y), g[k + 'y32']) < 1e-3 and rel_err(c(y), g[k + 'y16'].astype(np.float32)) < 2e-3, name
 
 
+def test_same_size_fir_marching_kernel_vs_float64():
+    """fir4_march_f16_kernel (same-size 4x4 filter): outer-product filters take the separable marching path, any other 4x4 filter the 16-tap
+    loop of the same launch; paddings incl. crops, flipped / asymmetric filters, gains, odd extents, 8...264 channels, every strip length."""
+    from shgan_amd import kernels_f16 as kf
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(7)
+    f1 = torch.tensor([1., 3., 3., 1.])
+    cases = [(2, 64, 37, 53, (2, 1, 2, 1), torch.outer(f1, f1) / 64, False, 1.0), (1, 8, 5, 4, (2, 1, 1, 2), torch.outer(f1, f1) / 64, False, 4.0),
+             (3, 264, 19, 18, (3, 0, 0, 3), torch.outer(torch.tensor([1., 2., -1., 0.5]), torch.tensor([0.25, 1., 3., -2.])), True, 0.7),
+             (1, 16, 130, 131, (1, 2, 2, 1), torch.outer(torch.tensor([1., 2., -1., 0.5]), torch.tensor([0.25, 1., 3., -2.])), False, 1.0),
+             (2, 32, 40, 33, (2, 2, 2, 2), torch.randn(4, 4, generator=gen), False, 1.3), (2, 32, 9, 70, (4, 1, -1, 3), torch.randn(4, 4, generator=gen), True, 1.0),
+             (8, 64, 65, 65, (2, 2, 2, 2), torch.outer(f1, f1) / 64, False, 1.0), (1, 128, 257, 129, (2, 1, 2, 1), torch.outer(f1, f1) / 16, True, 1.0)]
+    for n, ch, h, w, (px0, px1, py0, py1), f, flip, gain in cases:
+        x = torch.randn(n, ch, h, w, generator=gen).half()
+        y = kf.upfirdn2d(x.to(DEV).to(memory_format=CL), f.to(DEV), padx0=px0, padx1=px1, pady0=py0, pady1=py1, flip=flip, gain=gain)
+        xd = x.double()
+        xd = F.pad(xd, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+        xd = xd[:, :, max(-py0, 0): xd.shape[2] - max(-py1, 0), max(-px0, 0): xd.shape[3] - max(-px1, 0)]
+        fk = (f if flip else f.flip([0, 1])).double() * gain
+        ref = F.conv2d(xd, fk[None, None].repeat(ch, 1, 1, 1), groups=ch)
+        assert tuple(y.shape) == tuple(ref.shape) and y.dtype == torch.float16
+        e = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e < 6e-4, ((n, ch, h, w), e)                       # one half rounding of an fp32-accumulated sum
+
+
 def test_modulated_conv2d_halves_with_prenormalisation_vs_reference(g):
     from shgan_amd.model_zoo import stylegan
     f4 = torch.from_numpy(g['f']).to(DEV)

@@ -3,6 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import shgan_amd
+from shgan_amd import _lib
+if os.environ.get('SHG_VARIANT'):
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import kernels as kk
 N = 8
 CASES = [('3x3 s1 64ch 512^2', 64, 64, 512, 3, 1, 1), ('3x3 s1 128ch 256^2', 128, 128, 256, 3, 1, 1), ('3x3 s1 256ch 128^2', 256, 256, 128, 3, 1, 1),
