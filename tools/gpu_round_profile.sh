@@ -36,4 +36,6 @@ python tools/conv_f16_bench.py > $OUT/${TAG}_conv_f16_bench.txt 2>/dev/null
 python tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>/dev/null
 python tools/conv_bench_down.py > $OUT/${TAG}_conv_bench_down.txt 2>/dev/null
 python tools/fir_bench.py > $OUT/${TAG}_fir_bench.txt 2>/dev/null
+python tools/wgrad_bench.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_wgrad_bench.txt
+python tools/pointwise_bench.py 2>/dev/null | grep '^\[' > $OUT/${TAG}_pointwise_bench.txt
 cat $OUT/${TAG}_summary.txt; head -c 300 $OUT/${TAG}_bench512x16.json.log; echo; head -c 300 $OUT/${TAG}_bench256x32.json.log
