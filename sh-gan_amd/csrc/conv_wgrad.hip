@@ -328,9 +328,13 @@ static bool wgrad_packed(int OW, int W, int kh, int stride, int pad) {
 static int wgrad_slices(int NB, int I, int O, int OH, int OW, int taps) {
     const long tiles = (long)shg_cdiv(I, 64) * shg_cdiv(O, 64);
     const long nchunk = (long)NB * OH * shg_cdiv(OW, 32);
-    long s = (4 * 256 + tiles - 1) / tiles;                      // about four workgroups per CU (two resident at a time)
+    // 3x3: ONE workgroup per CU in ONE round (238 registers x 512 threads: a CU holds one) -- 256 / 512 / 768 / 1024 workgroups measured
+    // 86 / 83 / 80 / 78 TFLOP/s at 64 channels x 512^2 and 34 / 29 / 25 / 23 at 512 channels x 16^2 (every further round re-pays prologue,
+    // epilogue and 147 KB of partial sums per workgroup); the thin 1x1 layers are load-bound and want more workgroups in flight
+    long s = ((taps > 1 ? 256 : 4 * 256) + tiles - 1) / tiles;
     const long per_slice = (long)O * I * taps * (long)sizeof(float);
     const long cap = (256L << 20) / per_slice;                   // at most 256 MB of partial sums
+    if (const char* e = getenv("SHG_WGRAD_WGS")) s = (atol(e) + tiles - 1) / tiles;       // study switch: workgroups in total
     if (s > cap) s = cap;
     if (s > nchunk) s = nchunk;
     if (s > 1024) s = 1024;
