@@ -1132,14 +1132,20 @@ extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW
     return (crop + OH > 2 * H + 1 || crop + OW > 2 * W + 1) ? 1 : 0;
 }
 
+// pixel slices of the fp16 weight gradient: workgroups in total / (64 x 64 tiles)
+// (measured at 256 / 512 / 768 / 1024 workgroups: 3x3 stride 1 best at 512 = two resident per CU in one round, 467 / 531 / 467 / 478 TFLOP/s at
+// 64 channels; stride 2 at 256: 376 / 346 / 314 / 294; the load-bound 1x1 layers at 1024: 126 / 211 / 237 / 253 at 512 channels)
+static long wgrad_f16_slices(long tiles, long nblocks, long wgs) {
+    if (const char* e = getenv("SHG_WGRAD16_WGS")) wgs = atol(e);       // study switch
+    long slices = (wgs + tiles - 1) / tiles;
+    if (slices > nblocks) slices = nblocks;
+    return slices < 1 ? 1 : slices;
+}
+
 extern "C" size_t shg_conv2d_wgrad_f16_workspace_bytes(int N, int I, int O, int OH, int OW, int k) {
     const int OP = (O + 63) / 64 * 64, IP = (I + 63) / 64 * 64;
     const long nblocks = (long)N * shg_cdiv(OH, f16::WR) * shg_cdiv(OW, f16::WC);
-    const long tiles = (long)(OP / 64) * (IP / 64);
-    long slices = (512 + tiles - 1) / tiles;
-    if (slices > nblocks) slices = nblocks;
-    if (slices < 1) slices = 1;
-    return (size_t)slices * k * k * OP * IP * sizeof(float);
+    return (size_t)wgrad_f16_slices((long)(OP / 64) * (IP / 64), nblocks, k == 1 ? 1024 : 512) * k * k * OP * IP * sizeof(float);
 }
 
 // dw [k*k][O][I] fp32 = sum_{n,oy,ox} g[n,oy,ox,o] x[n, oy*stride - pad + ky, ox*stride - pad + kx, i]; x [N,H,W,I], g [N,OH,OW,O] halves
@@ -1157,8 +1163,7 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     p.by = shg_cdiv(OH, f16::WR); p.bx = shg_cdiv(OW, f16::WC);
     p.nblocks = (long)N * p.by * p.bx;
     const long tiles = (long)(p.OP / 64) * (p.IP / 64);
-    long slices = (512 + tiles - 1) / tiles;            // ~2 workgroups per CU; more slices only lengthen the reduction
-    if (slices > p.nblocks) slices = p.nblocks;
+    const long slices = wgrad_f16_slices(tiles, p.nblocks, k == 1 ? 1024 : (stride == 2 ? 256 : 512));
     p.slices = (int)slices;
     SHG_CHECK_ARG(!(k == 1 && stride == 2), "conv2d_wgrad_f16: 1x1 stride-2 (the forward decimates with upfirdn2d first)");
     p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
