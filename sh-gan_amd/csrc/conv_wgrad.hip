@@ -186,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradPa
     const int per = (p.nchunk + p.nslice - 1) / p.nslice;
     const int c_begin = slice * per, c_end = min(p.nchunk, c_begin + per);
     const int lw = 31 - __builtin_clz(p.OW), R = PX >> lw;      // log2 OW, output rows per chunk
+    const int lr = 31 - __builtin_clz(R), loh = 31 - __builtin_clz(p.OH);      // (host: OH a power of two)
     const int XWs = p.OW * S + KW - 1;                           // window columns
     const int lxp = 32 - __builtin_clz(XWs - 1);                 // log2 of the padded pitch used for indexing
     const int WR = R * KH;                                       // window rows per chunk
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradPa
         __syncthreads();
         {   // g: pixel gpx of the chunk = (row c*R + gpx / OW, column gpx % OW)
             const int row = c * R + (gpx >> lw), cx = gpx & (p.OW - 1);
-            const int n = row / p.OH, oy = row - n * p.OH;
+            const int n = row >> loh, oy = row & (p.OH - 1);
             const bool pok = row < rows_total;
             const float* gp = p.g + ((long)(pok ? n : 0) * p.O + o0) * gplane + (long)(pok ? oy : 0) * p.OW + cx;
 #pragma unroll
@@ -221,12 +222,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_packed_kernel(const WgradPa
             int dst[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                // element = ((channel, row in chunk), window row, column): R, OH and the padded pitch are powers of two, KH a constant --
+                // shifts and one division by a constant (the decode with runtime divisions by WR and OH cost more issue slots than the MFMAs)
                 const int e = e0 + tid + 512 * j;
                 const int col = e & ((1 << lxp) - 1), t = e >> lxp;
-                const int ch = t / WR, wr = t - ch * WR;
-                const int rr = wr / KH, ty = wr - rr * KH;
+                const int q = t / KH, ty = t - q * KH;
+                const int rr = q & (R - 1), ch = q >> lr, wr = rr * KH + ty;
                 const int row = c * R + rr;
-                const int n = row / p.OH, oy = row - n * p.OH;
+                const int n = row >> loh, oy = row & (p.OH - 1);
                 const int iy = oy * S - p.pad + ty, ix = col - p.pad;
                 const bool inwin = e < NE && col < XWs;
                 const bool ok = inwin && row < rows_total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && i0 + ch < p.I;
@@ -319,10 +322,10 @@ static void launch_wgrad_reduce(const float* part, float* dw, long n, int nslice
 }
 
 // small-image form: 3x3, OW a power of two of at most a quarter of a chunk (whole rows per chunk), x rows fully inside the window
-static bool wgrad_packed(int OW, int W, int kh, int stride, int pad) {
+static bool wgrad_packed(int OW, int OH, int W, int kh, int stride, int pad) {
     const int PX = stride == 1 ? 64 : 32;
     // (rows of half a chunk stay on the row-piece kernel: 990 vs 1039 us at 512 channels, 32^2)
-    return kh == 3 && OW >= 4 && OW <= PX / 4 && (OW & (OW - 1)) == 0 && W <= OW * stride + 2 && pad <= 2;
+    return kh == 3 && OW >= 4 && OW <= PX / 4 && (OW & (OW - 1)) == 0 && (OH & (OH - 1)) == 0 && W <= OW * stride + 2 && pad <= 2;
 }
 
 static int wgrad_slices(int NB, int I, int O, int OH, int OW, int taps) {
@@ -359,7 +362,7 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
                   "conv2d_wgrad: output extent does not match x, stride and padding");
     WgradParams p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
-    const bool packed = wgrad_packed(OW, W, kh, stride, pad);
+    const bool packed = wgrad_packed(OW, OH, W, kh, stride, pad);
     const bool two_rows = !packed && kh == 3 && stride == 1 && OW == 32 && (OH % 2) == 0 && W == 32 + 2 - 2 * pad;      // 32-pixel rows: two per chunk
     p.chunks_x = shg_cdiv(OW, stride == 1 ? 64 : 32);
     p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : (two_rows ? NB * (OH / 2) : NB * OH * p.chunks_x);
