@@ -32,14 +32,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(16))) float shg_wino4_zeros[64];
 
 #ifdef SHG_W4_TRACE
+#ifndef SHG_W4_TRACE_WG
+#define SHG_W4_TRACE_WG 0          // which workgroup records (a late one shows the steady state, 0 the synchronised first round)
+#endif
 // timeline study (tools/w4_variant.sh trace -DSHG_W4_TRACE=1): workgroup 0 records clock64() at six points of chunks 8..15
 __device__ long long shg_wino4_trace_buf[8 * 8 * 8];
 extern "C" int shg_wino4_trace_read(long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shg_wino4_trace_buf), sizeof(shg_wino4_trace_buf));
 }
-#define W4_TRACE(slot) do { if (blockIdx.x == 0 && c >= SHG_W4_TRACE - 1 && c < SHG_W4_TRACE + 6 && lane == 0) shg_wino4_trace_buf[(wave * 8 + (c - (SHG_W4_TRACE - 1))) * 8 + (slot)] = clock64(); } while (0)
-#define W4_TRACE_T(slot) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[((threadIdx.x >> 6) * 8 + 7) * 8 + (slot)] = clock64(); } while (0)
-#define W4_TRACE_E(slot) do { if (SHG_W4_TRACE == 100 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[(threadIdx.x >> 6) * 64 + (slot)] = clock64(); } while (0)
+#define W4_TRACE(slot) do { if (blockIdx.x == SHG_W4_TRACE_WG && c >= SHG_W4_TRACE - 1 && c < SHG_W4_TRACE + 6 && lane == 0) shg_wino4_trace_buf[(wave * 8 + (c - (SHG_W4_TRACE - 1))) * 8 + (slot)] = clock64(); } while (0)
+#define W4_TRACE_T(slot) do { if (blockIdx.x == SHG_W4_TRACE_WG && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[((threadIdx.x >> 6) * 8 + 7) * 8 + (slot)] = clock64(); } while (0)
+#define W4_TRACE_E(slot) do { if (SHG_W4_TRACE == 100 && blockIdx.x == SHG_W4_TRACE_WG && (threadIdx.x & 63) == 0) shg_wino4_trace_buf[(threadIdx.x >> 6) * 64 + (slot)] = clock64(); } while (0)
 #else
 #define W4_TRACE(slot) do { } while (0)
 #define W4_TRACE_T(slot) do { } while (0)
