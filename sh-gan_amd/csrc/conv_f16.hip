@@ -385,7 +385,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //                                                        kx = 0 / 2 from the even half (aligned / shifted by one), kx = 1 from the odd half.
 // Channel pitches (144 / 304 / 880 / 208 bytes) put the 16 lanes of a b128 group on 16 different 16-byte slots: conflict-free.
 template <int K, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_f16_kernel(const WgradP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_f16_kernel(const WgradP p) {
     constexpr int NT = K * K;
     constexpr int XR = (WR - 1) * S + K, XC = (WC - 1) * S + K, RP = S == 1 ? 24 : 48, GP = WR * WC + 8, XP = XR * RP + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
@@ -1133,8 +1133,9 @@ extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW
 }
 
 // pixel slices of the fp16 weight gradient: workgroups in total / (64 x 64 tiles)
-// (measured at 256 / 512 / 768 / 1024 workgroups: 3x3 stride 1 best at 512 = two resident per CU in one round, 467 / 531 / 467 / 478 TFLOP/s at
-// 64 channels; stride 2 at 256: 376 / 346 / 314 / 294; the load-bound 1x1 layers at 1024: 126 / 211 / 237 / 253 at 512 channels)
+// (measured at 256 / 512 / 768 / 1024 workgroups: 3x3 best at 512 = two resident per CU in one round, 467 / 531 / 467 / 478 TFLOP/s at 64 channels
+// stride 1, 372 / 449 / 381 at stride 2 -- whose 260-register build held ONE workgroup per CU (346 TFLOP/s) until amdgpu_waves_per_eu(2) brought it to
+// 255 without spills; the load-bound 1x1 layers at 1024: 126 / 211 / 237 / 253 at 512 channels)
 static long wgrad_f16_slices(long tiles, long nblocks, long wgs) {
     if (const char* e = getenv("SHG_WGRAD16_WGS")) wgs = atol(e);       // study switch
     long slices = (wgs + tiles - 1) / tiles;
@@ -1163,7 +1164,7 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     p.by = shg_cdiv(OH, f16::WR); p.bx = shg_cdiv(OW, f16::WC);
     p.nblocks = (long)N * p.by * p.bx;
     const long tiles = (long)(p.OP / 64) * (p.IP / 64);
-    const long slices = wgrad_f16_slices(tiles, p.nblocks, k == 1 ? 1024 : (stride == 2 ? 256 : 512));
+    const long slices = wgrad_f16_slices(tiles, p.nblocks, k == 1 ? 1024 : 512);
     p.slices = (int)slices;
     SHG_CHECK_ARG(!(k == 1 && stride == 2), "conv2d_wgrad_f16: 1x1 stride-2 (the forward decimates with upfirdn2d first)");
     p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
