@@ -80,7 +80,7 @@ struct ConvP {
 };
 
 template <int MB, int NT, int NB, bool WLDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NT < 9 && MB == 2 && NB == 2) ? 3 : 1))) void conv_f16_kernel(const ConvP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB == 2 && NB == 2 && !WLDS) ? 3 : 1))) void conv_f16_kernel(const ConvP p) {
     // tile = TH x (16 NB) output pixels: wave w owns rows 2w, 2w+1; with NB = 1 its 32 lanes-of-a-block are 2 rows x 16 columns, with
     // NB = 2 block nb is row 2w + nb and the lanes are its 32 columns -- every weight operand then feeds two MFMAs
     extern __shared__ __attribute__((aligned(16))) _Float16 patch[];
