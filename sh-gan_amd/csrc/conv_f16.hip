@@ -570,6 +570,75 @@ __global__ __launch_bounds__(256) void upfirdn2d_f16_kernel(const UfdH p) {
 // up = down = 1 (the pad-2 pre-filter of the stride-2 layers, the pad-1 post-filter of the transposed convolutions and both their
 // gradients -- all but the x2 resampling of the skip paths): a lane produces 2 x 4 adjacent pixels x 8 channels, so that each loaded
 // input vector feeds up to 2 x 4 outputs (35 loads per 8 outputs of a 4x4 filter instead of 16 each) and nothing is divided.
+// 4x4 filter with up = 2 or down = 2 (the skip branches of the half blocks and their gradients): the factors are compile-time constants (the generic
+// kernel above divides by run-time up / down factors per tap and waits for every guarded load), every load is issued unconditionally from a clamped
+// address and masked afterwards -- 16 loads per output for down = 2, the 4 taps that hit a real sample for up = 2.
+template <int UP, int DN>
+__global__ __launch_bounds__(256) void updn4_f16_kernel(const UfdH p) {
+    static_assert((UP == 1 && DN == 2) || (UP == 2 && DN == 1), "one factor of two");
+    __shared__ float sf[16];
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        sf[threadIdx.x] = p.f[(p.flip ? ky : 3 - ky) * 4 + (p.flip ? kx : 3 - kx)] * p.gain;
+    }
+    __syncthreads();
+    const unsigned c8n = p.C >> 3, total = (unsigned)p.N * p.OH * p.OW * c8n;                  // (host: < 2^31)
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned c8 = e % c8n;
+        unsigned r = e / c8n;
+        const int ox = r % p.OW;
+        r /= p.OW;
+        const int oy = r % p.OH, n = r / p.OH;
+        const _Float16* xb = p.x + (long)n * p.H * p.W * p.C + c8 * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (DN == 2) {
+            h8 xin[4][4];
+            float m[4][4];
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int iy = oy * 2 + ky - p.py0, iyc = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ix = ox * 2 + kx - p.px0, ixc = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+                    xin[ky][kx] = *(const h8*)(xb + ((long)iyc * p.W + ixc) * p.C);
+                    m[ky][kx] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? sf[ky * 4 + kx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += (float)xin[ky][kx][q] * m[ky][kx];
+        } else {
+            // sample (oy + ky - py0) / 2 exists for the two ky of the right parity
+            const int ky0 = (p.py0 - oy) & 1, kx0 = (p.px0 - ox) & 1;
+            h8 xin[2][2];
+            float m[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int ky = ky0 + 2 * a, uy = oy + ky - p.py0, iy = uy >> 1, iyc = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int kx = kx0 + 2 * b, ux = ox + kx - p.px0, ix = ux >> 1, ixc = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+                    xin[a][b] = *(const h8*)(xb + ((long)iyc * p.W + ixc) * p.C);
+                    m[a][b] = (uy >= 0 && iy < p.H && ux >= 0 && ix < p.W) ? sf[ky * 4 + kx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += (float)xin[a][b][q] * m[a][b];
+        }
+        h8 out;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[q] = (_Float16)v[q];
+        *(h8*)(p.y + (long)e * 8) = out;
+    }
+}
+
 template <int FS, int RB>  // FS = 4: the 4x4 filter, fully unrolled with unconditional (clamped) loads; FS = 0: any size, guarded loop; RB output rows per lane
 __global__ __launch_bounds__(256) void fir_same_f16_kernel(const UfdH p) {
     __shared__ float sf[64];
@@ -1214,6 +1283,10 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
         hipLaunchKernelGGL(f16::fir4_march_f16_kernel, dim3((unsigned)shg_cdiv(lanes(rows), 256)), dim3(256), 0, (hipStream_t)stream, p, rows);
     } else if (same && fh == 4 && fw == 4) hipLaunchKernelGGL((f16::fir_same_f16_kernel<4, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else if (same) hipLaunchKernelGGL((f16::fir_same_f16_kernel<0, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (fh == 4 && fw == 4 && upx == 1 && upy == 1 && downx == 2 && downy == 2 && total < (1L << 31))
+        hipLaunchKernelGGL((f16::updn4_f16_kernel<1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (fh == 4 && fw == 4 && upx == 2 && upy == 2 && downx == 1 && downy == 1 && total < (1L << 31))
+        hipLaunchKernelGGL((f16::updn4_f16_kernel<2, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(f16::upfirdn2d_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;

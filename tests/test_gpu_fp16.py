@@ -85,6 +85,27 @@ def test_same_size_fir_marching_kernel_vs_float64():
         assert e < 6e-4, ((n, ch, h, w), e)                       # one half rounding of an fp32-accumulated sum
 
 
+def test_up2_down2_fir_kernels_vs_oracle():
+    """updn4_f16_kernel<1,2> / <2,1> (4x4 filter, down = 2 or up = 2: the skip branches of the half blocks and their gradients) against the CPU
+    oracle's upfirdn2d on the same half inputs: odd extents, every padding incl. crops, flipped asymmetric filters, gains."""
+    from oracle import shgan_oracle as orc
+    from shgan_amd import kernels_f16 as kf
+    gen = torch.Generator().manual_seed(11)
+    f1 = torch.tensor([1., 3., 3., 1.])
+    fa = torch.outer(torch.tensor([1., 2., -1., 0.5]), torch.tensor([0.25, 1., 3., -2.]))
+    for n, ch, h, w, up, down, pad, f, flip, gain in [
+            (2, 64, 32, 32, 1, 2, (1, 1, 1, 1), torch.outer(f1, f1) / 64, False, 1.0), (2, 64, 16, 16, 2, 1, (2, 1, 2, 1), torch.outer(f1, f1) / 64, False, 4.0),
+            (1, 8, 7, 9, 1, 2, (2, 0, 1, 3), fa, True, 0.6), (1, 8, 7, 9, 2, 1, (3, 2, 0, 1), fa, True, 1.7), (3, 264, 13, 6, 1, 2, (0, 3, 3, 0), fa, False, 1.0),
+            (3, 264, 5, 11, 2, 1, (1, 1, 2, 2), torch.randn(4, 4, generator=gen), False, 1.0), (2, 16, 33, 20, 1, 2, (1, -1, -1, 2), fa, False, 1.0),
+            (2, 16, 12, 17, 2, 1, (-1, 2, 3, -2), torch.randn(4, 4, generator=gen), True, 2.0)]:
+        x = torch.randn(n, ch, h, w, generator=gen).half()
+        ref = orc.upfirdn2d(x.float(), f, up=up, down=down, padding=list(pad), flip_filter=flip, gain=gain)
+        y = kf.upfirdn2d(x.to(DEV).to(memory_format=CL), f.to(DEV), up, up, down, down, pad[0], pad[1], pad[2], pad[3], flip, gain)
+        assert tuple(y.shape) == tuple(ref.shape) and y.dtype == torch.float16, (up, down, pad)
+        e = float((y.cpu().float() - ref).abs().max() / ref.abs().max())
+        assert e < 6e-4, ((n, ch, h, w, up, down, pad), e)
+
+
 def test_modulated_conv2d_halves_with_prenormalisation_vs_reference(g):
     from shgan_amd.model_zoo import stylegan
     f4 = torch.from_numpy(g['f']).to(DEV)

@@ -53,6 +53,13 @@ f = torch.tensor([1., 3., 3., 1.], device=dev)
 f = torch.outer(f, f) / 64
 t = timeit(lambda: kf.upfirdn2d(x, f, padx0=2, padx1=2, pady0=2, pady1=2))
 print(f'upfirdn2d pad2 64ch 513^2: {t:8.1f} us {2.0 * 2 * x.numel() / t / 1e3:7.1f} GB/s')
+for (c, r) in [(64, 512), (128, 256)]:
+    xx = torch.randn(N, c, r, r, device=dev).half().to(memory_format=CL)
+    t = timeit(lambda: kf.upfirdn2d(xx, f, downx=2, downy=2, padx0=1, padx1=1, pady0=1, pady1=1))
+    print(f'upfirdn2d down 2 {c}ch {r}^2: {t:8.1f} us {2.0 * 1.25 * xx.numel() / t / 1e3:7.1f} GB/s')
+    xh = xx[:, :, ::2, ::2].contiguous(memory_format=CL)
+    t = timeit(lambda: kf.upfirdn2d(xh, f, upx=2, upy=2, padx0=2, padx1=1, pady0=2, pady1=1, gain=4.0))
+    print(f'upfirdn2d up 2 {c}ch {r // 2}^2: {t:8.1f} us {2.0 * 5 * xh.numel() / t / 1e3:7.1f} GB/s')
 for (c, r) in [(64, 513), (128, 257), (256, 128)]:
     x = torch.randn(N, c, r, r, device=dev).half().to(memory_format=CL)
     b, d = torch.randn(c, device=dev), torch.rand(N, c, device=dev) + 0.5
