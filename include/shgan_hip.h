@@ -233,7 +233,8 @@ int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, i
 /* ---- next row N3, fp16 route (the reference's `use_fp16` branches: stylegan.py:136-138,486,660-667, comodgan.py:40-47,305; its native
  * op is instantiated for half as well, upfirdn2d.cpp:59 AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Layout of every fp16 activation:
  * channels-LAST, [N,H,W,C] IEEE halves (torch.channels_last on a [N,C,H,W] tensor) -- 8 consecutive channels are one 16-byte MFMA
- * operand.  Arithmetic: v_mfma_f32_32x32x16_f16, fp32 accumulation, one rounding to fp16.
+ * operand.  Arithmetic: v_mfma_f32_32x32x16_f16, fp32 accumulation, one rounding to fp16.  Every tensor pointer of this section and the
+ * per-channel fp32 operands (bias, out_scale / d) must be 16-byte aligned (vector loads; SHG_ERR_ARG otherwise).
  * shg_conv2d_f16_pack_weight: w [T][O][I] halves (T = k*k correlation taps, row-major (ky,kx)) -> wp in MFMA operand order
  *   [ceil(O/32) rounded up to 4][T][I/16][64][8] (shg_conv2d_f16_packed_weight_elems halves, zero beyond O): every operand of the
  *   kernel is one coalesced, unconditional 1 KiB load.

@@ -1165,6 +1165,9 @@ extern "C" int shg_conv2d_f16_fused(const void* x, const void* w, void* y, int N
                                     float noise_strength, const float* bias, int act, float alpha, float gain, float clamp, const void* residual,
                                     void* stream) {
     SHG_CHECK_ARG(mode == 0 || !(out_scale || noise || act || residual || gain != 1.f), "conv2d_f16_fused: the transposed form takes in_scale only (its tail follows the FIR)");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(residual) |
+                    reinterpret_cast<uintptr_t>(out_scale) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  "conv2d_f16: x, w, y, residual, out_scale and bias must be 16-byte aligned (vector loads)");
     const shg_f16_tail_ tl{in_scale, out_scale, noise, noise_mode, noise_strength, act, alpha, gain, clamp, residual};
     return conv2d_f16_impl(x, w, bias, y, N, I, O, H, W, k, stride, pad, mode, crop, OH, OW, &tl, stream);
 }
@@ -1295,6 +1298,8 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
 extern "C" int shg_bias_act_f16(const void* x, const float* bias, void* y, long pixels, int C, int act, float alpha, float gain, float clamp,
                                 void* stream) {
     SHG_CHECK_ARG(x && y, "bias_act_f16: null pointer");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  "bias_act_f16: x, y and bias must be 16-byte aligned");
     SHG_CHECK_ARG(pixels >= 0 && C >= 8 && (C % 8) == 0, "bias_act_f16: C must be a multiple of 8");
     const long total8 = pixels * (C / 8);
     if (total8 == 0) return SHG_OK;
@@ -1328,6 +1333,8 @@ extern "C" int shg_bias_act_backward_f16(const void* g, const void* y, void* dx,
 extern "C" int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C,
                                int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(t && y && N >= 1 && HW >= 1 && C >= 8 && (C % 8) == 0, "modtail_f16: bad arguments (C must be a multiple of 8)");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  "modtail_f16: t, y, d and bias must be 16-byte aligned");
     f16::TailP p{};
     p.t = (const _Float16*)t; p.d = d; p.noise = noise_mode ? noise : nullptr; p.noise_mode = noise ? noise_mode : 0; p.bias = bias;
     p.out = (_Float16*)y; p.N = N; p.HW = (int)HW; p.C = C; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
