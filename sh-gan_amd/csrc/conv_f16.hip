@@ -1209,7 +1209,9 @@ extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW
 // stride 1, 372 / 449 / 381 at stride 2 -- whose 260-register build held ONE workgroup per CU (346 TFLOP/s) until amdgpu_waves_per_eu(2) brought it to
 // 255 without spills; the load-bound 1x1 layers at 1024: 126 / 211 / 237 / 253 at 512 channels)
 static long wgrad_f16_slices(long tiles, long nblocks, long wgs) {
-    if (const char* e = getenv("SHG_WGRAD16_WGS")) wgs = atol(e);       // study switch
+#ifdef SHG_ABLATE
+    if (const char* e = getenv("SHG_WGRAD16_WGS")) wgs = atol(e);       // study switch (python sh-gan_amd/build.py --ablate: tools/_variants)
+#endif
     long slices = (wgs + tiles - 1) / tiles;
     if (slices > nblocks) slices = nblocks;
     return slices < 1 ? 1 : slices;
@@ -1277,7 +1279,12 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
     const long total = same ? (long)N * ((OH + rb - 1) / rb) * ((OW + 3) / 4) * (C / 8) : (long)N * OH * OW * (C / 8);
     int grid = shg_cdiv(total, 256);
     if (grid > 256 * 32) grid = 256 * 32;
-    if (same && fh == 4 && fw == 4 && !getenv("SHG_F16_FIR_OLD")) {
+#ifdef SHG_ABLATE
+    const bool march = !getenv("SHG_F16_FIR_OLD");                     // study switch: the 2 x 4-pixel kernel instead
+#else
+    const bool march = true;
+#endif
+    if (same && fh == 4 && fw == 4 && march) {
         // marching strips: the longest of 32 / 16 / 8 / 4 rows that still leaves >= 8 workgroups per CU
         int rows = 32;
         auto lanes = [&](int r) { return (long)N * ((OH + r - 1) / r) * ((OW + 1) / 2) * (C / 8); };

@@ -337,7 +337,9 @@ static int wgrad_slices(int NB, int I, int O, int OH, int OW, int taps) {
     long s = ((taps > 1 ? 256 : 4 * 256) + tiles - 1) / tiles;
     const long per_slice = (long)O * I * taps * (long)sizeof(float);
     const long cap = (256L << 20) / per_slice;                   // at most 256 MB of partial sums
-    if (const char* e = getenv("SHG_WGRAD_WGS")) s = (atol(e) + tiles - 1) / tiles;       // study switch: workgroups in total
+#ifdef SHG_ABLATE
+    if (const char* e = getenv("SHG_WGRAD_WGS")) s = (atol(e) + tiles - 1) / tiles;       // study switch: workgroups in total (--ablate build, tools/_variants)
+#endif
     if (s > cap) s = cap;
     if (s > nchunk) s = nchunk;
     if (s > 1024) s = 1024;
