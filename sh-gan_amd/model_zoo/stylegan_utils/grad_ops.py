@@ -65,6 +65,7 @@ class _BiasActFn(torch.autograd.Function):
                                  act_gain=act_gain, clamp=clamp)
         ctx.save_for_backward(y)
         ctx.cfg = (act, gain, alpha, act_gain, clamp, bias is not None)
+        ctx.bias_dtype = None if bias is None else bias.dtype
         return y
 
     @staticmethod
@@ -80,7 +81,7 @@ class _BiasActFn(torch.autograd.Function):
             else:
                 dx, _, s0, _ = kernels.modtail_backward(g.detach().contiguous(), y, None, None, want_sums=True, want_noise=False, act=act, gain=gain,
                                                         alpha=alpha, act_gain=act_gain, clamp=clamp)
-            return dx, s0.sum(0), None, None, None, None, None
+            return dx, s0.sum(0).to(ctx.bias_dtype), None, None, None, None, None
         dx = _BiasActBwdFn.apply(g, y, (act, gain, alpha, act_gain, clamp))
         db = None
         if has_bias and ctx.needs_input_grad[1]:
