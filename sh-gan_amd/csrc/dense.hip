@@ -14,37 +14,35 @@
 // One wave per output feature: lane l walks k = l, l+64, ... of the weight row (coalesced 256 B) and of the
 // DENSE_MAXN activation rows (the whole activation matrix is a few hundred KB and stays in L2); all loads
 // of an iteration are independent, so the compiler keeps 1 + N of them in flight per lane.
+// MAXN = 4 / 8 / 16 samples per pass (the smallest that holds the batch; larger batches in slabs of 16): every activation load is unconditional --
+// rows past the batch re-read the last row.  (A run-time `n < nb` guard around the loads made the batch-8 training calls 4x slower than the
+// batch-16 inference calls: 57 vs 15 us.)
+template <int MAXN>
 __global__ __launch_bounds__(256) void dense_kernel(const float* x, const float* w, const float* b, float* y, int N, int K, int O,
                                                     int ldx, int ldy, float wgain, float bgain, int act, float alpha, float gain,
                                                     float clamp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = blockIdx.x * 4 + wave;
     if (o >= O) return;
-    const int n0 = blockIdx.y * DENSE_MAXN;
-    const int nb = min(DENSE_MAXN, N - n0);
+    const int n0 = blockIdx.y * MAXN;
+    const int nb = min(MAXN, N - n0);
     const float* wr = w + (long)o * K;
     const float* xr = x + (long)n0 * ldx;
-    float acc[DENSE_MAXN];
+    long roff[MAXN];
 #pragma unroll
-    for (int n = 0; n < DENSE_MAXN; ++n) acc[n] = 0.f;
-    if (nb == DENSE_MAXN) {
+    for (int n = 0; n < MAXN; ++n) roff[n] = (long)(n < nb ? n : nb - 1) * ldx;
+    float acc[MAXN];
+#pragma unroll
+    for (int n = 0; n < MAXN; ++n) acc[n] = 0.f;
 #pragma unroll 2
-        for (int k = lane; k < K; k += 64) {
-            const float wv = wr[k];
+    for (int k = lane; k < K; k += 64) {
+        const float wv = wr[k];
 #pragma unroll
-            for (int n = 0; n < DENSE_MAXN; ++n) acc[n] += wv * xr[(long)n * ldx + k];
-        }
-    } else {
-        for (int k = lane; k < K; k += 64) {
-            const float wv = wr[k];
-#pragma unroll
-            for (int n = 0; n < DENSE_MAXN; ++n)
-                if (n < nb) acc[n] += wv * xr[(long)n * ldx + k];
-        }
+        for (int n = 0; n < MAXN; ++n) acc[n] += wv * xr[roff[n] + k];
     }
     const float bias = b ? b[o] * bgain : 0.f;
 #pragma unroll
-    for (int n = 0; n < DENSE_MAXN; ++n) {
+    for (int n = 0; n < MAXN; ++n) {
         float v = acc[n];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -61,9 +59,15 @@ extern "C" int shg_dense_f32(const float* x, const float* w, const float* b, flo
                              float wgain, float bgain, int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(x && w && y, "dense: null pointer");
     SHG_CHECK_ARG(N >= 1 && K >= 1 && O >= 1 && ldx >= K && ldy >= O, "dense: bad shape");
-    dim3 grid(shg_cdiv(O, 4), shg_cdiv(N, DENSE_MAXN));
-    hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, N, K, O, ldx, ldy, wgain, bgain, act,
-                       alpha, gain, clamp);
+    if (N <= 4)
+        hipLaunchKernelGGL(dense_kernel<4>, dim3(shg_cdiv(O, 4), 1), dim3(256), 0, (hipStream_t)stream, x, w, b, y, N, K, O, ldx, ldy, wgain, bgain,
+                           act, alpha, gain, clamp);
+    else if (N <= 8)
+        hipLaunchKernelGGL(dense_kernel<8>, dim3(shg_cdiv(O, 4), 1), dim3(256), 0, (hipStream_t)stream, x, w, b, y, N, K, O, ldx, ldy, wgain, bgain,
+                           act, alpha, gain, clamp);
+    else
+        hipLaunchKernelGGL(dense_kernel<DENSE_MAXN>, dim3(shg_cdiv(O, 4), shg_cdiv(N, DENSE_MAXN)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, N, K,
+                           O, ldx, ldy, wgain, bgain, act, alpha, gain, clamp);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
