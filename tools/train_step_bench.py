@@ -18,6 +18,7 @@ ap.add_argument('--resolution', type=int, default=512)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--fp16', action='store_true', help='the use_fp16 blocks of the reference: encoder > 64, synthesis > 32, discriminator > 32')
+ap.add_argument('--host-enqueue', action='store_true', help='also time how long the host needs to enqueue a G phase (one extra G phase)')
 ap.add_argument('--direct-convt', action='store_true', help='transposed convolutions on the direct interleaved kernel (A/B)')
 a = ap.parse_args()
 if a.direct_convt:
@@ -77,18 +78,19 @@ for _ in range(a.steps):
     tg += e[0].elapsed_time(e[1]); td += e[1].elapsed_time(e[2]); hist.append((lg, ld))
 print(f'G phase {tg / a.steps:8.1f} ms   D phase {td / a.steps:8.1f} ms   step {(tg + td) / a.steps:8.1f} ms   '
       f'({a.batch / ((tg + td) / a.steps) * 1e3:.1f} images/s, losses {lg:.4f} {ld:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)')
-# host time to ENQUEUE a step (the losses are read with float(): one sync per phase, so this is measured on the autograd part alone)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-G.requires_grad_(True); D.requires_grad_(False); syncG.zero_grad()
-with torch.enable_grad():
-    _img = G(x=x, z=z, c=cnd, noise_mode='random')
-    _loss = F.softplus(-D(d_in(_img), None)).mean()
-    _loss.backward()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f'host enqueue of the G phase (forward + backward, no sync): {(t1 - t0) * 1e3:.1f} ms; GPU drained {(t2 - t1) * 1e3:.1f} ms later')
+if a.host_enqueue:
+    # host time to ENQUEUE a step (the losses are read with float(): one sync per phase, so this is measured on the autograd part alone)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    G.requires_grad_(True); D.requires_grad_(False); syncG.zero_grad()
+    with torch.enable_grad():
+        _img = G(x=x, z=z, c=cnd, noise_mode='random')
+        _loss = F.softplus(-D(d_in(_img), None)).mean()
+        _loss.backward()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f'host enqueue of the G phase (forward + backward, no sync): {(t1 - t0) * 1e3:.1f} ms; GPU drained {(t2 - t1) * 1e3:.1f} ms later')
 print('loss history (G, D) per step:', ' '.join(f'({g:.4f} {d:.4f})' for g, d in hist))
 kt = kernels.KernelTimer()
 kernels.set_timer(kt)
