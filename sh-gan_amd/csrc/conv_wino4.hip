@@ -49,6 +49,15 @@ extern "C" int shg_wino4_trace_read(long long* host) {
 #define W4_TRACE_E(slot) do { } while (0)
 #endif
 
+// Epilogue barrier.  __syncthreads() carries a release fence that becomes `s_waitcnt vmcnt(0)`: every pass would wait until its
+// own output rows have reached memory before the next pass may exchange its accumulators.  The exchange only needs the LDS
+// traffic ordered, so the barrier is raw and the stores of pass p drain under the exchange and the arithmetic of pass p+1.
+#ifdef SHG_W4_EPI_SYNC
+#define W4_EPI_BARRIER() __syncthreads()
+#else
+#define W4_EPI_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+
 struct Wino4Params {
     const float* x;          // [NB, I, H, W]
     const float* wu;         // transformed weights [OP/64][nchunk][4 k-steps][72 units][64 lanes]
@@ -140,6 +149,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
 
     // ---- staging roles: waves 0..3 transform two channels each; waves 4..7 fetch the raw windows of two channels each
     const bool xformer = wave < 4;
+    // Window fetch: LDS-DMA through a buffer descriptor.  The descriptor covers ONE channel plane (base = x[n, ch],
+    // num_records = the plane's bytes; checked with tools/micro/lds_dma_probe.hip), a lane's offset is its position inside the plane
+    // and every lane outside the image (halo rows / columns, padding lanes of the last piece) carries an offset beyond
+    // num_records: the hardware's range check then delivers zeros, which is exactly the convolution's zero padding.  Per piece
+    // this is one M0 write and one instruction; the 64-bit flat-address form (select between the plane and a block of zeros per
+    // lane) cost ~15 scalar and vector instructions per piece and made the fetch waves the slow half of every chunk.
     int roff[NPIECE];
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
@@ -147,28 +162,31 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         const int py = q / PW4, p4 = q - py * PW4;
         const int iy = oy0 - 1 + py, ix = ox0 - 4 + 4 * p4;
         const bool ok = q < PATCH4 && iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W;
-        roff[j] = ok ? n * p.I * HW + iy * p.W + ix : -1;
+        roff[j] = ok ? (iy * p.W + ix) * 4 : (int)0x80000000;
     }
-    auto dma_piece = [&](int c, int buf, int q, int j) __attribute__((always_inline)) {
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const unsigned rl_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)Rl);   // LDS byte address of the window buffers
+    const unsigned long long xn = reinterpret_cast<unsigned long long>(p.x) + (unsigned long long)n * p.I * HW4;
+    auto dma_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
         if (p.dbg & 2) return;
-        const int k = (wave - 4) * 2 + q;
+        const int k = wave;                                      // every wave fetches the window of ONE channel of the chunk
         const int ch = c * KC + k;
         const bool chok = ch < p.I;                              // (also false for chunks past the end)
-        const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino4_zeros;
-        // Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: the compiler orders every later LDS read (and,
-        // with 40+ loads in flight, every use of a loaded register) behind an LDS-DMA it knows about with `s_waitcnt vmcnt(0)`,
-        // i.e. it waits for the weight loads issued a few instructions earlier.  The windows are ordered by hand (the counted
-        // vmcnt before the chunk's barrier); to the compiler's own counts these are unknown extra loads, which only makes its
-        // waits for older loads conservative.
-        const unsigned lds = __builtin_amdgcn_readfirstlane(
-            (unsigned)(size_t)(__attribute__((address_space(3))) void*)(Rl + buf * R_SZ + k * RP + j * 256));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "m0", "memory");
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long xc = xn + (unsigned long long)(chok ? ch : 0) * HW4;      // (the scalar-offset operand takes part in the range check: the channel goes into the base)
+        i32x4 srd;
+        srd[0] = (int)(unsigned)xc; srd[1] = (int)(unsigned)(xc >> 32); srd[2] = chok ? (int)HW4 : 0; srd[3] = 0x00020000;
+        // Inline assembly, not a builtin: the compiler orders every later LDS read (and, with 40+ loads in flight, every use of a
+        // loaded register) behind an LDS-DMA it knows about with `s_waitcnt vmcnt(0)`, i.e. it would wait for the weight loads
+        // issued a few instructions earlier.  The windows are ordered by hand (the counted vmcnt before the chunk's barrier); to
+        // the compiler's own counts these are unknown extra loads, which only makes its waits for older loads conservative.
+        // s_nop 4: the descriptor / offset SGPRs may come straight from scalar ALU instructions (5 wait states before a VMEM read).
+        const unsigned lds = rl_lds + (unsigned)(buf * R_SZ + k * RP + j * 256) * 4u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(roff[j]), "s"(srd) : "memory");
     };
     auto dma_raw = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < NPIECE; ++j) dma_piece(c, buf, q, j);
+        for (int j = 0; j < NPIECE; ++j) dma_piece(c, buf, j);
     };
 
     // ---- input transform role: channel 2*wave + half, block l31 (ty = l31 / TX, tx = l31 % TX)
@@ -253,10 +271,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         for (int j = 0; j < NU; ++j) ur[3][j] = 0.f;
 #pragma unroll
         for (int q = 0; q < NP; ++q) b[1][q] = 0.f;
-        if constexpr (!XF) {
-            dma_raw(0, 0);
-            dma_raw(1, 1);
-        }
+        dma_raw(0, 0);
+        dma_raw(1, 1);
         __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), as an instruction the compiler's wait-count tracking sees
         __syncthreads();
         if constexpr (XF) {
@@ -323,9 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 mma(3, 1, j);
-                if constexpr (!XF) {
-                    if (j < 2 * NPIECE) dma_piece(c + 2, buf, j / NPIECE, j % NPIECE);   // raw(c) was consumed during chunk c-1
-                }
+                if (j < NPIECE) dma_piece(c + 2, buf, j);                  // raw(c) was consumed during chunk c-1
                 if (j >= RFD) refill_m(j - RFD);
                 if constexpr (XF) {
                     if (j < 6) tr_read(j, w[j & 1], buf ^ 1);                     // raw(c+1) landed before the previous barrier
@@ -352,10 +366,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
             }
 #pragma unroll
             for (int m = 4 * NU - RFD; m < 4 * NU; ++m) refill_m(m);
-            // the last window piece went out ahead of all but 2*NPIECE - 1 - RFD of the chunk's 4*NU weight loads: in-order retirement makes
-            // "at most that many outstanding" mean "the window has landed" without waiting for the weights
+            // the last window piece went out behind max(0, NPIECE - 1 - RFD) of the chunk's 4*NU weight loads and ahead of all others:
+            // in-order retirement makes "at most that many outstanding" mean "the window has landed" without waiting for the weights
             W4_TRACE(4);
-            if constexpr (!XF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NU - 2 * NPIECE + 1 + RFD) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NU - (NPIECE - 1 - RFD > 0 ? NPIECE - 1 - RFD : 0)) : "memory");
             // raw barrier: __syncthreads() carries a release fence that the compiler lowers to `s_waitcnt vmcnt(0)`, i.e. a wait for
             // the weight loads just issued.  LDS traffic is ordered by lgkmcnt(0), the DMA by the count above.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -453,11 +467,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
                     Mx[((pfirst + q) * 16 + lr) * 32 + l31] = acc[2 * q + ob][r];
                 }
             }
-            __syncthreads();
+            W4_EPI_BARRIER();
             finish(pass, tops);
             W4_TRACE_E(pass * 8 + 3);
             W4_TRACE_T(3 + pass);
-            if (pass < 3) __syncthreads();
+            if (pass < 3) W4_EPI_BARRIER();
         }
     };
     if (xformer) body(std::integral_constant<int, 8>{}, std::true_type{});
@@ -527,7 +541,8 @@ extern "C" int shg_conv_weight_prep_wino4_f32(const float* w, const float* wscal
 
 // 1 when shg_conv2d_wino4_f32 serves the geometry (otherwise shg_conv2d_wino_f32 / shg_conv2d_f32)
 extern "C" int shg_conv2d_wino4_supported(int NB, int I, int O, int H, int W) {
-    return (H >= 16 && W >= 32 && W % 4 == 0 && I <= 128 * wino4::KC && NB >= 1 && O >= 1) ? 1 : 0;
+    // (one sample's input must stay below 4 GiB: the window fetch addresses a channel plane as descriptor base + 32-bit scalar offset)
+    return (H >= 16 && W >= 32 && W % 4 == 0 && I <= 128 * wino4::KC && NB >= 1 && O >= 1 && (long)I * H * W < (1L << 30)) ? 1 : 0;
 }
 
 // y = act(out_scale[n,o] * conv3x3_same(x * in_scale[n,i], w) + noise*noise_strength + bias[o]) + residual, stride 1, pad 1.

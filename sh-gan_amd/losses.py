@@ -132,13 +132,22 @@ class InpaintingLoss(StyleGAN2Loss):
       * ``real_img`` is the discriminator's real input ``[N, 4, R, R] = cat([mask - 0.5, real])`` (``ic_n = 4``);
       * the generator input is derived from it as the evaluation loop does (``shgan_default.py:268-273``):
         ``x = cat([mask - 0.5, real * mask])``, ``img = G.synthesis(*G.encoder(x), ws)`` with ``ws`` from ``G.mapping`` (style mixing on ``ws``);
-      * generated images reach the discriminator as ``cat([mask - 0.5, img])``; R1 differentiates the logits w.r.t. the 4-channel real input.
+      * generated images reach the discriminator as ``cat([mask - 0.5, img])``; R1 differentiates the logits w.r.t. the 4-channel real input;
+      * ``composite_fake`` (default True): the generator's output is composited with the known pixels,
+        ``img * (1 - mask) + real * mask``, before anything downstream sees it -- the critic, and with it the path-length
+        regulariser -- as CoModGAN does inside its generator and as the reference's evaluation loop does with this generator
+        (``shgan_default.py:259``).  Without it the critic can tell real from fake from the known region alone and the generator is
+        trained on pixels that are thrown away at evaluation time.  ``composite_fake=False`` is the raw-output objective; the
+        full-width reference-autograd fixtures (``tests/golden/config5_step512.npz``, generated by feeding the reference's modules
+        the raw output) are evaluated in that mode, the composite itself is pinned by ``tests/test_gpu_config5.py``.
+    CoModGAN's optional L1 term on the known region is not part of ``stylegan_default_loss.py`` and is not added.
     ``noise_mode`` is the synthesis noise ('random' in training; tests pin 'const')."""
 
-    def __init__(self, device, G, D, noise_mode='random', **kw):
+    def __init__(self, device, G, D, noise_mode='random', composite_fake=True, **kw):
         super().__init__(device, G.mapping, None, D, **kw)
         self.G = G
         self.noise_mode = noise_mode
+        self.composite_fake = composite_fake
         self._m05 = self._x = None
 
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync=True, gain=1):
@@ -155,7 +164,11 @@ class InpaintingLoss(StyleGAN2Loss):
         n = z.shape[0]
         ws = self._style_mix(self.G.mapping(z, c), z, c)
         x_global, feats = self.G.encoder(self._x[:n])
-        return self.G.synthesis(x_global, feats, ws, noise_mode=self.noise_mode), ws
+        img = self.G.synthesis(x_global, feats, ws, noise_mode=self.noise_mode)
+        if self.composite_fake:                                  # known pixels from the input (x[:, 1:4] = real * mask), the hole from G
+            m = self._m05[:n] + 0.5
+            img = img * (1.0 - m) + self._x[:n, 1:4]
+        return img, ws
 
     def run_D(self, img, c, sync=True):
         if img.shape[1] == 3:                                   # a generated image: prepend the mask channel it was conditioned on
