@@ -123,7 +123,7 @@ def parse():
     ap.add_argument('--noise-mode', default='random')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=None, help='images per CPU forward (default: the full bench batch, SURVEY 8d)')
-    ap.add_argument('--cpu-forwards', type=int, default=2)
+    ap.add_argument('--cpu-forwards', type=int, default=3, help='timed CPU forwards after one warm-up (SURVEY 8d: >= 3)')
     ap.add_argument('--no-second-config', action='store_true', help='skip the 256x256 batch-32 block (BASELINE config 2)')
     ap.add_argument('--no-train-step', action='store_true', help='skip the config-5 training-step block')
     ap.add_argument('--all-blocks', action='store_true',
@@ -131,6 +131,9 @@ def parse():
                          'measures the headline and nothing can stand between it and its JSON line)')
     ap.add_argument('--train-batch', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=3)
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
+                    help='headline loop as HIP-graph replays (eval_harness.GraphPipeline) instead of eager launches; auto = on when it '
+                         'captures and is not slower than the eager loop in a short trial')
     ap.add_argument('--pipeline-depth', type=int, default=None,
                     help='HIP streams the consecutive (independent) batches are issued on round-robin; 1 = one stream')
     ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
@@ -276,6 +279,7 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
 
 def worker(local_rank, a, spawned_world=None, port=None):
     """One rank.  ``spawned_world`` is set when this process was started by bench.py's own spawn."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / device-memory sharing across processes needs it on this driver
     import torch
     import torch.distributed as dist
     import shgan_amd  # noqa: F401
@@ -326,19 +330,68 @@ def worker(local_rank, a, spawned_world=None, port=None):
 
     if a.pipeline_depth is None:
         a.pipeline_depth = eval_harness.PIPELINE_DEPTH
+
+    def agree(flag):
+        """every rank takes the same loop: the flag holds only if it holds on all ranks"""
+        if use_dist:
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            flag = bool(t.item() > 0.5)
+        return flag
+
+    def loop(pipe, n, graphed):
+        o = None
+        for _ in range(n):
+            o = pipe.run(x, z) if graphed else pipe.run(step)
+        pipe.join()
+        return o
+
+    # ---- eager loop (round-robin streams) or the same loop as HIP-graph replays
     pipe = eval_harness.StreamPipeline(dev, depth=a.pipeline_depth)
-    for _ in range(a.warmup):
-        pipe.run(step)
-    pipe.join()
+    loop(pipe, max(a.warmup, 1), False)
+    graph_info = {'mode': a.graph, 'used': False}
+    gpipe = None
+    if a.graph != 'off':
+        try:
+            gpipe = eval_harness.GraphPipeline(dev, lambda x_, z_: eval_harness.run_generator(G, x_, z_, noise_mode=a.noise_mode), (x, z),
+                                               depth=a.pipeline_depth)
+            loop(gpipe, max(a.pipeline_depth, 2), True)
+            torch.cuda.synchronize()
+        except Exception as e:
+            graph_info['capture_error'] = repr(e)[:300]
+            gpipe = None
+        captured = agree(gpipe is not None)
+        graph_info['captured_on_all_ranks'] = captured
+        use_graph = captured
+        if captured and a.graph == 'auto':
+            trial = {}
+            for name, pp, gr in (('eager', pipe, False), ('graph', gpipe, True), ('eager', pipe, False), ('graph', gpipe, True)):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                loop(pp, 6, gr)
+                torch.cuda.synchronize()
+                trial[name] = min(trial.get(name, 1e9), (time.perf_counter() - t_) / 6 * 1e3)
+            graph_info['trial_ms_per_step'] = {k: round(v, 3) for k, v in trial.items()}
+            # one GPU: the replay must not be slower; several ranks on one host: prefer it unless clearly slower (eight interpreters
+            # enqueueing ~120 launches per step compete for the host's cores -- the replay is one call)
+            use_graph = agree(trial['graph'] <= trial['eager'] * (1.0 if world == 1 else 1.03))
+        graph_info['used'] = use_graph
+        if not use_graph:
+            gpipe = None
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = pipe.run(step)
-    pipe.join()
+    out = loop(gpipe, a.steps, True) if gpipe is not None else loop(pipe, a.steps, False)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev)
+    rank_ms = [dt_local / a.steps * 1e3]
+    if use_dist:                           # every rank's own loop time: a straggler shows in the line the first time N > 1 runs on hardware
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        t[rank] = dt_local / a.steps * 1e3
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) for v in t.tolist()]
     ranks_counted = 1
     if use_dist:                           # every rank contributes 1: the line proves how many ranks the collective really spanned
         t = torch.ones(1, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
@@ -368,7 +421,8 @@ def worker(local_rank, a, spawned_world=None, port=None):
         kernels.set_timer(None)
         tsum = timer.summary()
     barrier()
-    del pipe
+    del pipe, gpipe
+    torch.cuda.empty_cache()
     second = train = fp16_eval = None
     extra = world == 1 or a.all_blocks
     if extra and not a.no_second_config and res == 512 and a.batch is None:
@@ -450,7 +504,10 @@ def worker(local_rank, a, spawned_world=None, port=None):
                        'parallelism': f'batch-shard x{world}', 'launcher': 'self-spawn' if spawned_world else
                        ('torch.distributed.run' if 'RANK' in os.environ and spawned_world is None and use_dist else 'single process'),
                        'collective_backend': backend, 'ranks_all_reduced': ranks_counted, 'ranks_share_devices': oversub,
-                       'stream_pipeline_depth': a.pipeline_depth},
+                       'stream_pipeline_depth': a.pipeline_depth, 'hip_graph': graph_info,
+                       'ms_per_step_by_rank': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
+                                               'all': [round(v, 3) for v in rank_ms],
+                                               'note': 'each rank\'s own loop time (before the closing barrier); ms_per_step = barrier-to-barrier, max over ranks'}},
             'pipeline': {'depth': a.pipeline_depth, 'ms_per_step_single_stream': round(lat_ms, 3) if lat_ms else None,
                          'note': 'the K timed steps are independent batches issued round-robin on `depth` HIP streams '
                                  '(eval_harness.StreamPipeline, the evaluation loop of the product): the launch-boundary gaps of '

@@ -127,6 +127,58 @@ class StreamPipeline:
         self.outs = []
 
 
+class GraphPipeline:
+    """The same round-robin loop with every slot's forward pass captured once as a HIP graph (``torch.cuda.graph``: the ~150 ctypes
+    launches, the allocator traffic and the device RNG of ``fn`` become one ``hipGraphLaunch`` per batch).  On one GPU the host
+    keeps up with eager launches anyway (2 ms of Python per 19 ms step); with eight ranks on one host eight interpreters compete
+    for cores, and the replay takes the host out of the step.  ``fn(*args)`` must be shape-static and sync-free; per-parameter
+    caches are warmed by eager calls before the capture.  ``run(*args)`` copies the arguments into the slot's static inputs and
+    replays; the returned tensor is the slot's static output (valid until that slot runs again, ``depth`` calls later).
+
+        pipe = GraphPipeline(device, step_fn, (x0, z0), depth=3)
+        for x, z in batches: out = pipe.run(x, z); ...
+        pipe.join()"""
+
+    def __init__(self, device, fn, example_args, depth=None, warmup=2):
+        depth = PIPELINE_DEPTH if depth is None else max(1, depth)
+        self.device = torch.device(device)
+        cur = torch.cuda.current_stream(self.device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.graphs, self.ins, self.outs = [], [], []
+        self.k = 0
+        for s in self.streams:
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ins = [a.clone() if torch.is_tensor(a) else a for a in example_args]
+                for _ in range(warmup):
+                    fn(*ins)
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = fn(*ins)
+            self.graphs.append(g)
+            self.ins.append(ins)
+            self.outs.append(out)
+        cur.wait_stream(self.streams[-1])
+
+    def run(self, *args):
+        i = self.k % len(self.streams)
+        self.k += 1
+        s = self.streams[i]
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for dst, a in zip(self.ins[i], args):
+                if torch.is_tensor(dst) and dst.data_ptr() != a.data_ptr():
+                    dst.copy_(a, non_blocking=True)
+            self.graphs[i].replay()
+        return self.outs[i]
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
 def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, gather=True, device='cuda',
                  noise_mode='const', step_fn=None, z_dim=None, pipeline_depth=None):
     """Batch-sharded evaluation over a synthetic dataset of ``n_items`` images (BASELINE config 4): rank r processes
