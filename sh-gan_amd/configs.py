@@ -1,6 +1,6 @@
 """Resolved model configurations of the SH-GAN generators (the YAML inheritance of the reference's
 configs/model/{stylegan,comodgan,shgan}.yaml flattened: SURVEY.md appendix A.1) and a deterministic
-random initialiser, so that the product can construct ``shgan_g256`` / ``shgan_g512`` by itself:
+random initialiser, so that the product can construct ``shgan_g256`` / ``shgan_g512`` / ``shgan_g1024`` by itself:
 
     G = configs.build_generator(512)            # == get_model()(configs.model_cfg('shgan_g512'))
     configs.seeded_init_(G, seed=0)             # the reference's initialisers, identical on every rank
@@ -21,9 +21,9 @@ def model_cfg(name='shgan_g512', ch_base=32768, ch_max=512, w_dim=512, z_dim=512
     """Registry config (``type`` / ``args``) of a shipped generator; the width arguments exist for reduced-size tests.  The shipped
     configs are float32 (``use_fp16_*: null``, comodgan.yaml:27,46); ``use_fp16_before_res`` (encoder blocks above that resolution) /
     ``use_fp16_after_res`` (synthesis blocks above it) switch the reference's half-precision blocks on (BASELINE config 5)."""
-    if name not in ('shgan_g256', 'shgan_g512'):
-        raise KeyError(f'unknown model config {name!r} (shipped: shgan_g256, shgan_g512)')
-    res = int(name[-3:])
+    if name not in ('shgan_g256', 'shgan_g512', 'shgan_g1024'):            # configs/model/shgan.yaml:51-124
+        raise KeyError(f'unknown model config {name!r} (shipped: shgan_g256, shgan_g512, shgan_g1024)')
+    res = int(name.split('_g')[1])
     mapping = dict(type='comodgan_mapping', args=dict(
         z_dim=z_dim, c_dim=0, w_dim=w_dim, num_ws=NUM_WS[res], num_layers=8, embed_features=None, layer_features=None,
         activation=ACT, lr_multiplier=0.01, w_avg_beta=0.995))

@@ -63,6 +63,57 @@ def test_generator_small_golden(env):
     assert torch.isfinite(img_r).all() and rel_err(c(img_r), c(img)) > 1e-4
 
 
+def test_generator_small1024_golden(env):
+    """The shipped 1024 configuration (configs/model/shgan.yaml:94-124) at reduced width against the reference's own run."""
+    import hashlib
+    g = load_golden('generator_small1024')
+    orc = env['orc']
+    res, ch_base, ch_max, w_dim, z_dim, w0_dim = [int(v) for v in g['cfg']]
+    sd = orc.init_state_dict(res, seed=int(g['seeds'][0]), ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim,
+                             noise_strength=0.1, bias_std=0.1)
+    G = make_G(env, res, sd, ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim)
+    assert G.num_ws == 18 and G.img_resolution == 1024
+    x, z, real_u8, mask = orc.synthetic_batch(1, res, z_dim, seed=int(g['seeds'][1]))
+    x, z = x.to(DEV), z.to(DEV)
+    cnd = torch.zeros(1, 0, device=DEV)
+    assert rel_err(c(G.mapping(z, cnd)), g['ws']) < 1e-5
+    xg, feats = G.encoder(x)
+    assert rel_err(c(xg), g['xg']) < 1e-4
+    for r in (4, 16, 64):
+        assert rel_err(c(feats[r]), g[f'feat{r}']) < 1e-4, r
+    for r in (256, 512, 1024):
+        f = feats[r]
+        st = np.array([f.mean().item(), f.std().item(), f.min().item(), f.max().item()])
+        assert np.allclose(st, g[f'feat{r}_stats'], rtol=1e-3, atol=1e-3), r
+    img = G(x=x, z=z, c=cnd, noise_mode='const')
+    assert rel_err(c(img)[:, :, ::4, ::4], g['img_ds']) < 1e-3
+    assert rel_err(c(img).flatten()[g['sample_idx']], g['sample_val']) < 1e-3
+    u8 = env['kernels'].composite_u8(x, img)
+    known = c(u8) * mask.astype(np.uint8)
+    assert hashlib.sha256(known.tobytes()).hexdigest() == str(g['known_sha256'])
+
+
+def test_generator_full_width_1024(env):
+    """shgan_g1024 at FULL width (32-channel 1024^2 layers, below the 64-channel tile of every convolution kernel: zero-padded
+    operand layouts), batch 2 on the device, one image against the CPU oracle; known pixels exact, shard-invariant."""
+    from shgan_amd import configs
+    orc, hz = env['orc'], env['harness']
+    assert configs.model_cfg('shgan_g1024')['args']['mapping']['args']['num_ws'] == 18
+    sd = orc.init_state_dict(1024, seed=81, noise_strength=0.05)
+    G = make_G(env, 1024, sd)
+    x, z, real_u8, mask = hz.synthetic_batch(2, 1024, 512, seed=82, device=DEV, masks='bernoulli')
+    cnd = torch.zeros(2, 0, device=DEV)
+    a = G(x=x, z=z, c=cnd, noise_mode='const')
+    assert tuple(a.shape) == (2, 3, 1024, 1024) and torch.isfinite(a).all()
+    one = G(x=x[:1], z=z[:1], c=cnd[:1], noise_mode='const')
+    assert rel_err(c(one), c(a[:1])) < 1e-4
+    u8 = hz.run_generator(G, x, z, noise_mode='const')
+    m = mask.astype(bool)
+    assert np.array_equal(np.where(m, c(u8), 0), np.where(m, real_u8, 0))
+    ref = orc.generator_forward(sd, x[:1].cpu(), z[:1].cpu(), 1024, noise_mode='const')
+    assert rel_err(c(one), ref.numpy()) < 1e-3
+
+
 def test_generator_full_width_256_golden(env):
     """BASELINE config 1 shape on the GPU: full-width 256x256, batch 2, weights from the seed."""
     g = load_golden('generator_full256_stats')

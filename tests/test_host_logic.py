@@ -174,8 +174,13 @@ def test_configs_build_and_seeded_init_are_deterministic():
     assert cfg['type'] == 'comodgan_generator' and cfg['args']['encoder']['type'] == 'shgan_encoder'
     assert cfg['args']['encoder']['args']['shu_df_freedom'] == [2, 3] and cfg['args']['mapping']['args']['num_ws'] == 14
     assert configs.model_cfg('shgan_g512')['args']['synthesis']['args']['resolution'] == 512
+    c1024 = configs.model_cfg('shgan_g1024')                                    # configs/model/shgan.yaml:94-124
+    assert c1024['args']['mapping']['args']['num_ws'] == 18 and c1024['args']['encoder']['args']['resolution'] == 1024
+    assert c1024['args']['encoder']['args']['shu_input_res'] == 64 and c1024['args']['synthesis']['args']['resolution'] == 1024
     with pytest.raises(KeyError):
-        configs.model_cfg('shgan_g1024')
+        configs.model_cfg('shgan_g128')
+    g1024 = configs.build_generator(1024, **kw)
+    assert g1024.num_ws == 18 and 'synthesis.b1024.torgb.weight' in g1024.state_dict() and 'encoder.b1024.fromrgb.weight' in g1024.state_dict()
     a = configs.seeded_init_(configs.build_generator(256, **kw), seed=3, noise_strength=0.1, bias_std=0.1).state_dict()
     b = configs.seeded_init_(configs.build_generator(256, **kw), seed=3, noise_strength=0.1, bias_std=0.1).state_dict()
     c = configs.seeded_init_(configs.build_generator(256, **kw), seed=4).state_dict()

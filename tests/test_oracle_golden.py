@@ -139,6 +139,25 @@ def test_generator_small_against_reference():
     assert np.array_equal(np.where(m, g['comb_u8'], 0), np.where(m, g['real_u8'], 0))
 
 
+def test_generator_small1024_against_reference():
+    """configs/model/shgan.yaml:94-124 (shgan_g1024: num_ws 18, two more blocks) at reduced width, N=1."""
+    g = load_golden('generator_small1024')
+    res, ch_base, ch_max, w_dim, z_dim, w0_dim = [int(v) for v in g['cfg']]
+    sd = orc.init_state_dict(res, seed=int(g['seeds'][0]), ch_base=ch_base, ch_max=ch_max, w_dim=w_dim, z_dim=z_dim, w0_dim=w0_dim,
+                             noise_strength=0.1, bias_std=0.1)
+    assert sorted(sd.keys()) == list(g['state_dict_keys'])
+    x, z, real_u8, mask = orc.synthetic_batch(1, res, z_dim, seed=int(g['seeds'][1]))
+    assert np.array_equal(np.packbits(mask), g['mask_bits']) and np.array_equal(z.numpy(), g['z'])
+    img, mid = orc.generator_forward(sd, x, z, res, noise_mode='const', return_intermediates=True)
+    assert mid['ws'].shape[1] == 18
+    assert rel_err(mid['ws'].numpy(), g['ws']) < TOL
+    assert rel_err(mid['xg'].numpy(), g['xg']) < 1e-5
+    for r in (4, 16, 64):
+        assert rel_err(mid['feats'][r].numpy(), g[f'feat{r}']) < 1e-5, r
+    assert rel_err(img[:, :, ::4, ::4].numpy(), g['img_ds']) < 2e-5
+    assert rel_err(img.flatten()[torch.from_numpy(g['sample_idx'])].numpy(), g['sample_val']) < 2e-5
+
+
 def test_generator_full256_stats():
     """BASELINE config 1: full-width 256x256, batch 2, random-init, CPU."""
     g = load_golden('generator_full256_stats')

@@ -333,6 +333,39 @@ def gen_generator_small():
     save('generator_small', **out)
 
 
+def gen_generator_small1024():
+    """The shipped 1024 configuration (configs/model/shgan.yaml:94-124: num_ws 18, two more encoder / synthesis blocks) at reduced width,
+    N=1, noise_mode const: ws, x_global, the low-resolution skip features, the image on a stride-4 grid + sampled pixels, the uint8
+    composite's known region as a hash."""
+    cfg = dict(resolution=1024, ch_base=4096, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = build_reference_generator(**cfg)
+    sd = orc.init_state_dict(1024, seed=71, ch_base=4096, ch_max=32, w_dim=64, z_dim=64, w0_dim=128, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    real_u8, mask, z = synth_inputs(1, 1024, 64, seed=72)
+    x = assemble_x(real_u8, mask)
+    zt = torch.from_numpy(z)
+    c = torch.zeros(1, 0)
+    with torch.no_grad():
+        ws = G.mapping(zt, c)
+        xg, feats = G.encoder(x)
+        img = G(x=x, z=zt, c=c, noise_mode='const')
+    out = dict(mask_bits=np.packbits(mask), z=z, seeds=np.array([71, 72], dtype=np.int64),
+               cfg=np.array([1024, 4096, 32, 64, 64, 128], dtype=np.int64), ws=ws.numpy(), xg=xg.numpy())
+    for r in (4, 16, 64):
+        out[f'feat{r}'] = feats[r].numpy()
+    for r in (256, 512, 1024):
+        out[f'feat{r}_stats'] = np.array([feats[r].mean().item(), feats[r].std().item(), feats[r].min().item(), feats[r].max().item()])
+    out['img_ds'] = img[:, :, ::4, ::4].numpy()
+    idx = rs(73).randint(0, img.numel(), size=512)
+    out['sample_idx'], out['sample_val'] = idx, img.flatten()[idx].numpy()
+    out['img_stats'] = np.array([img.mean().item(), img.std().item(), img.min().item(), img.max().item()])
+    m = x[:, 0:1] + 0.5
+    comb_u8 = ((x[:, 1:4] * m + img * (1 - m)) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8)
+    out['known_sha256'] = np.array(hashlib.sha256((comb_u8 * torch.from_numpy(mask)).numpy().tobytes()).hexdigest())
+    out['state_dict_keys'] = np.array(sorted(G.state_dict().keys()))
+    save('generator_small1024', **out)
+
+
 def gen_generator_full_stats():
     """Full-width G (79.2 M params) at 256x256, N=2 (BASELINE config 1): statistics + sampled
     pixels + a strided slice; weights are re-creatable from the seed."""
@@ -914,7 +947,7 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
-            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16)
+            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16, generator_small1024=gen_generator_small1024)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
