@@ -220,10 +220,15 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     mask = (torch.rand(b, 1, res, res, device=dev) < 0.7).float()
     real4 = torch.cat([mask - 0.5, real], dim=1)
     L = losses.InpaintingLoss(dev, G, D, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
-    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8)
+    use_graph = world == 1 and a.graph != 'off'           # phases as HIP graphs (train_stage.PhaseGraphs); eager loop timed beside it
+    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=use_graph)
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
+    pg = ts.PhaseGraphs(phases, L, b, 512, tuple(real4.shape), dev) if use_graph else None
+    mode = {'graph': False}
 
     def iteration(idx):
+        if mode['graph']:
+            return pg.run(real4, idx)
         return ts.run_phases(real4, 512, phases, batch_idx=idx, loss=L, batch_gpu=b, device=dev)
 
     def timed(idxs):
@@ -239,6 +244,28 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     iteration(1)
     ms_main = timed([1 + (k % 3) for k in range(a.train_steps)])       # Gmain + Dmain only (batch_idx % 4 != 0)
     ms_all = timed([0])                                   # Gmain + Greg + Dmain + Dreg
+    graph_info = {'used': False}
+    if use_graph:
+        eager = (ms_main, ms_all)
+        try:
+            mode['graph'] = True
+            for _ in range(3):
+                iteration(0)                              # two eager runs of every phase inside PhaseGraphs, then the capture + first replay
+            torch.cuda.synchronize()
+            g_main = timed([1 + (k % 3) for k in range(a.train_steps)])
+            g_all = timed([0])
+            graph_info = {'used': True, 'eager_ms_per_step': round(eager[0], 2), 'eager_ms_iteration_with_both_lazy_regularisers': round(eager[1], 2),
+                          'note': 'every phase captured once as a HIP graph (train_stage.PhaseGraphs) and replayed; the eager loop '
+                                  '(Python + autograd + ctypes enqueue of ~4 500 launches per step) timed beside it'}
+            ms_main, ms_all = g_main, g_all
+        except Exception as e:
+            graph_info = {'used': False, 'error': repr(e)[:400]}
+            ms_main, ms_all = eager
+        mode['graph'] = False
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
     finite = all(bool(torch.isfinite(v).all()) for v in L.stats.values())
     cls = {}
     if rank == 0:
@@ -264,7 +291,7 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     for ph in phases:
         if ph.sync is not None:
             ph.sync.remove()
-    del G, D, L, phases
+    del G, D, L, phases, pg
     torch.cuda.empty_cache()
     # Greg runs every 4th and Dreg every 16th iteration: (ms_all - ms_main) is their joint cost in an iteration where both run
     return {'workload': f'FFHQ-512 G + D training step (Gmain + Dmain: non-saturating logistic loss, Adam), random-init, batch {b} per GPU, '
@@ -273,7 +300,7 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             'ms_iteration_with_both_lazy_regularisers': round(ms_all, 2),
             'lazy_regularisers': 'Greg (path length, batch/2) every 4th, Dreg (R1) every 16th iteration (stylegan_default.py:304-321)',
             'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
-            'grad_all_reduce': (backend if world > 1 else None), 'kernel_classes_one_step_rank0': cls,
+            'grad_all_reduce': (backend if world > 1 else None), 'hip_graph': graph_info, 'kernel_classes_one_step_rank0': cls,
             'conv_kernel_ms': round(sum(v['ms_per_step'] for k, v in cls.items() if k.startswith('conv')), 2) if cls else None}
 
 

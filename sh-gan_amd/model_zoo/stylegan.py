@@ -57,11 +57,17 @@ class _ParamCache:
     """Derived device tensors (GEMM-layout weights, host copies of scalars) keyed by the identity and
     version counter of the parameters they were computed from."""
 
+    epoch = 0          # bumped by invalidate_all(): a replayed HIP graph changes parameters without touching their version counters
+
     def __init__(self):
         self.store = {}
 
+    @classmethod
+    def invalidate_all(cls):
+        cls.epoch += 1
+
     def get(self, tag, params, builder):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        key = (_ParamCache.epoch,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         hit = self.store.get(tag)
         if hit is None or hit[0] != key:
             hit = (key, builder())
@@ -432,7 +438,14 @@ class synthesis_layer(conv2d_layer):
                                  up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1),
                                  _tail=(self.bias, ak))
             return y if residual is None else y + residual
-        ns = self._noise_strength_host() if noise is not None else 0.0
+        ns = 0.0
+        if noise is not None:
+            if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                # inside a HIP-graph capture (train_stage.PhaseGraphs: the generator's no-grad pass of Dmain) a kernel argument is
+                # frozen and a host read is illegal: the learnt strength is applied on the device instead
+                noise, ns = noise * self.noise_strength.detach(), 1.0
+            else:
+                ns = self._noise_strength_host()
         pw = self.prepped()
         if styles_sd is not None:
             s, d = styles_sd

@@ -106,6 +106,93 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
     return ran
 
 
+def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
+    """One phase of an iteration on given tensors: the inner block of ``run_phases`` (stylegan_default.py:141-166)."""
+    if phase.sync is not None:
+        phase.sync.zero_grad()
+    else:
+        phase.opt.zero_grad(set_to_none=True)
+    phase.module.requires_grad_(True)
+    if hasattr(loss, 'grad_sync'):
+        loss.grad_sync = phase.sync
+    rr, rc, gz, gc = real_img.split(eff), real_c.split(eff), gen_z.split(eff), gen_c.split(eff)
+    for round_idx in range(len(rr)):
+        loss.accumulate_gradients(phase=phase.name, real_img=rr[round_idx], real_c=rc[round_idx], gen_z=gz[round_idx], gen_c=gc[round_idx],
+                                  sync=(round_idx == len(rr) - 1), gain=phase.interval)
+    phase.module.requires_grad_(False)
+    if hasattr(loss, 'grad_sync'):
+        loss.grad_sync = None
+    if phase.sync is not None:
+        phase.sync.finish()
+        for p in phase.sync.untouched():
+            p.grad = None
+    else:
+        sanitize_(phase.module.parameters())
+    phase.opt.step()
+
+
+class PhaseGraphs:
+    """``run_phases`` with every phase captured ONCE as a HIP graph and replayed afterwards.
+
+    A G + D step of the FFHQ-512 networks is ~4 500 kernel launches (convolutions forward / backward / weight gradient, FIR, layer
+    tails, ~2 000 small elementwise kernels of autograd glue and the optimiser); the Python + autograd + ctypes path needs ~85 ms
+    to enqueue them, about what the GPU needs to run them -- the step is host-bound as soon as the kernels get faster.  A phase
+    has static shapes and no host read on the device path (style-mixing cutoff, lazy-regulariser means and the Adam step counter
+    live on the device: ``Adam(capturable=True)`` is required), so ``torch.cuda.graph`` can record zero_grad -> forward(s) ->
+    backward(s) -> gradient sanitisation -> optimiser step as one graph per phase.  Replays read the real batch and the latents
+    from static buffers that ``run`` fills first.
+
+    Parameter-derived caches (prepared weight layouts of no-grad passes) are keyed on version counters, which a replay does not
+    advance: the caches are invalidated around captures and after every replay.  Single process only (a captured RCCL
+    all-reduce is not exercised here): with more than one rank use ``run_phases``."""
+
+    def __init__(self, phases, loss, batch_gpu, z_dim, real_shape, device, effective_batch_gpu=None, warmup=2):
+        self.phases, self.loss, self.b, self.z_dim = phases, loss, batch_gpu, z_dim
+        self.device = torch.device(device)
+        self.eff = batch_gpu if effective_batch_gpu is None else effective_batch_gpu
+        self.real = torch.zeros(real_shape, device=self.device, dtype=torch.float32)
+        self.real_c = torch.zeros([batch_gpu, 0], device=self.device)
+        self.gen_c = torch.zeros([batch_gpu, 0], device=self.device)
+        self.z = {ph.name: torch.zeros([batch_gpu, z_dim], device=self.device) for ph in phases}
+        self.graphs = {}
+        self.seen = {ph.name: 0 for ph in phases}
+        self.warmup = warmup
+        for ph in phases:
+            for g in ph.opt.param_groups:
+                if not g.get('capturable', False):
+                    raise ValueError('PhaseGraphs: build the optimisers with capturable=True (the step counter must live on the device)')
+
+    def _invalidate(self):
+        from .model_zoo.stylegan import _ParamCache
+        _ParamCache.invalidate_all()
+
+    def run(self, real_img, batch_idx):
+        """One iteration; the first ``warmup`` runs of a phase are eager (allocator, lazily built constants), the next one is
+        captured.  Returns the names of the phases that ran."""
+        all_z = torch.randn([len(self.phases) * self.b, self.z_dim]).to(self.device)      # drawn on the host like the reference (:128)
+        self.real.copy_(real_img.to(self.device, torch.float32))
+        ran = []
+        for ph, z in zip(self.phases, all_z.split(self.b)):
+            if batch_idx % ph.interval != 0:
+                continue
+            self.z[ph.name].copy_(z)
+            g = self.graphs.get(ph.name)
+            if g is None and self.seen[ph.name] < self.warmup:
+                self.seen[ph.name] += 1
+                _phase_body(ph, self.loss, self.real, self.real_c, self.z[ph.name], self.gen_c, self.eff)
+            else:
+                if g is None:
+                    self._invalidate()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        _phase_body(ph, self.loss, self.real, self.real_c, self.z[ph.name], self.gen_c, self.eff)
+                    self.graphs[ph.name] = g
+                g.replay()
+                self._invalidate()
+            ran.append(ph.name)
+        return ran
+
+
 def ema_beta(batch_size, cur_nimg, ema_kimg=10.0, ema_rampup=None):
     ema_nimg = ema_kimg * 1000
     if ema_rampup is not None:

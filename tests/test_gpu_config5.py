@@ -109,7 +109,8 @@ def test_config5_full_width_phases_vs_reference_autograd():
     z = torch.from_numpy(g['z']).to(DEV)
     cnd = torch.zeros(n, 0, device=DEV)
     pl_noise = torch.from_numpy(np.random.RandomState(s_pl).standard_normal((1, 3, res, res)).astype(np.float32)).to(DEV)
-    L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+    L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2,
+                              composite_fake=False)       # the fixture fed the reference's critic the raw generator output
     L.randn_like = lambda t: pl_noise[:t.shape[0]]
     seen = {}
     run_G = L.run_G
@@ -206,7 +207,8 @@ def test_config5_fp16_blocks_full_width_vs_the_float32_reference():
     mask = torch.from_numpy(np.unpackbits(g['mask_bits'])[: n * res * res].reshape(n, 1, res, res).astype(np.float32))
     real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
     z, cnd = torch.from_numpy(g['z']).to(DEV), torch.zeros(n, 0, device=DEV)
-    L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+    L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2,
+                              composite_fake=False)       # the fixture fed the reference's critic the raw generator output
     seen = {}
     run_G = L.run_G
 

@@ -1,0 +1,97 @@
+"""The training stage's HIP-graph form (train_stage.PhaseGraphs) against the eager loop (train_stage.run_phases), and the
+composite that InpaintingLoss feeds the critic.  Reduced-width networks: the property tested is the stage, not the kernels."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def small_networks(seed):
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs
+    from shgan_amd.model_zoo import stylegan
+    G = configs.seeded_init_(configs.build_generator(256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128), seed=seed,
+                             noise_strength=0.1, bias_std=0.1).to(DEV).train().requires_grad_(False)
+    for m in G.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    torch.manual_seed(seed + 1)
+    D = stylegan.Discriminator(resolution=256, ic_n=4, ch_base=2048, ch_max=32, mbstd_group_size=4, mbstd_c_n=1).to(DEV).train().requires_grad_(False)
+    return G, D
+
+
+def real_batch(n, seed):
+    rs = np.random.RandomState(seed)
+    real = torch.from_numpy(rs.uniform(-1, 1, size=(n, 3, 256, 256)).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(size=(n, 1, 256, 256)) < 0.7).astype(np.float32))
+    return torch.cat([mask - 0.5, real], dim=1).to(DEV)
+
+
+def test_phase_graphs_follow_the_eager_loop():
+    """Six iterations (Gmain + Dmain every time, Greg at 0 / 4, Dreg at 0) from the same state: eager ``run_phases`` vs ``PhaseGraphs``
+    (two eager runs of a phase, then capture + replays).  Deterministic setting (noise_mode 'const', no style mixing, host latents from
+    a seeded generator): the replays run the same kernels on the same data, so the parameters agree to round-off."""
+    from shgan_amd import losses, train_stage as ts
+    G, D = small_networks(5)
+    g0, d0 = copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict())
+    real4 = real_batch(4, 6)
+    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=True)
+    order = [0, 1, 2, 4, 5, 8, 9]           # Greg needs three visits (two eager, one captured) before its replay at 8 is a pure replay
+    out = []
+    for graphed in (False, True):
+        G.load_state_dict(g0); D.load_state_dict(d0)
+        torch.manual_seed(11)
+        L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0)
+        phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
+        pg = ts.PhaseGraphs(phases, L, 4, 64, tuple(real4.shape), DEV) if graphed else None
+        ran = []
+        for idx in order:
+            ran.append(pg.run(real4, idx) if graphed else ts.run_phases(real4, 64, phases, batch_idx=idx, loss=L, batch_gpu=4, device=DEV))
+        torch.cuda.synchronize()
+        assert ran[0] == ['Gmain', 'Greg', 'Dmain', 'Dreg'] and ran[1] == ['Gmain', 'Dmain'] and ran[3] == ['Gmain', 'Greg', 'Dmain']
+        if graphed:
+            assert set(pg.graphs) == {'Gmain', 'Greg', 'Dmain'}        # Dreg ran once: still in its eager warm-up
+        out.append({n: p.detach().clone() for n, p in list(G.named_parameters()) + [('D.' + n, p) for n, p in D.named_parameters()]})
+        for ph in phases:
+            if ph.sync is not None:
+                ph.sync.remove()
+    worst = 0.0
+    for n in out[0]:
+        a, b = out[0][n], out[1][n]
+        assert torch.isfinite(b).all(), n
+        worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+    moved = sum(int((out[1][n] - g0[n].to(DEV)).abs().max() > 0) for n in g0 if n in out[1])
+    print(f'PhaseGraphs vs eager after {len(order)} iterations: worst relative parameter difference {worst:.2e}; {moved} G parameters moved')
+    assert worst < 1e-4 and moved > 50
+
+
+def test_inpainting_loss_composites_the_fake_with_the_known_pixels():
+    """What the critic sees for a generated image: cat([mask - 0.5, G(x) * (1 - mask) + real * mask]) (CoModGAN; the reference's
+    evaluation composite shgan_default.py:259); ``composite_fake=False`` hands it the raw output."""
+    from shgan_amd import losses
+    G, D = small_networks(7)
+    real4 = real_batch(2, 8)
+    seen = []
+
+    class Spy(torch.nn.Module):
+        def forward(self, img, c):
+            seen.append(img.detach().clone())
+            return img.mean(dim=(1, 2, 3)).reshape(-1, 1)
+    z = torch.randn(2, 64, device=DEV)
+    for comp in (True, False):
+        L = losses.InpaintingLoss(DEV, G, Spy(), noise_mode='const', style_mixing_prob=0, composite_fake=comp)
+        G.requires_grad_(True)
+        L.accumulate_gradients('Gmain', real4, torch.zeros(2, 0, device=DEV), z, torch.zeros(2, 0, device=DEV))
+        G.requires_grad_(False)
+    comp_in, raw_in = seen
+    m = real4[:, 0:1] + 0.5
+    assert torch.equal(comp_in[:, 0:1], real4[:, 0:1]) and torch.equal(raw_in[:, 0:1], real4[:, 0:1])
+    assert torch.allclose(comp_in[:, 1:4], raw_in[:, 1:4] * (1 - m) + real4[:, 1:4] * m, atol=1e-6)
+    known = m.expand(-1, 3, -1, -1) > 0
+    assert torch.equal(comp_in[:, 1:4][known], real4[:, 1:4][known])              # the known region is exactly the real image
+    assert not torch.equal(raw_in[:, 1:4][known], real4[:, 1:4][known])
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in G.synthesis.parameters())
