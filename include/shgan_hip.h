@@ -160,6 +160,12 @@ int shg_torgb_f32(const float* x, const float* w, const float* styles, const flo
 /* ---- A3/A2: dense (stylegan.py:87-98), normalize_2nd_moment (stylegan.py:343-344). */
 int shg_dense_f32(const float* x, const float* w, const float* b, float* y, int N, int K, int O, int ldx, int ldy, float wgain,
                   float bgain, int act, float alpha, float gain, float clamp, void* stream);
+/* The other two products of a dense layer under autograd (the gradients of stylegan.py:87-98; the reference reaches them through
+ * torch.addmm's backward): out[N,K] = scale * a[N,M] @ b[M,K]  and  out[M,K] = scale * a[N,M]^T @ b[N,K] with, optionally,
+ * colsum[m] = csum_scale * sum_n a[n,m] (weight and bias gradient in one pass). */
+int shg_matmul_nn_f32(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo, float scale, void* stream);
+int shg_matmul_tn_f32(const float* a, const float* b, float* out, float* colsum, int N, int M, int K, int lda, int ldb, float scale,
+                      float csum_scale, void* stream);
 int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream);
 /* ---- A4: per-forward style side of modulated_conv2d (stylegan.py:147-155):
  * s_out = styles*pre_gain*rsqrt(mean(.^2)) when demod (else styles*pre_gain); dcoef[n,o] = rsqrt(sum_i s^2*wsq[i,o] + 1e-8). */

@@ -88,6 +88,86 @@ __global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const float* 
     for (int k = threadIdx.x; k < K; k += 256) y[(long)n * K + k] = x[(long)n * K + k] * r;
 }
 
+// ---- the two other products of a dense layer's gradient (training rows: the transposed forms of stylegan.py:87-98 under autograd).
+// out[N,K] = scale * a[N,M] @ b[M,K]: block = 64 output columns x 4 slices of M (one wave each), MATN batch rows in registers per
+// pass; every b element is read once per batch slab, the a values are wave-uniform.  Partial sums of the four waves meet in LDS.
+#define MATN 8
+__global__ __launch_bounds__(256) void matmul_nn_kernel(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo,
+                                                       float scale) {
+    __shared__ float red[4][MATN][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int n0 = blockIdx.y * MATN;
+    const int nb = min(MATN, N - n0);
+    const int kc = k < K ? k : K - 1;
+    const int per = (M + 3) / 4, m0 = wave * per, m1 = min(M, m0 + per);
+    const float* ar[MATN];
+#pragma unroll
+    for (int n = 0; n < MATN; ++n) ar[n] = a + (long)(n0 + (n < nb ? n : nb - 1)) * lda;
+    float acc[MATN];
+#pragma unroll
+    for (int n = 0; n < MATN; ++n) acc[n] = 0.f;
+#pragma unroll 4
+    for (int m = m0; m < m1; ++m) {
+        const float bv = b[(long)m * K + kc];
+#pragma unroll
+        for (int n = 0; n < MATN; ++n) acc[n] += ar[n][m] * bv;
+    }
+#pragma unroll
+    for (int n = 0; n < MATN; ++n) red[wave][n][lane] = acc[n];
+    __syncthreads();
+    for (int e = threadIdx.x; e < MATN * 64; e += 256) {
+        const int n = e >> 6, l = e & 63, kk = blockIdx.x * 64 + l;
+        if (n < nb && kk < K) out[(long)(n0 + n) * ldo + kk] = scale * (red[0][n][l] + red[1][n][l] + red[2][n][l] + red[3][n][l]);
+    }
+}
+
+// out[M,K] = scale * a[N,M]^T @ b[N,K] (the weight gradient: a sum over the batch) and, optionally, colsum[m] = csum_scale * sum_n a[n,m]
+// (the bias gradient of the same layer): a thread owns 4 rows x 1 column of `out`, walks the batch.
+__global__ __launch_bounds__(256) void matmul_tn_kernel(const float* a, const float* b, float* out, float* colsum, int N, int M, int K, int lda,
+                                                       int ldb, float scale, float csum_scale) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * 4;
+    const int kc = k < K ? k : K - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+    int mm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mm[r] = m0 + r < M ? m0 + r : M - 1;
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) {
+        const float bv = b[(long)n * ldb + kc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float av = a[(long)n * lda + mm[r]];
+            acc[r] += av * bv;
+            cs[r] += av;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (m0 + r < M && k < K) out[(long)(m0 + r) * K + k] = scale * acc[r];
+        if (colsum && m0 + r < M && k == 0) colsum[m0 + r] = csum_scale * cs[r];
+    }
+}
+
+extern "C" int shg_matmul_nn_f32(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo, float scale, void* stream) {
+    SHG_CHECK_ARG(a && b && out, "matmul_nn: null pointer");
+    SHG_CHECK_ARG(N >= 1 && M >= 1 && K >= 1 && lda >= M && ldo >= K, "matmul_nn: bad shape");
+    hipLaunchKernelGGL(matmul_nn_kernel, dim3(shg_cdiv(K, 64), shg_cdiv(N, MATN)), dim3(256), 0, (hipStream_t)stream, a, b, out, N, M, K, lda, ldo, scale);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+extern "C" int shg_matmul_tn_f32(const float* a, const float* b, float* out, float* colsum, int N, int M, int K, int lda, int ldb, float scale,
+                                 float csum_scale, void* stream) {
+    SHG_CHECK_ARG(a && b && out, "matmul_tn: null pointer");
+    SHG_CHECK_ARG(N >= 1 && M >= 1 && K >= 1 && lda >= M && ldb >= K, "matmul_tn: bad shape");
+    hipLaunchKernelGGL(matmul_tn_kernel, dim3(shg_cdiv(K, 256), shg_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, colsum, N, M, K, lda, ldb,
+                       scale, csum_scale);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 extern "C" int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream) {
     SHG_CHECK_ARG(x && y && N >= 1 && K >= 1, "normalize_2nd_moment: bad arguments");
     hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, y, K, eps);

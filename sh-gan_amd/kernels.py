@@ -693,6 +693,36 @@ def dense(x, w, b=None, wgain=1.0, bgain=1.0, act=False, gain=1.0, alpha=0.2, ac
     return y
 
 
+def matmul_nn(a, b, scale=1.0):
+    """scale * a[N,M] @ b[M,K] (csrc/dense.hip: the input gradient of a dense layer)."""
+    L = _Launch()
+    a, b = L.req(a, 'a'), L.req(b, 'b')
+    n, m = a.shape
+    if b.shape[0] != m:
+        raise _lib.ShgError(f'matmul_nn: a is {tuple(a.shape)}, b is {tuple(b.shape)}')
+    k = b.shape[1]
+    out = L.new((n, k))
+    with _timed(L, 'dense', 4.0 * (a.numel() + b.numel() + out.numel())):
+        check(_lib.get_lib().shg_matmul_nn_f32(_ptr(a), _ptr(b), _ptr(out), n, m, k, a.stride(0), out.stride(0), float(scale), L.stream()), 'matmul_nn')
+    return out
+
+
+def matmul_tn(a, b, scale=1.0, colsum_scale=None):
+    """-> (scale * a[N,M]^T @ b[N,K], colsum_scale * a.sum(0) or None): weight and bias gradient of a dense layer in one pass."""
+    L = _Launch()
+    a, b = L.req(a, 'a'), L.req(b, 'b')
+    n, m = a.shape
+    if b.shape[0] != n:
+        raise _lib.ShgError(f'matmul_tn: a is {tuple(a.shape)}, b is {tuple(b.shape)}')
+    k = b.shape[1]
+    out = L.new((m, k))
+    col = L.new((m,)) if colsum_scale is not None else None
+    with _timed(L, 'dense', 4.0 * (a.numel() + b.numel() + out.numel())):
+        check(_lib.get_lib().shg_matmul_tn_f32(_ptr(a), _ptr(b), _ptr(out), _ptr(col), n, m, k, a.stride(0), b.stride(0), float(scale),
+                                               float(colsum_scale or 0.0), L.stream()), 'matmul_tn')
+    return out, col
+
+
 def normalize_2nd_moment(x, eps=1e-8):
     L = _Launch()
     x = L.req(x, 'x')

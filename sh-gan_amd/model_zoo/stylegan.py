@@ -139,7 +139,15 @@ class dense(nn.Module):
 
     def forward(self, x, out=None):
         if grad_ops.wants_grad(x, self.weight, self.bias):
-            # training rows: a plain library GEMM (torch.addmm -> rocBLAS, as stylegan.py:87-98) + the autograd bias/activation op
+            # training rows: the layer and its gradients on the dense kernels (dense_ops: x W^T, g W, g^T x -- a closed family, so the
+            # path-length regulariser's second derivative needs nothing else), both learning-rate gains folded into the kernels
+            if x.ndim == 2 and x.dtype == torch.float32:
+                from .stylegan_utils import dense_ops
+                y = dense_ops.linear(x, self.weight, self.bias, self.weight_gain, self.bias_gain)
+                ak = _act_kwargs(self.activation)
+                if ak is None:
+                    return self.activation(y)
+                return grad_ops.bias_act(y, None, **ak) if ak['act'] or ak.get('gain', 1.0) != 1.0 else y
             y = x.matmul((self.weight * self.weight_gain).t())
             ak = _act_kwargs(self.activation)
             b = None if self.bias is None else self.bias * self.bias_gain
