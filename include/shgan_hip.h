@@ -211,6 +211,11 @@ int shg_shu_spectral_f32(const float* T, const float* w0p, const float* b0, cons
  * (shgan.py:378-382).  gauss[l] = [r, r/2+1] table (shgan.py:281-310). */
 int shg_shu_split_irfft2_f32(const float* Y, const float* cw, const float* const* gauss, float* const* out,
                              const long* out_batch_stride, int N, int C, int bands, int accumulate, void* stream);
+/* Transpose of shg_shu_split_irfft2_f32 with bands == 1 (training rows: the gradient of shgan.py:326-336 w.r.t. the filtered
+ * spectrum): g[l] = dL/d(out[l]) planes [N,C,r,r] (null = none) -> GS [N,2C,64,33].  The transpose of shg_shu_rfft2_shift_f32 is
+ * shg_shu_split_irfft2_f32 itself, restricted to the 64 x 64 level with the table (1/c_k)/4096 (c_0 = c_32 = 1, else 2). */
+int shg_shu_split_adjoint_f32(const float* const* g, const long* g_batch_stride, const float* const* gauss, float* GS, int N, int C,
+                              void* stream);
 
 /* ---- A24: eval composite (lib/experiments/shgan_default.py:257-262): x4 [N,4,H,W], img [N,3,H,W] -> u8 [N,3,H,W]. */
 int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int H, int W, void* stream);

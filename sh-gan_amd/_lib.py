@@ -71,6 +71,7 @@ _SIGS = {
     'shg_conv2d_wgrad_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_shu_spectral_f32': [c_fp] * 6 + [c_i] * 4 + [c_fp],
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
+    'shg_shu_split_adjoint_f32': [c_pp, ctypes.POINTER(c_l), c_pp, c_fp, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_assemble_input_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_conv_weight_prep_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],

@@ -356,3 +356,85 @@ extern "C" int shg_shu_split_irfft2_f32(const float* Y, const float* cw, const f
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
+
+// ---- adjoint of the split stage (training rows: the gradient of shgan.py:326-336 w.r.t. the filtered spectrum).
+// out_r = irfft2( unshift( crop_r(S) * gauss_r ) ) is linear in S; with G_r = dL/dout_r its transpose is
+//   dL/dS[32 - r/2 + j][kx] += gauss_r[j][kx] * c_kx * DFT2_r(G_r)[ky][kx],   j = (ky + r/2 - 1) mod r,  c_0 = c_{r/2} = 1, else 2
+// (the c2r pass counts the interior columns twice and ignores Im of the DC / Nyquist columns -- whose adjoint terms vanish by
+// themselves: the forward DFT of a real row is real there).  One workgroup = one (sample, channel) plane; the five levels are scalar
+// DFTs from LDS (together < 1.5 MFLOP per plane; this kernel runs once per training step on 32 channels), accumulated in LDS.
+struct ShuSplitAdjParams {
+    const float* g[5];     // level l: planes [C][r][r] per sample at g[l] + n*gbs[l]; null = no gradient for that level
+    long gbs[5];
+    const float* gauss[5];
+    float* GS;             // [N, 2C, 64, 33]: Re planes, then Im planes
+    int C;
+};
+
+__global__ __launch_bounds__(256) void shu_split_adjoint_kernel(const ShuSplitAdjParams p) {
+    __shared__ float2 acc[SHU_N][SHU_NH];
+    __shared__ float2 T1[SHU_N][SHU_NH];
+    __shared__ float gl[SHU_N * SHU_N];
+    __shared__ float2 tw[SHU_N];
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    shu_build_twiddles(tw);
+    for (int e = tid; e < SHU_N * SHU_NH; e += 256) acc[e / SHU_NH][e % SHU_NH] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int l = 0; l < 5; ++l) {
+        if (!p.g[l]) continue;
+        const int r = 4 << l, rh = r / 2 + 1, tstep = SHU_N / r;
+        const float* gp = p.g[l] + (long)n * p.gbs[l] + (long)c * r * r;
+        for (int e = tid; e < r * r; e += 256) gl[e] = gp[e];
+        __syncthreads();
+        for (int e = tid; e < r * rh; e += 256) {               // along x: real -> half complex, e^{-i theta}
+            const int y = e / rh, kx = e - y * rh;
+            float re = 0.f, im = 0.f;
+            for (int x = 0; x < r; ++x) {
+                const float2 t = tw[(kx * x * tstep) & 63];
+                const float v = gl[y * r + x];
+                re += v * t.x; im -= v * t.y;
+            }
+            T1[y][kx] = make_float2(re, im);
+        }
+        __syncthreads();
+        const float* gw = p.gauss[l];
+        for (int e = tid; e < r * rh; e += 256) {               // along y: complex, e^{-i theta}; weight, shift, embed
+            const int ky = e / rh, kx = e - ky * rh;
+            float re = 0.f, im = 0.f;
+            for (int y = 0; y < r; ++y) {
+                const float2 t = tw[(ky * y * tstep) & 63];
+                const float2 v = T1[y][kx];
+                re += v.x * t.x + v.y * t.y;                     // (a + bi)(c - si)
+                im += v.y * t.x - v.x * t.y;
+            }
+            const int j = (ky + r / 2 - 1) & (r - 1);
+            const float wgt = gw[j * rh + kx] * ((kx == 0 || kx == r / 2) ? 1.f : 2.f);
+            float2& a = acc[SHU_N / 2 - r / 2 + j][kx];
+            a.x += wgt * re; a.y += wgt * im;
+        }
+        __syncthreads();
+    }
+    const long plane = SHU_N * SHU_NH;
+    float* ore = p.GS + ((long)n * 2 * p.C + c) * plane;
+    float* oim = p.GS + ((long)n * 2 * p.C + p.C + c) * plane;
+    for (int e = tid; e < plane; e += 256) {
+        const float2 a = acc[e / SHU_NH][e % SHU_NH];
+        ore[e] = a.x; oim[e] = a.y;
+    }
+}
+
+// g / g_batch_stride / gauss: arrays of 5 entries for r = 4, 8, 16, 32, 64 (g[l] may be null); GS [N, 2C, 64, 33] is overwritten.
+extern "C" int shg_shu_split_adjoint_f32(const float* const* g, const long* g_batch_stride, const float* const* gauss, float* GS, int N, int C,
+                                         void* stream) {
+    SHG_CHECK_ARG(g && g_batch_stride && gauss && GS, "shu_split_adjoint: null pointer");
+    SHG_CHECK_ARG(N >= 1 && N <= 65535 && C >= 1, "shu_split_adjoint: bad shape");
+    ShuSplitAdjParams p;
+    p.GS = GS; p.C = C;
+    for (int l = 0; l < 5; ++l) {
+        p.g[l] = g[l]; p.gbs[l] = g_batch_stride[l]; p.gauss[l] = gauss[l];
+        SHG_CHECK_ARG(!g[l] || gauss[l], "shu_split_adjoint: missing gaussian table for level %d", l);
+    }
+    hipLaunchKernelGGL(shu_split_adjoint_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}

@@ -822,6 +822,30 @@ def shu_rfft2_shift(x):
     return t
 
 
+def shu_split_adjoint(grads, gauss, n, c):
+    """Transpose of ``shu_split_irfft2`` (bands == 1): grads = 5 tensors [N,C,r,r] (r = 4..64; None = no gradient) -> [N,2C,64,33]."""
+    L = _Launch()
+    g_arr = (ctypes.c_void_p * 5)()
+    s_arr = (ctypes.c_long * 5)()
+    t_arr = (ctypes.c_void_p * 5)()
+    for l in range(5):
+        r = 4 << l
+        t_arr[l] = L.req(gauss[l], 'gauss').data_ptr()
+        g = grads[l]
+        if g is None:
+            g_arr[l] = None
+            continue
+        g = L.req(g, 'grad')
+        if tuple(g.shape) != (n, c, r, r):
+            raise _lib.ShgError(f'shu_split_adjoint: grads[{l}] must be [N,{c},{r},{r}]')
+        g_arr[l] = g.data_ptr()
+        s_arr[l] = g.stride(0)
+    out = L.new((n, 2 * c, 64, 33))
+    with _timed(L, 'shu', 4.0 * out.numel()):
+        check(_lib.get_lib().shg_shu_split_adjoint_f32(g_arr, s_arr, t_arr, _ptr(out), n, c, L.stream()), 'shu_split_adjoint')
+    return out
+
+
 def conv2d_wgrad(x, g, kh, kw, stride=1, pad=0):
     """Weight gradient of y = conv2d(x, w, stride, pad): x [NB,I,H,W], g = dL/dy [NB,O,OH,OW] -> dw [O,I,kh,kw]
     (shg_conv2d_wgrad_f32; for conv_transpose2d call it with (dL/dy, x) and read the result as [Cin,Cout,kh,kw])."""

@@ -198,6 +198,78 @@ class gaussian_heatmap_2d(object):
         return out
 
 
+def _adjoint_table(device):
+    """(1/c_k) / 4096 on [64,33], c_0 = c_32 = 1, else 2: with it the 64 x 64 level of ``shu_split_irfft2`` is the transpose of
+    ``shu_rfft2_shift`` (rfft2 with norm='forward' keeps half of a Hermitian spectrum; irfft2 counts the interior columns twice)."""
+    t = _ADJ_TABLE.get(str(device))
+    if t is None:
+        w = torch.full((64, 33), 0.5 / 4096.0)
+        w[:, 0] = w[:, 32] = 1.0 / 4096.0
+        t = _ADJ_TABLE[str(device)] = w.to(device)
+    return t
+
+
+_ADJ_TABLE = {}
+_LEVELS = (4, 8, 16, 32, 64)
+
+
+class _ShuSpectrum(torch.autograd.Function):
+    """x [N,C,64,64] -> [N,2C,64,33] (rfft2, norm='forward', rows shifted: shgan.py:313-319); backward = its transpose."""
+    @staticmethod
+    def forward(ctx, x):
+        return kernels.shu_rfft2_shift(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ShuSpectrumT.apply(g.contiguous())
+
+
+class _ShuSpectrumT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = g.detach()
+        n, c = g.shape[0], g.shape[1] // 2
+        out = torch.empty((n, c, 64, 64), device=g.device, dtype=torch.float32)
+        tab = _adjoint_table(g.device)
+        kernels.shu_split_irfft2(g, None, [tab] * 5, [None, None, None, None, out], accumulate=False)
+        return out
+
+    @staticmethod
+    def backward(ctx, gx):
+        return _ShuSpectrum.apply(gx.contiguous())
+
+
+class _ShuSplit(torch.autograd.Function):
+    """S [N,2C,64,33] -> the five hints [N,C,r,r] (crop, Gaussian split, un-shift, irfft2: shgan.py:326-336); backward = its transpose."""
+    @staticmethod
+    def forward(ctx, s, *gauss):
+        s = s.detach()
+        n, c = s.shape[0], s.shape[1] // 2
+        ctx.gauss = gauss
+        outs = [torch.empty((n, c, r, r), device=s.device, dtype=torch.float32) for r in _LEVELS]
+        kernels.shu_split_irfft2(s, None, list(gauss), outs, accumulate=False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (_ShuSplitT.apply(*[None if g is None else g.contiguous() for g in grads], *ctx.gauss),) + (None,) * 5
+
+
+class _ShuSplitT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g4, g8, g16, g32, g64, *gauss):
+        grads = [None if g is None else g.detach() for g in (g4, g8, g16, g32, g64)]
+        ctx.gauss = gauss
+        ctx.present = [g is not None for g in grads]
+        ref = next(g for g in grads if g is not None)
+        return kernels.shu_split_adjoint(grads, list(gauss), ref.shape[0], ref.shape[1])
+
+    @staticmethod
+    def backward(ctx, gs):
+        outs = _ShuSplit.apply(gs.contiguous(), *ctx.gauss)
+        return tuple(o if pr else None for o, pr in zip(outs, ctx.present)) + (None,) * 5
+
+
 class SHU(nn.Module):
     """Spectral Hint Unit (shgan.py:252-336): rFFT2 -> 1x1 conv + ReLU -> heterogeneous filter ->
     Gaussian split into a pyramid of bands -> irFFT2 per band.  x [N,C,64,64] -> {r: [N,C,r,r]}."""
@@ -261,21 +333,15 @@ class SHU(nn.Module):
         return self.df1.band_conv(t), self._cw         # [N,2C*6,64,33]
 
     def _forward_train(self, x):
-        """Training rows: shgan.py:312-336 on differentiable operators -- library FFTs (torch.fft -> rocFFT), the two 1x1
-        convolutions on the HIP conv kernels (forward / backward), everything else elementwise."""
-        sp = torch.fft.rfftn(x, dim=(2, 3), norm='forward')
-        hh = sp.shape[2]
-        sp = torch.cat([sp[:, :, hh // 2 + 1:], sp[:, :, :hh // 2 + 1]], dim=2)
-        t = self.conv0(torch.cat([sp.real, sp.imag], dim=1).contiguous(), relu=True)
-        t = self.df1(t)
-        sp = torch.complex(t[:, :self.out_channels], t[:, self.out_channels:])
-        out = {}
-        for r in self.reslist:
-            s_ = sp[:, :, self.input_res // 2 - r // 2: self.input_res // 2 + r // 2, 0: r // 2 + 1]
-            s_ = s_ * getattr(self, f'_gauss{r}')[None, None]
-            s_ = torch.cat([s_[:, :, r - r // 2 - 1:], s_[:, :, :r - r // 2 - 1]], dim=2)
-            out[r] = torch.fft.irfftn(s_, dim=(2, 3), norm='forward')
-        return out
+        """Training rows: shgan.py:312-336 on differentiable operators that are all HIP kernels -- the two transform stages through
+        ``_ShuSpectrum`` / ``_ShuSplit`` (the inference kernels forward, their transposes backward: both stages are linear maps),
+        the two 1x1 convolutions on the HIP conv kernels (forward / backward)."""
+        gauss = [getattr(self, f'_gauss{r}') for r in self.reslist]
+        t = _ShuSpectrum.apply(x.contiguous())                                   # [N,2C,64,33]: Re | Im, DC on row 31, norm='forward'
+        t = self.conv0(t, relu=True)
+        t = self.df1(t)                                                          # [N,2C,64,33], bands summed
+        outs = _ShuSplit.apply(t.contiguous(), *gauss)
+        return dict(zip(self.reslist, outs))
 
     def forward(self, x):
         if grad_ops.wants_grad(x, *self.parameters()):

@@ -228,7 +228,12 @@ def _modulation_factors(half, weight, styles, demodulate):
     if demodulate:
         weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
         styles = styles * styles.square().mean().rsqrt()                                   # :147
-        dcoefs = (styles.square().matmul(weight.square().sum([2, 3]).t()) + 1e-8).rsqrt()  # :155, [N,O]
+        wsq = weight.square().sum([2, 3])                                                  # [O, I]
+        if styles.is_cuda and styles.dtype == torch.float32 and styles.ndim == 2:
+            from .stylegan_utils import dense_ops
+            dcoefs = (dense_ops.nt(styles.square(), wsq) + 1e-8).rsqrt()                      # :155, [N,O] -- s^2 @ wsq^T on the dense kernels
+        else:
+            dcoefs = (styles.square().matmul(wsq.t()) + 1e-8).rsqrt()
     return weight, styles, dcoefs
 
 

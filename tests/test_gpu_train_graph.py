@@ -146,3 +146,62 @@ def test_dense_layer_training_route_uses_no_library_gemm():
     names = [e.key for e in prof.key_averages()]
     assert any('dense_kernel' in k for k in names) and any('matmul_tn_kernel' in k for k in names), names
     assert not any(k.startswith('Cijk_') or 'rocblas' in k.lower() for k in names), names
+
+
+def test_shu_training_route_matches_the_fft_formulation():
+    """SHU.forward under autograd (transform stages = the inference kernels + their transposes, csrc/shu.hip) against the reference's
+    formulation with torch.fft (shgan.py:312-336) evaluated in float64 on the CPU: the five hints, and the gradients of a random
+    functional w.r.t. the input and the SHU's parameters.  No rocFFT / rocBLAS kernel may run in the HIP version."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs
+    from torch.profiler import profile, ProfilerActivity
+    G = configs.seeded_init_(configs.build_generator(256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128), seed=9, bias_std=0.1)
+    shu = G.encoder.shu.to(DEV)
+    rs = np.random.RandomState(10)
+    x0 = rs.standard_normal((3, shu.conv0.weight.shape[1] // 2, 64, 64))
+    ws = {r: rs.standard_normal((3, shu.out_channels, r, r)) for r in shu.reslist}
+
+    def fft_form(x, params, gauss, cw, dt):
+        w0, b0, w1 = params
+        sp = torch.fft.rfftn(x, dim=(2, 3), norm='forward')
+        sp = torch.cat([sp[:, :, 33:], sp[:, :, :33]], dim=2)
+        t = torch.cat([sp.real, sp.imag], dim=1)
+        t = torch.relu(torch.nn.functional.conv2d(t, w0 * shu.conv0.weight_gain, b0))
+        y = torch.nn.functional.conv2d(t, w1.t()[:, :, None, None])             # df1.weight is [in, out * bands]; flat output channel = o * bands + k
+        nb = cw.shape[0]
+        y = (y.reshape(y.shape[0], -1, nb, 64, 33) * cw[None, None]).sum(2)
+        c = y.shape[1] // 2
+        sp = torch.complex(y[:, :c], y[:, c:])
+        out = {}
+        for r in shu.reslist:
+            s_ = sp[:, :, 32 - r // 2: 32 + r // 2, 0: r // 2 + 1] * gauss[r][None, None]
+            s_ = torch.cat([s_[:, :, r - r // 2 - 1:], s_[:, :, :r - r // 2 - 1]], dim=2)
+            out[r] = torch.fft.irfftn(s_, dim=(2, 3), norm='forward')
+        return out
+
+    with torch.enable_grad():
+        # float64 reference on the CPU
+        xr = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+        pr = [p.detach().cpu().double().requires_grad_(True) for p in (shu.conv0.weight, shu.conv0.bias, shu.df1.weight)]
+        gauss = {r: getattr(shu, f'_gauss{r}').cpu().double() for r in shu.reslist}
+        ref = fft_form(xr, pr, gauss, shu._cw.cpu().double(), torch.float64)
+        loss_r = sum((ref[r] * torch.tensor(ws[r])).sum() for r in shu.reslist)
+        gref = torch.autograd.grad(loss_r, [xr] + pr)
+        # HIP
+        shu.requires_grad_(True)
+        xg = torch.tensor(x0, dtype=torch.float32, device=DEV, requires_grad=True)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            got = shu(xg)
+            loss_g = sum((got[r] * torch.tensor(ws[r], dtype=torch.float32, device=DEV)).sum() for r in shu.reslist)
+            ggot = torch.autograd.grad(loss_g, [xg, shu.conv0.weight, shu.conv0.bias, shu.df1.weight])
+            torch.cuda.synchronize()
+        shu.requires_grad_(False)
+    for r in shu.reslist:
+        e = float((got[r].detach().cpu().double() - ref[r].detach()).abs().max() / ref[r].detach().abs().max())
+        assert e < 2e-5, (r, e)
+    for name, a, b in zip(('x', 'conv0.weight', 'conv0.bias', 'df1.weight'), ggot, gref):
+        e = float((a.detach().cpu().double() - b).abs().max() / b.abs().max())
+        assert e < 5e-5, (name, e)
+    names = [e.key for e in prof.key_averages()]
+    assert any('shu_split_adjoint_kernel' in k for k in names), names
+    assert not any(k.startswith('Cijk_') or ('fft' in k.lower() and not k.startswith('shu_')) for k in names), names       # (rocBLAS / rocFFT kernel names)
