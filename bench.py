@@ -221,7 +221,7 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     real4 = torch.cat([mask - 0.5, real], dim=1)
     L = losses.InpaintingLoss(dev, G, D, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
     use_graph = world == 1 and a.graph != 'off'           # phases as HIP graphs (train_stage.PhaseGraphs); eager loop timed beside it
-    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=use_graph)
+    kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=use_graph, fused=True)     # one multi-tensor kernel per optimiser step
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
     pg = ts.PhaseGraphs(phases, L, b, 512, tuple(real4.shape), dev) if use_graph else None
     mode = {'graph': False}

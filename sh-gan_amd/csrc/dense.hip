@@ -89,25 +89,26 @@ __global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const float* 
 }
 
 // ---- the two other products of a dense layer's gradient (training rows: the transposed forms of stylegan.py:87-98 under autograd).
-// out[N,K] = scale * a[N,M] @ b[M,K]: block = 64 output columns x 4 slices of M (one wave each), MATN batch rows in registers per
-// pass; every b element is read once per batch slab, the a values are wave-uniform.  Partial sums of the four waves meet in LDS.
+// out[N,K] = scale * a[N,M] @ b[M,K]: block = 64 output columns x MATW slices of M (one wave each), MATN batch rows in registers per
+// pass; every b element is read once per batch slab, the a values are wave-uniform.  Partial sums of the waves meet in LDS.
 #define MATN 8
-__global__ __launch_bounds__(256) void matmul_nn_kernel(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo,
-                                                       float scale) {
-    __shared__ float red[4][MATN][64];
+#define MATW 16           // waves per block = slices of M (a 1536-long sum becomes 96 steps per wave: the kernel is latency-bound, not bandwidth-bound)
+__global__ __launch_bounds__(64 * MATW) void matmul_nn_kernel(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo,
+                                                             float scale) {
+    __shared__ float red[MATW][MATN][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane;
     const int n0 = blockIdx.y * MATN;
     const int nb = min(MATN, N - n0);
     const int kc = k < K ? k : K - 1;
-    const int per = (M + 3) / 4, m0 = wave * per, m1 = min(M, m0 + per);
+    const int per = (M + MATW - 1) / MATW, m0 = wave * per, m1 = min(M, m0 + per);
     const float* ar[MATN];
 #pragma unroll
     for (int n = 0; n < MATN; ++n) ar[n] = a + (long)(n0 + (n < nb ? n : nb - 1)) * lda;
     float acc[MATN];
 #pragma unroll
     for (int n = 0; n < MATN; ++n) acc[n] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int m = m0; m < m1; ++m) {
         const float bv = b[(long)m * K + kc];
 #pragma unroll
@@ -116,9 +117,12 @@ __global__ __launch_bounds__(256) void matmul_nn_kernel(const float* a, const fl
 #pragma unroll
     for (int n = 0; n < MATN; ++n) red[wave][n][lane] = acc[n];
     __syncthreads();
-    for (int e = threadIdx.x; e < MATN * 64; e += 256) {
+    for (int e = threadIdx.x; e < MATN * 64; e += 64 * MATW) {
         const int n = e >> 6, l = e & 63, kk = blockIdx.x * 64 + l;
-        if (n < nb && kk < K) out[(long)(n0 + n) * ldo + kk] = scale * (red[0][n][l] + red[1][n][l] + red[2][n][l] + red[3][n][l]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < MATW; ++w) v += red[w][n][l];
+        if (n < nb && kk < K) out[(long)(n0 + n) * ldo + kk] = scale * v;
     }
 }
 
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void matmul_tn_kernel(const float* a, const fl
 extern "C" int shg_matmul_nn_f32(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo, float scale, void* stream) {
     SHG_CHECK_ARG(a && b && out, "matmul_nn: null pointer");
     SHG_CHECK_ARG(N >= 1 && M >= 1 && K >= 1 && lda >= M && ldo >= K, "matmul_nn: bad shape");
-    hipLaunchKernelGGL(matmul_nn_kernel, dim3(shg_cdiv(K, 64), shg_cdiv(N, MATN)), dim3(256), 0, (hipStream_t)stream, a, b, out, N, M, K, lda, ldo, scale);
+    hipLaunchKernelGGL(matmul_nn_kernel, dim3(shg_cdiv(K, 64), shg_cdiv(N, MATN)), dim3(64 * MATW), 0, (hipStream_t)stream, a, b, out, N, M, K, lda, ldo, scale);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -46,6 +46,74 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return y.reshape(n, -1, *y.shape[2:])
 
 
+def _fusable(x, w, f, groups):
+    """float32 training rows whose resampling layer has the model's shape: 3x3 weights, the 4x4 low-pass, one group."""
+    return (x.dtype == torch.float32 and x.is_cuda and groups == 1 and tuple(w.shape[2:]) == (3, 3) and f is not None and f.ndim == 2
+            and tuple(f.shape) == (4, 4) and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+            and x.shape[0] * max(w.shape[0], w.shape[1]) <= 65535)
+
+
+class _UpConvFirFn(torch.autograd.Function):
+    """The up path of conv2d_resample.py:122-142 for float32 training rows as ONE autograd node: transposed convolution as four phase
+    planes (polyphase-Winograd kernel) -> FIR straight from the planes (``upfir_planar``, the pair the inference route uses).  The
+    generic composition interleaved the planes into the (2H+1)^2 image only for the FIR to read it back (``planes_to_image``: 5.7 ms
+    of a 170 ms float32 step).  Backward = the composition of the public differentiable operators (FIR transpose, strided
+    convolution, weight gradient with the tensors exchanged: conv2d_gradfix.py:118-146), so second derivatives keep working."""
+    @staticmethod
+    def forward(ctx, x, wt, f, flip_filter):
+        ctx.save_for_backward(x, wt, f)
+        ctx.flip = flip_filter
+        pw = kernels.conv_weight_prep(wt.detach().transpose(0, 1).contiguous())
+        mid = kernels.conv2d(x.detach().contiguous(), pw, mode=kernels.MODE_UP2T, planar=True)
+        return kernels.upfir_planar(mid, f, fir_gain=4.0, flip=flip_filter)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wt, f = ctx.saved_tensors
+        n, _, h, w = x.shape
+        g_mid = upfirdn2d.upfirdn2d_backward(gy.contiguous(), f, (n, wt.shape[1], 2 * h + 1, 2 * w + 1), padding=[1, 1, 1, 1],
+                                             flip_filter=ctx.flip, gain=4)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = conv2d_gradfix.conv2d(g_mid, wt, stride=2, padding=0)
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            gw = conv2d_gradfix._WgradFn.apply(x, g_mid, 3, 2, 0)
+        return gx, gw, None, None
+
+
+class _FirDownConvFn(torch.autograd.Function):
+    """The down path (conv2d_resample.py:116-120: pad-2 low-pass, then the stride-2 convolution) for float32 training rows as one
+    node.  Forward: the two kernels as before.  First-order backward: the input gradient is conv_transpose2d followed by the FIR's
+    transpose -- exactly the phase-plane pair of the up path with gain 1 -- instead of planes -> interleaved image -> same-size FIR."""
+    @staticmethod
+    def forward(ctx, x, w, f, flip_filter):
+        xf = upfirdn2d.upfirdn2d(x.detach(), f, padding=[2, 2, 2, 2], flip_filter=flip_filter)
+        ctx.save_for_backward(xf, w, f)
+        ctx.cfg = (tuple(x.shape), flip_filter)
+        return conv2d_gradfix.conv2d(xf, w.detach(), stride=2, padding=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        xf, w, f = ctx.saved_tensors
+        x_shape, flip = ctx.cfg
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if torch.is_grad_enabled():          # create_graph: compose the differentiable operators
+                gm = conv2d_gradfix._conv_input_grad(g, w, xf.shape, 2, 0)
+                gx = upfirdn2d.upfirdn2d_backward(gm, f, x_shape, padding=[2, 2, 2, 2], flip_filter=flip, gain=1)
+            else:
+                pw = kernels.conv_weight_prep(w.detach().transpose(0, 1).contiguous())
+                mid = kernels.conv2d(g, pw, mode=kernels.MODE_UP2T, planar=True)
+                gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip)
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            gw = conv2d_gradfix._WgradFn.apply(g, xf, 3, 2, 0)
+        return gx, gw, None, None
+
+
+FUSED_TRAIN_RESAMPLE = True      # (A/B switch for the two nodes above)
+
+
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
     """x [N,C,H,W], w [O, C/groups, kh, kw], f from ``upfirdn2d.setup_filter`` (None = identity).
     Padding is given with respect to the upsampled image and applied once, up front."""
@@ -78,11 +146,18 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=pads, gain=up ** 2, flip_filter=flip_filter)
     if down > 1 and up == 1:                     # low-pass, then strided convolution
+        if (FUSED_TRAIN_RESAMPLE and down == 2 and pads == [2, 2, 2, 2] and _fusable(x, w, f, groups) and x.shape[2] % 2 == 0
+                and x.shape[3] % 2 == 0):
+            return _FirDownConvFn.apply(x, w if flip_weight else w.flip([2, 3]), f, flip_filter)
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=pads, flip_filter=flip_filter)
         return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
     if up > 1:                                   # transposed strided convolution, then low-pass
         px0, px1, py0, py1 = px0 - (kw - 1), px1 - (kw - up), py0 - (kh - 1), py1 - (kh - up)
         pxt, pyt = max(min(-px0, -px1), 0), max(min(-py0, -py1), 0)
+        if (FUSED_TRAIN_RESAMPLE and up == 2 and down == 1 and pxt == 0 and pyt == 0 and [px0, px1, py0, py1] == [1, 1, 1, 1]
+                and _fusable(x, w, f, groups)):
+            wg = w.flip([2, 3]) if flip_weight else w           # (_conv2d_wrapper is called with flip_weight negated for the transposed form)
+            return _UpConvFirFn.apply(x, wg.transpose(0, 1), f, flip_filter)
         x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True,
                             flip_weight=(not flip_weight))
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2,
