@@ -55,12 +55,31 @@ def _fit(y, h, w, lo):
     return _dense(y)
 
 
+THIN_1X1 = True                      # (A/B switch: thin 1x1 convolutions on the pointwise kernels)
+_ONES = {}
+
+
+def _ones(n, i, device):
+    t = _ONES.get((n, i, str(device)))
+    if t is None:
+        t = _ONES[(n, i, str(device))] = torch.ones(n, i, device=device)
+    return t
+
+
 def _conv_fwd(x, weight, bias, stride, padding, groups):
     if x.dtype == torch.float16:             # the reference's fp16 blocks (stylegan.py:486,660-667): NHWC fp16-MFMA kernels, fp32 accumulation
         if groups != 1:
             raise NotImplementedError('conv2d: grouped fp16 convolutions (the fused N=1 form, stylegan.py:187-190) are not built; fp16 layers run the non-fused algebra')
         return kernels_f16.conv2d(x, weight.to(torch.float16), bias, stride, padding)
     n, c, h, w = x.shape
+    if THIN_1X1 and groups == 1 and stride == 1 and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and n <= 65535:
+        # thin 1x1 convolutions (RGB branch: 64 -> 3 and its input gradient 3 -> 64; fromrgb 4 -> 64 and back): HBM-bound pointwise
+        # kernels instead of the MFMA kernel with 3 of its 64 output (or 32 input) lanes in use
+        o, i = weight.shape[0], weight.shape[1]
+        if o <= 4 and 16 * i + 4096 <= 65536:
+            return kernels.torgb(x, weight.reshape(o, i), styles=_ones(n, i, x.device), bias=bias)
+        if i <= 8 and (h * w) % 4 == 0:
+            return kernels.conv1x1_thin_in(x, weight.reshape(o, i), bias, act=False)
     pw = kernels.conv_weight_prep(weight, groups=groups)
     y = kernels.conv2d(x.reshape(n * groups, c // groups, h, w), pw, mode=kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2,
                        pad=padding, bias=(bias if groups == 1 else None))

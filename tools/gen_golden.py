@@ -618,6 +618,65 @@ def _sampled(gn, k=512):
     return gn if gn.size <= 2 * k else np.concatenate([gn[:k], gn[-k:]])
 
 
+def gen_generator_grads64():
+    """The first functional of ``gen_generator_grads`` (sum(img * r) / N) once more with the reference's modules redirected to FLOAT64 (the
+    ``torch.float32`` casts hard-wired in stylegan.py:403,486,517,567 / comodgan.py:43,238,305,337,398 read ``torch.float64``): the
+    yardstick for the round-off of the float32 golden itself.  Stored like the float32 gradients (first / last 2048 entries)."""
+    import copy
+    cfg = dict(resolution=256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = build_reference_generator(**cfg)
+    sd = orc.init_state_dict(256, seed=41, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    real_u8, mask, z = synth_inputs(2, 256, 64, seed=42)
+    x = assemble_x(real_u8, mask)
+    r = np.random.RandomState(43).standard_normal((2, 3, 256, 256)).astype(np.float32)
+
+    class _Torch64:
+        float32 = torch.float64
+
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+    mods = [stylegan, comodgan, shgan, ref_utils, ref_ufd, ref_c2r]
+    saved = [m_.torch for m_ in mods]
+    out = {}
+    try:
+        for m_ in mods:
+            m_.torch = _Torch64()
+        G64 = copy.deepcopy(G).double().eval().requires_grad_(True)
+        with torch.enable_grad():
+            zt = torch.from_numpy(z).double().requires_grad_(True)
+            img = G64(x=x.double(), z=zt, c=torch.zeros(2, 0, dtype=torch.float64), noise_mode='const')
+            assert img.dtype == torch.float64
+            ((img * torch.from_numpy(r).double()).sum() / 2).backward()
+        out['grad__z'] = zt.grad.numpy()
+        for n_, p_ in G64.named_parameters():
+            gn = p_.grad.reshape(-1).numpy()
+            out['grad__' + n_] = gn if gn.size <= 4096 else np.concatenate([gn[:2048], gn[-2048:]])
+        # the path-length functional of gen_generator_grads (second order), same draws
+        G64.zero_grad()
+        rs_ = np.random.RandomState(43)
+        rs_.standard_normal((2, 3, 256, 256))
+        pl_noise = torch.from_numpy(rs_.standard_normal((2, 3, 256, 256)).astype(np.float32) / np.sqrt(256 * 256)).double()
+        with torch.enable_grad():
+            ws = G64.mapping(torch.from_numpy(z).double(), torch.zeros(2, 0, dtype=torch.float64))
+            xg, feats = G64.encoder(x.double())
+            img = G64.synthesis(xg, feats, ws, noise_mode='const')
+            pl_grads = torch.autograd.grad(outputs=[(img * pl_noise).sum()], inputs=[ws], create_graph=True, only_inputs=True)[0]
+            pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+            ((img[:, 0, 0, 0] * 0 + pl_lengths.square() * 2.0).mean()).backward()
+        out['pl_lengths'] = pl_lengths.detach().numpy()
+        for n_, p_ in G64.named_parameters():
+            if p_.grad is None:
+                continue
+            gn = p_.grad.reshape(-1).numpy()
+            out['plgrad__' + n_] = gn if gn.size <= 4096 else np.concatenate([gn[:2048], gn[-2048:]])
+    finally:
+        for m_, t_ in zip(mods, saved):
+            m_.torch = t_
+    save('generator_grads64', **out)
+
+
 def gen_config5_step():
     """BASELINE config 5 at FULL width (FFHQ-512: ch_base 32768, ch_max 512, w/z 512, w0 1024; discriminator 512, ic_n 4), batch 2:
     the four phases of stylegan_default_loss.py:53-128 -- Gmain :56-66, Dmain :94-127 (Dgen + Dreal), Dreg (R1, gamma 10) :118-124,
@@ -947,7 +1006,8 @@ GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modcon
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
-            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16, generator_small1024=gen_generator_small1024)
+            discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16, generator_small1024=gen_generator_small1024,
+            generator_grads64=gen_generator_grads64)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
