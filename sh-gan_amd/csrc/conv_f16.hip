@@ -1114,6 +1114,8 @@ static int conv2d_f16_impl(const void* x, const void* w, const float* bias, void
     SHG_CHECK_ARG(x && w && y, "conv2d_f16: null pointer");
     SHG_CHECK_ARG(N >= 1 && I >= 32 && (I % 32) == 0 && O >= 1 && H >= 1 && W >= 1, "conv2d_f16: bad shape (I must be a multiple of 32)");
     SHG_CHECK_ARG((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= k, "conv2d_f16: 1x1 / 3x3 kernels, stride 1 / 2");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                  "conv2d_f16: x, w and y must be 16-byte aligned (vector loads / stores)");
     f16::ConvP p{};
     p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = bias; p.y = (_Float16*)y;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OHt = OH; p.OWt = OW;
@@ -1340,6 +1342,7 @@ extern "C" int shg_bias_act_backward_f16(const void* g, const void* y, void* dx,
 extern "C" int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C,
                                int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(t && y && N >= 1 && HW >= 1 && C >= 8 && (C % 8) == 0, "modtail_f16: bad arguments (C must be a multiple of 8)");
+    SHG_CHECK_ARG(HW < 2147483647L, "modtail_f16: H*W must fit 31 bits");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
                   "modtail_f16: t, y, d and bias must be 16-byte aligned");
     f16::TailP p{};
@@ -1364,6 +1367,9 @@ extern "C" int shg_modtail_backward_f16_blocks(long HW, int C) {
 extern "C" int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, void* gt, float* part, float* gnoise, int N,
                                         long HW, int C, int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(gy && y && gt && N >= 1 && HW >= 1, "modtail_backward_f16: null pointer / empty");
+    SHG_CHECK_ARG(HW < 2147483647L, "modtail_backward_f16: H*W must fit 31 bits");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gt) |
+                    reinterpret_cast<uintptr_t>(d)) & 15) == 0, "modtail_backward_f16: gy, y, t, gt and d must be 16-byte aligned (vector accesses)");
     const int c8n = C / 8;
     SHG_CHECK_ARG(C >= 8 && (C % 8) == 0 && c8n <= 64 && (c8n & (c8n - 1)) == 0, "modtail_backward_f16: C/8 must be a power of two <= 64");
     f16::TailP p{};

@@ -37,6 +37,7 @@ class BucketedAllReduce:
         self._hooks = []
         self._touched = set()      # id(param) of the parameters that received a gradient since zero_grad()
         self._armed = False        # True only inside the LAST backward pass of a phase (arm())
+        self._armed_once = False   # arm() seen since zero_grad()
         cap = max(int(bucket_bytes) // 4, 1)
         cur, cur_n = [], 0
         groups = []
@@ -93,6 +94,7 @@ class BucketedAllReduce:
         self._handles = []
         self._touched = set()
         self._armed = False
+        self._armed_once = False
 
     def arm(self):
         """Announce the last backward pass of the phase (the reference's ``sync=True`` forward under ``misc.ddp_sync``): from now on
@@ -101,7 +103,12 @@ class BucketedAllReduce:
         if self._armed:
             raise RuntimeError('BucketedAllReduce.arm(): already armed -- finish() must run between two armed backward passes')
         self._armed = True
+        self._armed_once = True
         self._pending = list(self._sizes)
+
+    def was_armed(self):
+        """True if ``arm()`` was called since the last ``zero_grad()`` / ``finish()``."""
+        return self._armed or self._armed_once
 
     def untouched(self):
         """Parameters that received no gradient since ``zero_grad()`` -- their bucket slots hold zeros; an optimiser that must skip

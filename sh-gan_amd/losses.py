@@ -20,6 +20,12 @@ PHASES = ('Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth')
 
 
 class Loss:
+    """Contract with the training stage (train_stage.run_phases): one call per phase and round.  ``sync=True`` marks the phase's last
+    round; the implementation must call ``self.grad_sync.arm()`` (when ``grad_sync`` is not None) right before the LAST ``backward()`` of
+    that call and before no other -- the buckets then all-reduce under that backward pass.  Without it the gradients are still reduced
+    (synchronously, in ``finish()``) and the stage says so once."""
+    grad_sync = None
+
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
         raise NotImplementedError()
 

@@ -46,6 +46,16 @@ def _act_kwargs(act_obj, gain=1.0):
     return None
 
 
+def _act_generic(y, ak):
+    """lrelu_agc from its kwargs with tensor ops (any dtype / channel count): common/utils.py:135-143."""
+    g = float(ak.get('gain', 1.0))
+    if ak.get('act'):
+        y = torch.nn.functional.leaky_relu(y, float(ak['alpha'])) * (float(ak['act_gain']) * g)
+        c = ak.get('clamp')
+        return y if c is None else y.clamp(-float(c) * g, float(c) * g)
+    return y * g if g != 1.0 else y
+
+
 def _add(a, b):
     """a + b: one fused kernel on the inference path, a differentiable tensor op on the training path."""
     if grad_ops.generic_route(a, b):
@@ -283,6 +293,12 @@ def _modulated_conv2d_train(x, weight, styles, noise, up, down, padding, resampl
         if FUSED_F16_TAIL and grad_ops.modtail_supported(x) and ak is not None:
             return grad_ops.modconv_tail(x, d=dcoefs, noise=noise, bias=bias, **ak)
         y = _modulated_tail_unfused(x, n, dcoefs, noise, demodulate)
+        if ak is None or (y.dtype == torch.float16 and y.shape[1] % 8):
+            # activation objects the kernels do not know, and half tensors whose channel count is no multiple of 8 (custom widths: the
+            # fp16 kernels move 8 channels per lane): the per-operation form, as conv2d_layer._forward_train does
+            if bias is not None:
+                y = y + bias.view(1, -1, 1, 1).to(y.dtype)
+            return y if ak is None else _act_generic(y, ak)
         return grad_ops.bias_act(y, bias, **ak)
     return _modulated_tail_unfused(x, n, dcoefs, noise, demodulate)
 

@@ -54,6 +54,21 @@ def make_phases(G, D, g_opt_kwargs, d_opt_kwargs, g_reg_interval=4, d_reg_interv
     return phases
 
 
+_WARNED = set()
+
+
+def _warn_unarmed(loss, phase):
+    """The overlap of the gradient all-reduce with backward depends on the loss announcing the phase's LAST backward pass
+    (``loss.grad_sync.arm()``, as StyleGAN2Loss._arm does for sync=True); a Loss that never does gets correct gradients, reduced
+    bucket by bucket after backward.  Said once per loss class."""
+    key = (type(loss).__name__, phase.name)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(f'{type(loss).__name__} did not arm the gradient buckets in phase {phase.name}: the all-reduce runs after backward '
+                      'instead of under it (call self.grad_sync.arm() before the last backward of a phase call with sync=True)')
+
+
 def sanitize_(params):
     """``misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)`` of stylegan_default.py:160-164."""
     for p in params:
@@ -94,6 +109,8 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
         if hasattr(loss, 'grad_sync'):
             loss.grad_sync = None
         if phase.sync is not None:
+            if phase.sync.reduce and not phase.sync.was_armed():
+                _warn_unarmed(loss, phase)               # correct, but every bucket is reduced synchronously in finish(): no overlap
             phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
             for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them
                 p.grad = None
@@ -123,6 +140,8 @@ def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
     if hasattr(loss, 'grad_sync'):
         loss.grad_sync = None
     if phase.sync is not None:
+        if phase.sync.reduce and not phase.sync.was_armed():
+            _warn_unarmed(loss, phase)
         phase.sync.finish()
         for p in phase.sync.untouched():
             p.grad = None

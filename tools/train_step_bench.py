@@ -31,8 +31,8 @@ for m in G.modules():                         # dropout of the encoder epilogue 
         m.p = 0.0
 D = stylegan.Discriminator(resolution=a.resolution, ic_n=4, ch_base=32768, ch_max=512, use_fp16_before_res=(32 if a.fp16 else None),
                            mbstd_group_size=4, mbstd_c_n=1).to(dev).train()
-optG = torch.optim.Adam(G.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8)
-optD = torch.optim.Adam(D.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8)
+optG = torch.optim.Adam(G.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8, fused=True)
+optD = torch.optim.Adam(D.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8, fused=True)
 syncG, syncD = BucketedAllReduce(G.parameters()), BucketedAllReduce(D.parameters())
 x, z, _, _ = eval_harness.synthetic_batch(a.batch, a.resolution, 512, seed=1, device=dev, masks='bernoulli')
 real = torch.randn(a.batch, 3, a.resolution, a.resolution, device=dev).clamp(-1, 1)
