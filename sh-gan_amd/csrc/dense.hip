@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const float* 
 __global__ __launch_bounds__(64 * MATW) void matmul_nn_kernel(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo,
                                                              float scale) {
     __shared__ float red[MATW][MATN][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (provably uniform: the a values become scalar loads)
     const int k = blockIdx.x * 64 + lane;
     const int n0 = blockIdx.y * MATN;
     const int nb = min(MATN, N - n0);
