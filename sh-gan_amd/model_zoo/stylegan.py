@@ -249,6 +249,29 @@ def _modulation_factors(half, weight, styles, demodulate):
 
 F16_INFER_FUSED = True       # half layers without autograd: modulation / tail fused into the fp16 convolution (False: the composed route)
 
+# ---- the one place that decides which implementation a layer call takes ---------------------------------------------------------
+#   'f32_fused'   float32 activations, no gradient requested: the fused inference kernels (weights prepared once per parameter version,
+#                 styles / demodulation / noise / bias / lrelu_agc / skip-add inside the convolution or FIR kernel)
+#   'f16_fused'   float16 activations (a `use_fp16` block), no gradient requested: the same fusion on the NHWC fp16-MFMA kernels
+#   'generic'     a gradient is requested (training rows: the differentiable operators of stylegan_utils, first and second order), or a
+#                 float16 call with F16_INFER_FUSED switched off
+# ROUTE_TRACE: set to a list to record (module class, route, dtype, activation shape) per layer call -- "which kernel family ran"
+# without a profiler (tests/test_gpu_fp16.py, tools/).
+ROUTE_TRACE = None
+
+
+def layer_route(module, x, *tensors):
+    half = isinstance(x, torch.Tensor) and x.dtype == torch.float16
+    if grad_ops.wants_grad(x, *tensors):
+        route = 'generic'
+    elif half:
+        route = 'f16_fused' if F16_INFER_FUSED else 'generic'
+    else:
+        route = 'f32_fused'
+    if ROUTE_TRACE is not None:
+        ROUTE_TRACE.append((type(module).__name__, route, str(x.dtype).replace('torch.', ''), tuple(x.shape)))
+    return route
+
 
 def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual):
     """Inference route of a float16 modulated layer (no autograd): the same algebra as ``_modulated_conv2d_train`` with the passes fused
@@ -374,11 +397,12 @@ class conv2d_layer(nn.Module):
         return None
 
     def forward(self, x, gain=1):
-        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, self.weight, self.bias):
+        route = layer_route(self, x, self.weight, self.bias)
+        if route == 'f16_fused':
             y = self._forward_half_infer(x, gain)
             if y is not None:
                 return y
-        if grad_ops.generic_route(x, self.weight, self.bias):
+        if route != 'f32_fused':                 # 'generic', or a half geometry the fused half route does not serve
             return self._forward_train(x, gain)
         ak = _act_kwargs(self.activation, gain)
         b = self.bias.detach() if self.bias is not None else None
@@ -455,12 +479,13 @@ class synthesis_layer(conv2d_layer):
         ak = _act_kwargs(self.activation, gain)
         if ak is None or self.up not in (1, 2) or self.weight.shape[2] != 3:
             raise NotImplementedError('synthesis_layer: HIP path needs lrelu_agc, 3x3 kernels and up in {1,2}')
-        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, residual):
+        route = layer_route(self, x, w, self.weight, self.bias, self.affine.weight, residual)
+        if route == 'f16_fused':
             y = _modulated_conv2d_half_infer(x, self.weight.detach(), self.affine(w), None if noise is None else noise * self.noise_strength.detach(),
                                              self.up, self.padding, self.resample_filter, True, self.up == 1, self.bias.detach(), ak, residual)
             if y is not None:
                 return y
-        if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight):
+        if route != 'f32_fused':
             # training rows and float16 layers (stylegan.py:276-304): styles from the affine layer, noise scaled by its learnt strength, the
             # non-fused modulated convolution, bias + activation; the skip tensor (extension) is added last
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w), noise=None if noise is None else noise * self.noise_strength,
@@ -501,12 +526,13 @@ class torgb_layer(conv2d_layer):
     def forward(self, x, w, fused_modconv=True, base_img=None, base_filter=None, styles_sd=None):
         if self.activation is not None or self.weight.shape[2] != 1 or self.weight.shape[0] > 4:
             raise NotImplementedError('torgb_layer: HIP path is the 1x1, <=4-channel, linear form')
-        if F16_INFER_FUSED and x.dtype == torch.float16 and not grad_ops.wants_grad(x, w, self.weight, self.bias, self.affine.weight, base_img):
+        route = layer_route(self, x, w, self.weight, self.bias, self.affine.weight, base_img)
+        if route == 'f16_fused':
             from .. import kernels_f16
             y = kernels_f16.conv2d(x, self.weight.detach().to(torch.float16), self.bias.detach(), 1, 0, in_scale=self.affine(w) * self.weight_gain)
             y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
-        if grad_ops.generic_route(x, w, self.weight, self.bias, self.affine.weight, base_img):
+        if route != 'f32_fused':
             # training rows and float16 blocks (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338);
             # the RGB branch itself is float32 (`y.to(torch.float32)`, comodgan.py:337)
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w) * self.weight_gain, demodulate=False)

@@ -208,3 +208,38 @@ def test_shu_training_route_matches_the_fft_formulation():
     names = [e.key for e in prof.key_averages()]
     assert any('shu_split_adjoint_kernel' in k for k in names), names
     assert not any(k.startswith('Cijk_') or ('fft' in k.lower() and not k.startswith('shu_')) for k in names), names       # (rocBLAS / rocFFT kernel names)
+
+
+def test_layer_routes_are_decided_in_one_place_and_traceable():
+    """``stylegan.layer_route`` is the single dispatcher of the layer classes; ``ROUTE_TRACE`` records what every call took: float32 under
+    no_grad -> the fused inference kernels, gradients requested -> the differentiable operators, fp16 blocks under no_grad -> the fused
+    half kernels."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs
+    from shgan_amd.model_zoo import stylegan
+    G = configs.seeded_init_(configs.build_generator(256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128), seed=1).to(DEV).eval()
+    G16 = configs.seeded_init_(configs.build_generator(256, ch_base=4096, ch_max=64, w_dim=64, z_dim=64, w0_dim=128, use_fp16_before_res=64,
+                                                       use_fp16_after_res=32), seed=1).to(DEV).eval().requires_grad_(False)
+    x = real_batch(2, 3)
+    z = torch.randn(2, 64, device=DEV)
+    cnd = torch.zeros(2, 0, device=DEV)
+    try:
+        stylegan.ROUTE_TRACE = []
+        G.requires_grad_(False)
+        G(x=x, z=z, c=cnd, noise_mode='const')
+        infer = stylegan.ROUTE_TRACE
+        stylegan.ROUTE_TRACE = []
+        G.requires_grad_(True)
+        with torch.enable_grad():
+            G(x=x, z=z, c=cnd, noise_mode='const')
+        train = stylegan.ROUTE_TRACE
+        stylegan.ROUTE_TRACE = []
+        G16(x=x, z=z, c=cnd, noise_mode='const')
+        half = stylegan.ROUTE_TRACE
+    finally:
+        stylegan.ROUTE_TRACE = None
+        G.requires_grad_(False)
+    assert len(infer) > 30 and {r for _, r, _, _ in infer} == {'f32_fused'}
+    assert len(train) == len(infer) and {r for _, r, _, _ in train} == {'generic'}
+    routes16 = {(r, d) for _, r, d, _ in half}
+    assert ('f16_fused', 'float16') in routes16 and ('f32_fused', 'float32') in routes16 and not any(r == 'generic' for r, _ in routes16)
