@@ -62,6 +62,25 @@ def _taps_weight(L, w_oihw, i_mult):
     return wp
 
 
+class PackedWeight:
+    """A convolution weight already in MFMA operand order (``pack_weight``): what ``conv2d`` / ``conv_transpose2d`` build per call from a
+    [O,I,k,k] half tensor.  The no-grad route of the modules caches one per parameter version."""
+    __slots__ = ('wp', 'o', 'i', 'k')
+
+    def __init__(self, wp, o, i, k):
+        self.wp, self.o, self.i, self.k = wp, o, i, k
+
+
+def pack_weight(weight, transposed=False):
+    """weight [O,I,k,k] halves (``transposed``: the torch conv_transpose2d layout [Cin,Cout,3,3]) -> PackedWeight."""
+    if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
+        raise _lib.ShgError('pack_weight: weight must be float16 [O,I,k,k] with k = 1 or 3')
+    L = kernels._Launch()
+    L._own(weight, 'weight')
+    w = weight.detach().transpose(0, 1) if transposed else weight.detach()
+    return PackedWeight(_taps_weight(L, w, 32), w.shape[0], w.shape[1], w.shape[2])
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, in_scale=None, out_scale=None, noise=None, noise_strength=1.0, act=None, gain=1.0,
            alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0, residual=None):
     """F.conv2d(x, weight, bias, stride, padding) on halves: x [N,I,H,W], weight [O,I,k,k] (k = 1 | 3) -> [N,O,OH,OW].
@@ -70,18 +89,22 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, in_scale=None, out_scale=N
     y = A(conv * out_scale + noise + bias) + residual in the store pass."""
     L = kernels._Launch()
     x = _h(L, x, 'x')
-    if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
-        raise _lib.ShgError('conv2d_f16: weight must be float16 [O,I,k,k] with k = 1 or 3')
-    if weight.shape[1] != x.shape[1]:
-        raise _lib.ShgError(f'conv2d_f16: weight expects {weight.shape[1]} input channels, x has {x.shape[1]}')
-    L._own(weight, 'weight')
+    packed = weight if isinstance(weight, PackedWeight) else None
+    if packed is None:
+        if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
+            raise _lib.ShgError('conv2d_f16: weight must be float16 [O,I,k,k] with k = 1 or 3')
+        L._own(weight, 'weight')
+    wo, wi, k = (packed.o, packed.i, packed.k) if packed is not None else (weight.shape[0], weight.shape[1], weight.shape[2])
+    if wi != x.shape[1]:
+        raise _lib.ShgError(f'conv2d_f16: weight expects {wi} input channels, x has {x.shape[1]}')
     n, i, h, w = x.shape
-    o, k = weight.shape[0], weight.shape[2]
+    o = wo
     oh, ow = (h + 2 * padding - k) // stride + 1, (w + 2 * padding - k) // stride + 1
     if oh < 1 or ow < 1:
         raise _lib.ShgError('conv2d_f16: empty output')
     xp = _pad_channels(x, 32)
-    wt = _taps_weight(L, weight.detach(), 32)
+    wt = packed.wp if packed is not None else _taps_weight(L, weight.detach(), 32)
+    L.view(wt, 'weight')
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     y = _new_cl(L, n, o, oh, ow)
     fused = in_scale is not None or out_scale is not None or noise is not None or act is not None or residual is not None
@@ -113,14 +136,19 @@ def conv_transpose2d(x, weight, bias=None, padding=0, out_hw=None, in_scale=None
     ``in_scale`` [N,Cin] (inference route): x * in_scale while the patch is staged."""
     L = kernels._Launch()
     x = _h(L, x, 'x')
-    if weight.dtype != torch.float16 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[0] != x.shape[1]:
-        raise _lib.ShgError('conv_transpose2d_f16: weight must be float16 [Cin,Cout,3,3] matching x')
-    L._own(weight, 'weight')
+    packed = weight if isinstance(weight, PackedWeight) else None            # (pack_weight(w, transposed=True))
+    if packed is None:
+        if weight.dtype != torch.float16 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[0] != x.shape[1]:
+            raise _lib.ShgError('conv_transpose2d_f16: weight must be float16 [Cin,Cout,3,3] matching x')
+        L._own(weight, 'weight')
+    elif packed.k != 3 or packed.i != x.shape[1]:
+        raise _lib.ShgError('conv_transpose2d_f16: packed weight does not match x')
     n, i, h, w = x.shape
-    o = weight.shape[1]
+    o = packed.o if packed is not None else weight.shape[1]
     oh, ow = out_hw if out_hw is not None else (2 * h + 1 - 2 * padding, 2 * w + 1 - 2 * padding)
     xp = _pad_channels(x, 32)
-    wt = _taps_weight(L, weight.detach().transpose(0, 1), 32)
+    wt = packed.wp if packed is not None else _taps_weight(L, weight.detach().transpose(0, 1), 32)
+    L.view(wt, 'weight')
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     lib = _lib.get_lib()
     y = _new_cl(L, n, o, oh, ow, zero=bool(lib.shg_conv2d_f16_needs_clear(h, w, padding, oh, ow)))

@@ -228,17 +228,28 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                             residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
 
 
-def _modulation_factors(half, weight, styles, demodulate):
-    """(normalised weight, normalised styles, demodulation coefficients [N,O] | None) of stylegan.py:136-155."""
-    dcoefs = None
+def _weight_factors(half, weight, demodulate):
+    """The weight side of stylegan.py:136-155 (a function of the parameter alone: the no-grad routes cache it per parameter version):
+    (normalised weight, sum_k w^2 [O,I] | None)."""
     if half and demodulate:
         o, i, kh, kw = weight.shape
         weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))       # max_Ikk, :137
-        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I, :138
+    wsq = None
     if demodulate:
         weight = weight * weight.square().mean([1, 2, 3], keepdim=True).rsqrt()          # stylegan.py:146
-        styles = styles * styles.square().mean().rsqrt()                                   # :147
         wsq = weight.square().sum([2, 3])                                                  # [O, I]
+    return weight, wsq
+
+
+def _modulation_factors(half, weight, styles, demodulate, wfac=None):
+    """(normalised weight, normalised styles, demodulation coefficients [N,O] | None) of stylegan.py:136-155; ``wfac`` = a cached
+    ``_weight_factors`` result."""
+    dcoefs = None
+    weight, wsq = wfac if wfac is not None else _weight_factors(half, weight, demodulate)
+    if half and demodulate:
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I, :138
+    if demodulate:
+        styles = styles * styles.square().mean().rsqrt()                                   # :147
         if styles.is_cuda and styles.dtype == torch.float32 and styles.ndim == 2:
             from .stylegan_utils import dense_ops
             dcoefs = (dense_ops.nt(styles.square(), wsq) + 1e-8).rsqrt()                      # :155, [N,O] -- s^2 @ wsq^T on the dense kernels
@@ -273,7 +284,7 @@ def layer_route(module, x, *tensors):
     return route
 
 
-def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual):
+def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual, cache=None):
     """Inference route of a float16 modulated layer (no autograd): the same algebra as ``_modulated_conv2d_train`` with the passes fused
     into the NHWC fp16 convolution -- ``x * styles`` while the patch is staged, demodulation / noise / bias / lrelu_agc / skip-add in its
     store pass (up = 1); the transposed form (up = 2) takes the style scale at staging, its tail follows the FIR in one modtail pass.
@@ -284,13 +295,21 @@ def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample
         return None
     if up == 2 and not (k == 3 and resample_filter is not None and resample_filter.ndim == 2 and tuple(resample_filter.shape) == (4, 4)):
         return None
-    wn, sn, d = _modulation_factors(True, weight, styles, demodulate)
+    # the weight side (normalisation, sum of squares, operand-order packing) depends on the parameter alone: cached per parameter version
+    # when the caller hands its layer cache (the float32 route does the same with `prepped()`)
+    def build():
+        wn_, wsq_ = _weight_factors(True, weight, demodulate)
+        if up == 1:
+            pk = kernels_f16.pack_weight((wn_ if flip_weight else wn_.flip([2, 3])).to(torch.float16))
+        else:
+            pk = kernels_f16.pack_weight((wn_.flip([2, 3]) if flip_weight else wn_).transpose(0, 1).to(torch.float16), transposed=True)
+        return wn_, wsq_, pk
+    wn, wsq, pk = cache.get(f'w16_{up}_{int(bool(flip_weight))}_{int(bool(demodulate))}', [weight], build) if cache is not None else build()
+    _, sn, d = _modulation_factors(True, weight, styles, demodulate, wfac=(wn, wsq))
     if up == 1:
-        wh = (wn if flip_weight else wn.flip([2, 3])).to(torch.float16)
-        return kernels_f16.conv2d(x, wh, bias, 1, padding, in_scale=sn, out_scale=d, noise=noise, residual=residual, **ak)
+        return kernels_f16.conv2d(x, pk, bias, 1, padding, in_scale=sn, out_scale=d, noise=noise, residual=residual, **ak)
     # conv2d_resample.py:122-142 with up = 2, padding = 1, a 4x4 filter: conv_transpose2d(stride 2, padding 0) -> FIR pad [1,1,1,1], gain 4
-    wt = (wn.flip([2, 3]) if flip_weight else wn).transpose(0, 1).to(torch.float16)
-    mid = kernels_f16.conv_transpose2d(x, wt, None, 0, None, in_scale=sn)
+    mid = kernels_f16.conv_transpose2d(x, pk, None, 0, None, in_scale=sn)
     mid = kernels_f16.upfirdn2d(mid, resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0)
     y = kernels_f16.modtail(mid, d=d, noise=noise, bias=bias, **ak)
     return y if residual is None else y + residual
@@ -386,7 +405,7 @@ class conv2d_layer(nn.Module):
         k = self.weight.shape[2]
         if ak is None or self.up != 1 or k not in (1, 3) or self.weight.shape[0] % 8:
             return None
-        w = (self.weight.detach() * self.weight_gain).to(torch.float16)
+        w = _cache_of(self).get('w16', [self.weight], lambda: kernels_f16.pack_weight((self.weight.detach() * self.weight_gain).to(torch.float16)))
         b = None if self.bias is None else self.bias.detach()
         if self.down == 1:
             return kernels_f16.conv2d(x, w, b, 1, self.padding, **ak)
@@ -482,7 +501,8 @@ class synthesis_layer(conv2d_layer):
         route = layer_route(self, x, w, self.weight, self.bias, self.affine.weight, residual)
         if route == 'f16_fused':
             y = _modulated_conv2d_half_infer(x, self.weight.detach(), self.affine(w), None if noise is None else noise * self.noise_strength.detach(),
-                                             self.up, self.padding, self.resample_filter, True, self.up == 1, self.bias.detach(), ak, residual)
+                                             self.up, self.padding, self.resample_filter, True, self.up == 1, self.bias.detach(), ak, residual,
+                                             cache=_cache_of(self))
             if y is not None:
                 return y
         if route != 'f32_fused':

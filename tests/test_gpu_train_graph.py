@@ -243,3 +243,27 @@ def test_layer_routes_are_decided_in_one_place_and_traceable():
     assert len(train) == len(infer) and {r for _, r, _, _ in train} == {'generic'}
     routes16 = {(r, d) for _, r, d, _ in half}
     assert ('f16_fused', 'float16') in routes16 and ('f32_fused', 'float32') in routes16 and not any(r == 'generic' for r, _ in routes16)
+
+
+def test_graph_pipeline_replays_the_evaluation_step_bit_exactly():
+    """``eval_harness.GraphPipeline`` (every slot's forward captured once as a HIP graph) against the eager ``run_generator`` on a sequence
+    of different batches: identical uint8 results (noise_mode 'const': no device RNG in the step), also after the parameters changed
+    and the slots were re-captured."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs, eval_harness as hz
+    G = configs.seeded_init_(configs.build_generator(256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128), seed=2,
+                             noise_strength=0.1).to(DEV).eval().requires_grad_(False)
+    batches = [hz.synthetic_batch(2, 256, 64, seed=s, device=DEV, masks='bernoulli')[:2] for s in (1, 2, 3, 4, 5)]
+
+    def step(x, z):
+        return hz.run_generator(G, x, z, noise_mode='const')
+    eager = [step(x, z).clone() for x, z in batches]
+    pipe = hz.GraphPipeline(DEV, step, batches[0], depth=2)
+    got = []
+    for x, z in batches:
+        out = pipe.run(x, z)
+        pipe.join()
+        got.append(out.clone())
+    for a, b in zip(eager, got):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0], got[1])

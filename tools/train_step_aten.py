@@ -19,5 +19,5 @@ for t, c, k, s in rows:
 for k, (t, c) in sorted(byop.items(), key=lambda kv: -kv[1][0])[:25]:
     print(f'  {k:34s} {t / 1e3:8.3f} ms {c:6d} calls')
 print('largest (op, shapes):')
-for t, c, k, s in rows[:45]:
+for t, c, k, s in rows[:70]:
     print(f'  {t / 1e3:8.3f} ms {c:5d}x {k:28s} {s}')
