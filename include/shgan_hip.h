@@ -166,6 +166,12 @@ int shg_dense_f32(const float* x, const float* w, const float* b, float* y, int 
 int shg_matmul_nn_f32(const float* a, const float* b, float* out, int N, int M, int K, int lda, int ldo, float scale, void* stream);
 int shg_matmul_tn_f32(const float* a, const float* b, float* out, float* colsum, int N, int M, int K, int lda, int ldb, float scale,
                       float csum_scale, void* stream);
+/* Weight side of modulated_conv2d under autograd (stylegan.py:136-138,146,150-155): wn = w * rsqrt(mean_{i,k} w^2) per output channel (with
+ * the fp16 pre-normalisation by the max-norm first when `prenorm`), wsq[o,i] = sum_k wn^2, sfac[o] = wn / w; and its transpose
+ * g_w = sfac * (G - wn * mean(G wn)), G = g_wn + 2 g_wsq wn.  w, wn, gwn, gw: [O,I,K]; wsq, gwsq: [O,I]; sfac: [O]. */
+int shg_demod_weight_f32(const float* w, float* wn, float* wsq, float* sfac, int O, int I, int K, int prenorm, void* stream);
+int shg_demod_weight_backward_f32(const float* wn, const float* sfac, const float* gwn, const float* gwsq, float* gw, int O, int I, int K,
+                                  void* stream);
 int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream);
 /* ---- A4: per-forward style side of modulated_conv2d (stylegan.py:147-155):
  * s_out = styles*pre_gain*rsqrt(mean(.^2)) when demod (else styles*pre_gain); dcoef[n,o] = rsqrt(sum_i s^2*wsq[i,o] + 1e-8). */

@@ -59,6 +59,8 @@ _SIGS = {
     'shg_conv1x1_thin_in_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_torgb_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],
+    'shg_demod_weight_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'shg_demod_weight_backward_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_matmul_nn_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_matmul_tn_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_fp],
     'shg_normalize_2nd_moment_f32': [c_fp, c_fp, c_i, c_i, c_f, c_fp],

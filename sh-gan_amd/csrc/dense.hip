@@ -172,6 +172,89 @@ extern "C" int shg_matmul_tn_f32(const float* a, const float* b, float* out, flo
     return SHG_OK;
 }
 
+// ---- weight side of modulated_conv2d under autograd (stylegan.py:136-138,146,150-155): one launch instead of ~12 tensor ops forward and
+// ~25 backward per layer.  Per output channel o (one workgroup):
+//   w1 = w * c,  c = 1 / (sqrt(I K) max|w[o]|) when `prenorm` (the fp16 pre-normalisation), else w1 = w
+//   wn = w1 * rsqrt(mean(w1^2)),      wsq[o,i] = sum_k wn[o,i,k]^2,      sfac[o] = wn / w   (saved for the backward pass)
+// The pre-normalisation cancels in wn up to round-off (and exactly in its derivative), so the backward needs sfac only:
+//   G = g_wn + 2 g_wsq[o,i] wn,      g_w = sfac * (G - wn * mean(G wn)).
+__device__ __forceinline__ float dw_block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float dw_block_max(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void demod_weight_kernel(const float* w, float* wn, float* wsq, float* sfac, int I, int K, int prenorm) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, IK = I * K;
+    const float* wo = w + (long)o * IK;
+    float c = 1.f;
+    if (prenorm) {
+        float mx = 0.f;
+        for (int e = threadIdx.x; e < IK; e += 256) mx = fmaxf(mx, fabsf(wo[e]));
+        mx = dw_block_max(mx, red);
+        c = 1.f / sqrtf((float)IK) / mx;
+    }
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < IK; e += 256) { const float v = wo[e] * c; ss += v * v; }
+    ss = dw_block_sum(ss, red);
+    const float r = rsqrtf(ss / (float)IK);
+    for (int e = threadIdx.x; e < IK; e += 256) wn[(long)o * IK + e] = wo[e] * c * r;
+    if (threadIdx.x == 0) sfac[o] = c * r;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) { const float v = wo[i * K + k] * c * r; acc += v * v; }
+        wsq[(long)o * I + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_weight_backward_kernel(const float* wn, const float* sfac, const float* gwn, const float* gwsq, float* gw,
+                                                                   int I, int K) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, IK = I * K;
+    const float* u = wn + (long)o * IK;
+    float dot = 0.f;
+    for (int e = threadIdx.x; e < IK; e += 256) {
+        const float uu = u[e];
+        const float g = (gwn ? gwn[(long)o * IK + e] : 0.f) + (gwsq ? 2.f * gwsq[(long)o * I + e / K] * uu : 0.f);
+        dot += g * uu;
+    }
+    dot = dw_block_sum(dot, red) / (float)IK;
+    const float s = sfac[o];
+    for (int e = threadIdx.x; e < IK; e += 256) {
+        const float uu = u[e];
+        const float g = (gwn ? gwn[(long)o * IK + e] : 0.f) + (gwsq ? 2.f * gwsq[(long)o * I + e / K] * uu : 0.f);
+        gw[(long)o * IK + e] = s * (g - uu * dot);
+    }
+}
+
+extern "C" int shg_demod_weight_f32(const float* w, float* wn, float* wsq, float* sfac, int O, int I, int K, int prenorm, void* stream) {
+    SHG_CHECK_ARG(w && wn && wsq && sfac && O >= 1 && I >= 1 && K >= 1, "demod_weight: bad arguments");
+    hipLaunchKernelGGL(demod_weight_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, wn, wsq, sfac, I, K, prenorm);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// gwn [O,I,K] and gwsq [O,I]: either may be NULL (no gradient arrived on that output)
+extern "C" int shg_demod_weight_backward_f32(const float* wn, const float* sfac, const float* gwn, const float* gwsq, float* gw, int O, int I, int K,
+                                             void* stream) {
+    SHG_CHECK_ARG(wn && sfac && gw && (gwn || gwsq) && O >= 1 && I >= 1 && K >= 1, "demod_weight_backward: bad arguments");
+    hipLaunchKernelGGL(demod_weight_backward_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, wn, sfac, gwn, gwsq, gw, I, K);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 extern "C" int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream) {
     SHG_CHECK_ARG(x && y && N >= 1 && K >= 1, "normalize_2nd_moment: bad arguments");
     hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, y, K, eps);

@@ -693,6 +693,30 @@ def dense(x, w, b=None, wgain=1.0, bgain=1.0, act=False, gain=1.0, alpha=0.2, ac
     return y
 
 
+def demod_weight(w, prenorm=False):
+    """-> (wn, wsq [O,I], sfac [O]): the weight side of modulated_conv2d (csrc/dense.hip: demod_weight_kernel)."""
+    L = _Launch()
+    w = L.req(w, 'w')
+    o, i = w.shape[0], w.shape[1]
+    k = w.numel() // (o * i)
+    wn, wsq, sfac = torch.empty_like(w), L.new((o, i)), L.new((o,))
+    with L:
+        check(_lib.get_lib().shg_demod_weight_f32(_ptr(w), _ptr(wn), _ptr(wsq), _ptr(sfac), o, i, k, int(bool(prenorm)), L.stream()), 'demod_weight')
+    return wn, wsq, sfac
+
+
+def demod_weight_backward(wn, sfac, gwn, gwsq):
+    L = _Launch()
+    wn, sfac, gwn, gwsq = L.req(wn, 'wn'), L.req(sfac, 'sfac'), L.req(gwn, 'gwn'), L.req(gwsq, 'gwsq')
+    o, i = wn.shape[0], wn.shape[1]
+    k = wn.numel() // (o * i)
+    gw = torch.empty_like(wn)
+    with L:
+        check(_lib.get_lib().shg_demod_weight_backward_f32(_ptr(wn), _ptr(sfac), _ptr(gwn), _ptr(gwsq), _ptr(gw), o, i, k, L.stream()),
+              'demod_weight_backward')
+    return gw
+
+
 def matmul_nn(a, b, scale=1.0):
     """scale * a[N,M] @ b[M,K] (csrc/dense.hip: the input gradient of a dense layer)."""
     L = _Launch()

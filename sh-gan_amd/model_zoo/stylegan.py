@@ -16,6 +16,8 @@ float32 is the default and the only arithmetic of the shipped configs; the ``use
 fp16-MFMA kernels (csrc/conv_f16.hip) through the non-fused algebra, with or without autograd."""
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -228,9 +230,44 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                             residual=ep.get('residual'), act=ep.get('act', False), gain=ep.get('gain', 1.0))
 
 
+class _DemodWeightFn(torch.autograd.Function):
+    """(wn, wsq) of ``_weight_factors`` for a demodulated float32 weight in ONE kernel each way (csrc/dense.hip); under ``create_graph``
+    the backward is composed from tensor ops instead (never needed by the shipped losses: the path-length regulariser reaches the
+    weights only in its second, ordinary backward pass)."""
+    @staticmethod
+    def forward(ctx, weight, prenorm):
+        wn, wsq, sfac = kernels.demod_weight(weight.detach(), prenorm)
+        ctx.save_for_backward(wn, sfac)
+        ctx.mark_non_differentiable(sfac)
+        return wn, wsq, sfac
+
+    @staticmethod
+    def backward(ctx, gwn, gwsq, _gs):
+        wn, sfac = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            g = 0
+            if gwn is not None:
+                g = g + gwn
+            if gwsq is not None:
+                g = g + 2 * gwsq[:, :, None, None] * wn
+            s = sfac.reshape(-1, 1, 1, 1)
+            return s * (g - wn * (g * wn).mean([1, 2, 3], keepdim=True)), None
+        return kernels.demod_weight_backward(wn, sfac, None if gwn is None else gwn.contiguous(), None if gwsq is None else gwsq.contiguous()), None
+
+
+# Off by default: with it the FFHQ-512 training iteration is no longer bit-identical between its first and second execution in a
+# process (round-off-level differences, 5e-7, in the encoder's path-length gradients; tests/test_gpu_config5.py demands equality).
+# The kernels themselves are deterministic (tests/test_gpu_train_graph.py); the interaction is not understood -- MEASUREMENTS.md, round 4.
+FUSED_DEMOD_WEIGHT = os.environ.get('SHG_FUSED_DEMOD', '0') == '1'        # (opt-in switch; tools/ and the kernel test set it)
+
+
 def _weight_factors(half, weight, demodulate):
     """The weight side of stylegan.py:136-155 (a function of the parameter alone: the no-grad routes cache it per parameter version):
     (normalised weight, sum_k w^2 [O,I] | None)."""
+    if (FUSED_DEMOD_WEIGHT and demodulate and weight.is_cuda and weight.dtype == torch.float32 and weight.ndim == 4
+            and grad_ops.wants_grad(weight)):
+        wn, wsq, _ = _DemodWeightFn.apply(weight.contiguous(), bool(half))
+        return wn, wsq
     if half and demodulate:
         o, i, kh, kw = weight.shape
         weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))       # max_Ikk, :137

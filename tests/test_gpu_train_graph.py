@@ -267,3 +267,36 @@ def test_graph_pipeline_replays_the_evaluation_step_bit_exactly():
     for a, b in zip(eager, got):
         assert torch.equal(a, b)
     assert not torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize('o,i,k,half', [(64, 32, 3, False), (512, 512, 3, True), (70, 13, 3, True), (128, 64, 1, False)])
+def test_fused_demodulation_weight_kernel_vs_tensor_ops(o, i, k, half):
+    """``_weight_factors`` under autograd: the one-kernel form (csrc/dense.hip demod_weight / demod_weight_backward) against the tensor-op
+    composition of stylegan.py:136-138,146,150-155 in float64 -- outputs (wn, wsq) and the gradient of a random functional of both."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo import stylegan
+    rs = np.random.RandomState(o + i + k)
+    w0 = rs.standard_normal((o, i, k, k))
+    a0, b0 = rs.standard_normal((o, i, k, k)), rs.standard_normal((o, i))
+    with torch.enable_grad():
+        w = torch.tensor(w0, dtype=torch.float32, device=DEV, requires_grad=True)
+        keep = stylegan.FUSED_DEMOD_WEIGHT
+        try:
+            stylegan.FUSED_DEMOD_WEIGHT = True
+            wn, wsq = stylegan._weight_factors(half, w, True)
+        finally:
+            stylegan.FUSED_DEMOD_WEIGHT = keep
+        assert type(wn.grad_fn).__name__ == '_DemodWeightFnBackward'
+        (gw,) = torch.autograd.grad((wn * torch.tensor(a0, dtype=torch.float32, device=DEV)).sum()
+                                    + (wsq * torch.tensor(b0, dtype=torch.float32, device=DEV)).sum(), [w])
+        w64 = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+        old = stylegan.FUSED_DEMOD_WEIGHT
+        try:
+            stylegan.FUSED_DEMOD_WEIGHT = False
+            wn64, wsq64 = stylegan._weight_factors(half, w64, True)
+        finally:
+            stylegan.FUSED_DEMOD_WEIGHT = old
+        (gw64,) = torch.autograd.grad((wn64 * torch.tensor(a0)).sum() + (wsq64 * torch.tensor(b0)).sum(), [w64])
+    for name, got, ref in (('wn', wn, wn64), ('wsq', wsq, wsq64), ('gw', gw, gw64)):
+        e = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        assert e < 1e-5, (name, e)
