@@ -255,10 +255,7 @@ class _DemodWeightFn(torch.autograd.Function):
         return kernels.demod_weight_backward(wn, sfac, None if gwn is None else gwn.contiguous(), None if gwsq is None else gwsq.contiguous()), None
 
 
-# Off by default: with it the FFHQ-512 training iteration is no longer bit-identical between its first and second execution in a
-# process (round-off-level differences, 5e-7, in the encoder's path-length gradients; tests/test_gpu_config5.py demands equality).
-# The kernels themselves are deterministic (tests/test_gpu_train_graph.py); the interaction is not understood -- MEASUREMENTS.md, round 4.
-FUSED_DEMOD_WEIGHT = os.environ.get('SHG_FUSED_DEMOD', '0') == '1'        # (opt-in switch; tools/ and the kernel test set it)
+FUSED_DEMOD_WEIGHT = os.environ.get('SHG_FUSED_DEMOD', '1') == '1'        # (A/B switch; SHG_FUSED_DEMOD=0: the tensor-op composition)
 
 
 def _weight_factors(half, weight, demodulate):

@@ -157,8 +157,14 @@ def test_config5_full_width_phases_vs_reference_autograd():
 
 @pytest.mark.parametrize('fp16', [False, True])
 def test_config5_batch8_training_iteration_all_phases(fp16):
-    """The configuration's own size: FFHQ-512, batch 8 on this GPU, Gmain + Greg + Dmain + Dreg with Adam through
-    ``train_stage.run_phases`` (gradients in the all-reduce buckets, sanitised); two iterations from the same state are bit-identical."""
+    """The configuration's own size: FFHQ-512, batch 8 on this GPU, with Adam through ``train_stage.run_phases`` (gradients in the
+    all-reduce buckets, sanitised), each twice from the same state:
+      * Gmain + Dmain (every iteration; first-order passes): bit-identical on replay;
+      * Gmain + Greg + Dmain + Dreg (the lazy regularisers on top): equal to round-off.  The second-order path-length pass is NOT
+        bit-repeatable run to run -- its gradients w.r.t. x_global and the 128^2..512^2 encoder features differ by a few ulp (5e-7)
+        between executions although every layer, the dense operators and the RGB branch are bit-repeatable by themselves and
+        torch's deterministic mode flags no operator (MEASUREMENTS.md, round 4); Adam's first step then differs in the last bit of
+        some encoder parameters."""
     import copy
     from shgan_amd import losses, train_stage as ts
     G, D = build_networks(512, 61, 62, fp16=fp16)          # fp16: the second-order phases (R1, path length) differentiate the half kernels twice
@@ -169,22 +175,26 @@ def test_config5_batch8_training_iteration_all_phases(fp16):
     mask = torch.from_numpy((rs.uniform(size=(8, 1, 512, 512)) < 0.7).astype(np.float32))
     real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
     kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8)
-    results = []
-    for trial in range(2):
+
+    def iteration(batch_idx, expect):
         G.load_state_dict(g0); D.load_state_dict(d0)
         torch.manual_seed(7)
         L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0.9)
         phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
-        ran = ts.run_phases(real4, 512, phases, batch_idx=0, loss=L, batch_gpu=8, device=DEV)
-        assert ran == ['Gmain', 'Greg', 'Dmain', 'Dreg']
-        for k in ('Loss/G/loss', 'Loss/D/loss', 'Loss/r1_penalty', 'Loss/pl_penalty'):
+        ran = ts.run_phases(real4, 512, phases, batch_idx=batch_idx, loss=L, batch_gpu=8, device=DEV)
+        assert ran == expect
+        for k in ('Loss/G/loss', 'Loss/D/loss') + (('Loss/r1_penalty', 'Loss/pl_penalty') if len(expect) == 4 else ()):
             assert torch.isfinite(L.stats[k]).all(), k
-        results.append(torch.cat([p.detach().reshape(-1)[:4096] for p in list(G.parameters()) + list(D.parameters())]).clone())
+        out = torch.cat([p.detach().reshape(-1)[:4096] for p in list(G.parameters()) + list(D.parameters())]).clone()
         for ph in phases:
             if ph.sync is not None:
                 ph.sync.remove()
-    assert torch.isfinite(results[0]).all()
-    assert torch.equal(results[0], results[1])
+        return out
+    main = [iteration(1, ['Gmain', 'Dmain']) for _ in range(2)]
+    assert torch.isfinite(main[0]).all() and torch.equal(main[0], main[1])
+    full = [iteration(0, ['Gmain', 'Greg', 'Dmain', 'Dreg']) for _ in range(2)]
+    assert torch.isfinite(full[0]).all()
+    assert torch.allclose(full[0], full[1], rtol=1e-5, atol=1e-7), float((full[0] - full[1]).abs().max())
     moved = sum(int((p.detach().cpu() - g0[n].cpu()).abs().max() > 0) for n, p in G.named_parameters())
     assert moved >= len(list(G.parameters())) - 4, moved
 
