@@ -14,6 +14,7 @@ conv2d_gradfix.py:148-163), so gradients of gradients work: the R1 and path-leng
 import torch
 
 from ... import kernels, kernels_f16
+from . import grad_ops
 
 PLANAR_CONVT = True                  # transposed convolutions: phase planes + interleave pass (False: the direct interleaved kernel)
 enabled = True                       # (conv2d_gradfix.py:22) -- the HIP path is the only path; kept for interface compatibility
@@ -177,7 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             gw = _WgradFn.apply(g, x, weight.shape[2], stride, padding)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum([0, 2, 3])
+            gb = grad_ops.channel_sum(g).to(g.dtype)
         return gx, gw, gb, None, None
 
 
@@ -202,7 +203,7 @@ class _ConvTranspose2dFn(torch.autograd.Function):
             # dw[ci,co,ky,kx] = sum x[n,ci,y,x] * g[n,co,2y-p+ky,2x-p+kx]: the conv weight gradient with the tensors exchanged
             gw = _WgradFn.apply(x, g, 3, 2, padding)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum([0, 2, 3])
+            gb = grad_ops.channel_sum(g).to(g.dtype)
         return gx, gw, gb, None
 
 

@@ -54,6 +54,14 @@ class _BiasActBwdFn(torch.autograd.Function):
         return _BiasActBwdFn.apply(gg, y, ctx.cfg), None, None
 
 
+def channel_sum(t):
+    """Sum over every axis but the channel axis, accumulated in float32 (differentiable).  A reduction to C values runs on C workgroups:
+    the RGB branch's [8, 3, 512, 512] bias gradient took 670 us as one reduction; rows first, then the rest, is two launches of ~6 us."""
+    if t.ndim == 4 and t.shape[1] <= 32 and t.shape[2] * t.shape[3] >= 16384:
+        return t.sum(3, dtype=torch.float32).sum([0, 2])
+    return t.sum([0] + list(range(2, t.ndim)), dtype=torch.float32)
+
+
 class _BiasActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, act, gain, alpha, act_gain, clamp):
@@ -85,7 +93,7 @@ class _BiasActFn(torch.autograd.Function):
         dx = _BiasActBwdFn.apply(g, y, (act, gain, alpha, act_gain, clamp))
         db = None
         if has_bias and ctx.needs_input_grad[1]:
-            db = dx.sum([0] + list(range(2, dx.ndim)), dtype=torch.float32)          # (fp16 layers: the channel sum in fp32; the bias is an fp32 parameter)
+            db = channel_sum(dx)                                                     # (fp16 layers: the channel sum in fp32; the bias is an fp32 parameter)
         return dx, db, None, None, None, None, None
 
 
@@ -138,7 +146,7 @@ class _ModTailFn(torch.autograd.Function):
                 gn = gz.float().sum(1, keepdim=True)
                 gn = (gn.sum(0) if noise.numel() != gn.numel() else gn).reshape(noise.shape).to(noise.dtype)
             if bias is not None and need_b:
-                gb = gz.sum([0, 2, 3], dtype=torch.float32).to(bias.dtype)
+                gb = channel_sum(gz).to(bias.dtype)
             return gt, gd, gn, gb, None
         want_sums = (d is not None and need_d) or (bias is not None and need_b)
         if y.dtype == torch.float16:

@@ -15,6 +15,7 @@ Mirrors ``lib/experiments/stylegan_default.py``:
 The reference wraps the networks in DistributedDataParallel (:172-187); here every phase owns a ``grad_sync.BucketedAllReduce`` over
 its module's parameters (RCCL all-reduce launched from backward hooks, averaged and sanitised per bucket) -- with one rank it only
 sanitises, so the same code runs on one GPU and on N."""
+import os
 import torch
 
 from .grad_sync import BucketedAllReduce
@@ -85,65 +86,51 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
     real_c = torch.zeros([batch_gpu, 0], device=device) if real_c is None else real_c.to(device)
     all_gen_c = torch.zeros([len(phases) * batch_gpu, 0], device=device) if gen_c is None else gen_c.to(device)
     all_gen_z = torch.randn([len(phases) * batch_gpu, z_dim]).to(device)       # drawn on the host like the reference (:128)
-    real_img_r, real_c_r = real_img.split(eff), real_c.split(eff)
-    all_gen_z = [pz.split(eff) for pz in all_gen_z.split(batch_gpu)]
-    all_gen_c = [pc.split(eff) for pc in all_gen_c.split(batch_gpu)]
+    all_gen_z, all_gen_c = all_gen_z.split(batch_gpu), all_gen_c.split(batch_gpu)
     ran = []
     for phase, phase_gen_z, phase_gen_c in zip(phases, all_gen_z, all_gen_c):
         if batch_idx % phase.interval != 0:
             continue
         if phase.start_event is not None:
             phase.start_event.record(torch.cuda.current_stream(device))
-        if phase.sync is not None:
-            phase.sync.zero_grad()                       # gradients live in the all-reduce buckets
-        else:
-            phase.opt.zero_grad(set_to_none=True)
-        phase.module.requires_grad_(True)
-        if hasattr(loss, 'grad_sync'):
-            loss.grad_sync = phase.sync                  # the loss arms it before the phase's LAST backward (sync=True round only)
-        rounds = batch_gpu // eff
-        for round_idx, (ri, rc, gz, gc) in enumerate(zip(real_img_r, real_c_r, phase_gen_z, phase_gen_c)):
-            loss.accumulate_gradients(phase=phase.name, real_img=ri, real_c=rc, gen_z=gz, gen_c=gc,
-                                      sync=(round_idx == rounds - 1), gain=phase.interval)
-        phase.module.requires_grad_(False)
-        if hasattr(loss, 'grad_sync'):
-            loss.grad_sync = None
-        if phase.sync is not None:
-            if phase.sync.reduce and not phase.sync.was_armed():
-                _warn_unarmed(loss, phase)               # correct, but every bucket is reduced synchronously in finish(): no overlap
-            phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
-            for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them
-                p.grad = None
-        else:
-            sanitize_(phase.module.parameters())
-        phase.opt.step()
+        _phase_body(phase, loss, real_img, real_c, phase_gen_z, phase_gen_c, eff)
         if phase.end_event is not None:
             phase.end_event.record(torch.cuda.current_stream(device))
         ran.append(phase.name)
     return ran
 
 
+# Backward passes run on the calling thread.  With the engine's device worker thread, the nodes a create_graph backward creates
+# (path-length / R1 regularisers) are numbered by that thread's counter and the forward nodes by the main thread's; the two advance by
+# different amounts per iteration, so the ready-queue order of the double-backward graph -- and the order in which gradients with
+# several consumers (x_global, the encoder's skip features) are summed -- changed from one execution to the next: identical inputs
+# gave parameters that differed in the last bits (tools/probes/autograd_thread_order.py; every kernel is bit-repeatable).  One
+# GPU per process means the worker thread bought no concurrency anyway.
+SINGLE_THREADED_BACKWARD = os.environ.get('SHG_ENGINE_THREADS', '0') != '1'
+
+
 def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
     """One phase of an iteration on given tensors: the inner block of ``run_phases`` (stylegan_default.py:141-166)."""
     if phase.sync is not None:
-        phase.sync.zero_grad()
+        phase.sync.zero_grad()                       # gradients live in the all-reduce buckets
     else:
         phase.opt.zero_grad(set_to_none=True)
     phase.module.requires_grad_(True)
     if hasattr(loss, 'grad_sync'):
-        loss.grad_sync = phase.sync
+        loss.grad_sync = phase.sync                  # the loss arms it before the phase's LAST backward (sync=True round only)
     rr, rc, gz, gc = real_img.split(eff), real_c.split(eff), gen_z.split(eff), gen_c.split(eff)
-    for round_idx in range(len(rr)):
-        loss.accumulate_gradients(phase=phase.name, real_img=rr[round_idx], real_c=rc[round_idx], gen_z=gz[round_idx], gen_c=gc[round_idx],
-                                  sync=(round_idx == len(rr) - 1), gain=phase.interval)
+    with torch.autograd.set_multithreading_enabled(not SINGLE_THREADED_BACKWARD):
+        for round_idx in range(len(rr)):
+            loss.accumulate_gradients(phase=phase.name, real_img=rr[round_idx], real_c=rc[round_idx], gen_z=gz[round_idx],
+                                      gen_c=gc[round_idx], sync=(round_idx == len(rr) - 1), gain=phase.interval)
     phase.module.requires_grad_(False)
     if hasattr(loss, 'grad_sync'):
         loss.grad_sync = None
     if phase.sync is not None:
         if phase.sync.reduce and not phase.sync.was_armed():
-            _warn_unarmed(loss, phase)
-        phase.sync.finish()
-        for p in phase.sync.untouched():
+            _warn_unarmed(loss, phase)               # correct, but every bucket is reduced synchronously in finish(): no overlap
+        phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
+        for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them
             p.grad = None
     else:
         sanitize_(phase.module.parameters())
