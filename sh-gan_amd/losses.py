@@ -32,8 +32,9 @@ class Loss:
 
 class StyleGAN2Loss(Loss):
     def __init__(self, device, G_mapping, G_synthesis, D, augment_pipe=None, style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2,
-                 pl_decay=0.01, pl_weight=2):
+                 pl_decay=0.01, pl_weight=2, batch_critic=True):
         super().__init__()
+        self.batch_critic = batch_critic            # Dmain: generated and real images through the critic as ONE batch (see accumulate_gradients)
         if augment_pipe is not None:
             raise NotImplementedError('ADA augmentation is not part of the HIP path')
         self.device = device
@@ -69,6 +70,11 @@ class StyleGAN2Loss(Loss):
     def run_D(self, img, c, sync=True):
         return self.D(img, c)
 
+    def run_D_pair(self, gen_img, gen_c, real_img, real_c):
+        """-> (gen_logits, real_logits) from one critic pass over cat([gen, real]) with the minibatch statistic per half."""
+        logits = self.D(torch.cat([gen_img, real_img]), torch.cat([gen_c, real_c]), segments=2)
+        return logits[:gen_img.shape[0]], logits[gen_img.shape[0]:]
+
     # -- one phase (stylegan_default_loss.py:53-128) -----------------------------------------------------------------------
     def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync=True, gain=1):
         if phase not in PHASES:
@@ -101,6 +107,21 @@ class StyleGAN2Loss(Loss):
                 self.stats.update({'Loss/pl_penalty': pl_penalty.detach(), 'Loss/G/reg': loss_Gpl.detach()})
                 self._arm(sync)
                 (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
+
+            if do_Dmain and not do_Dr1 and self.batch_critic and real_img.shape[0] == gen_z.shape[0]:
+                # The reference judges the generated and the real batch in two critic passes with a backward each (:84-106).  No layer of
+                # the critic mixes samples except the minibatch statistic, so one pass over the stacked batch (statistic per half) and one
+                # backward of the summed losses give the same logits and the same gradients (to the order of the weight-gradient sums)
+                # with half the weight-side work and half the launches.  Dreg keeps the reference's form (R1 needs the real pass alone).
+                with torch.no_grad():
+                    gen_img, _ = self.run_G(gen_z, gen_c)
+                gen_logits, real_logits = self.run_D_pair(gen_img, gen_c, real_img.detach(), real_c)
+                loss_Dgen, loss_Dreal = F.softplus(gen_logits), F.softplus(-real_logits)
+                self.stats.update({'Loss/scores/fake': gen_logits.detach(), 'Loss/scores/real': real_logits.detach(),
+                                   'Loss/D/loss': (loss_Dgen + loss_Dreal).detach()})
+                self._arm(sync)
+                (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+                return
 
             loss_Dgen = 0
             if do_Dmain:                                             # minimise the logits of generated images
@@ -180,3 +201,9 @@ class InpaintingLoss(StyleGAN2Loss):
         if img.shape[1] == 3:                                   # a generated image: prepend the mask channel it was conditioned on
             img = torch.cat([self._m05[:img.shape[0]], img], dim=1)
         return self.D(img, c)
+
+    def run_D_pair(self, gen_img, gen_c, real_img, real_c):
+        n = gen_img.shape[0]
+        both = torch.cat([torch.cat([self._m05[:n], gen_img], dim=1), real_img])       # (one write pass: cat of the cat's pieces)
+        logits = self.D(both, torch.cat([gen_c, real_c]), segments=2)
+        return logits[:n], logits[n:]

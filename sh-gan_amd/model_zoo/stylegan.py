@@ -807,7 +807,11 @@ class minibatch_std_layer(nn.Module):
         self.group_size = group_size
         self.num_channels = num_channels
 
-    def forward(self, x):
+    def forward(self, x, segments=1):
+        if segments > 1:                     # independent sub-batches stacked along the batch axis: the statistic never mixes them
+            if x.shape[0] % segments:
+                raise ValueError('minibatch_std_layer: the batch does not split into %d equal segments' % segments)
+            return torch.cat([self.forward(part) for part in x.chunk(segments)], dim=0)
         if grad_ops.wants_grad(x):
             # training rows: the statistic is a handful of reductions over a 4x4 map -- composed from differentiable tensor ops
             n, c, h, w = x.shape
@@ -836,12 +840,12 @@ class discrim_epilogue(nn.Module):
         self.fc = dense(ic_n * (resolution ** 2), ic_n, activation=activation)
         self.out = dense(ic_n, 1 if cmap_dim is None else cmap_dim, activation=None)
 
-    def forward(self, x, img=None, cmap=None):
+    def forward(self, x, img=None, cmap=None, segments=1):
         x = grad_ops.to_block_dtype(x, False)                                    # stylegan.py:744: the tail is always float32
         if self.fromrgb is not None:
             x = _add(x, self.fromrgb(img.to(torch.float32)))
         if self.mbstd is not None:
-            x = self.mbstd(x)
+            x = self.mbstd(x, segments=segments)
         x = self.conv(x)
         x = self.out(self.fc(x.flatten(1)))
         if self.cmap_dim is not None:        # conditional projection (stylegan.py:752-753): [N, cmap_dim] x [N, cmap_dim] -> [N, 1]
@@ -879,9 +883,12 @@ class Discriminator(nn.Module):
         self.b4 = discrim_epilogue(c4, resolution=4, cmap_dim=None, activation=activation,
                                    mbstd_group_size=mbstd_group_size, mbstd_c_n=mbstd_c_n)
 
-    def forward(self, img, c, **kwargs):
+    def forward(self, img, c, segments=1, **kwargs):
+        """``segments`` (not in the reference): ``img`` is that many independently judged sub-batches stacked along the batch axis.
+        Every layer but the minibatch statistic is per-sample, and that one is then taken per segment, so
+        ``D(cat([a, b]), c, segments=2) == cat([D(a), D(b)])`` -- one pass over the weights instead of two (losses.py, Dmain)."""
         x = None
         for res in self.encode_res[0:-1]:
             x, img = getattr(self, 'b{}'.format(res))(x, img)
         cmap = self.mapping(None, c) if self.mapping is not None else None
-        return self.b4(x, img, cmap)
+        return self.b4(x, img, cmap, segments=segments)

@@ -300,3 +300,39 @@ def test_fused_demodulation_weight_kernel_vs_tensor_ops(o, i, k, half):
     for name, got, ref in (('wn', wn, wn64), ('wsq', wsq, wsq64), ('gw', gw, gw64)):
         e = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
         assert e < 1e-5, (name, e)
+
+
+@pytest.mark.parametrize('fp16', [False, True])
+def test_dmain_one_critic_pass_over_the_stacked_batch_equals_the_two_passes_of_the_reference(fp16):
+    """stylegan_default_loss.py:84-106 judges the generated and the real batch in two critic passes with a backward each.  The product
+    stacks them (``Discriminator.forward(segments=2)``: minibatch statistic per half) and runs one backward of the summed losses.  No
+    other layer mixes samples: the logits must be IDENTICAL, the parameter gradients equal up to the order of the weight-gradient sums."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import losses
+    from shgan_amd.model_zoo import stylegan
+    G, _ = small_networks(21)
+    torch.manual_seed(22)
+    D = stylegan.Discriminator(resolution=256, ic_n=4, ch_base=2048, ch_max=32, mbstd_group_size=4, mbstd_c_n=1,
+                               use_fp16_before_res=(32 if fp16 else None)).to(DEV).train().requires_grad_(False)
+    real4 = real_batch(8, 23)
+    z, c = torch.randn(8, 64, device=DEV), torch.zeros(8, 0, device=DEV)
+    res = []
+    for batched in (False, True):
+        L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, batch_critic=batched)
+        D.requires_grad_(True)
+        for p in D.parameters():
+            p.grad = None
+        L.accumulate_gradients('Dmain', real4, c, z, c)
+        D.requires_grad_(False)
+        res.append(({k: v.clone() for k, v in L.stats.items()}, {n: p.grad.clone() for n, p in D.named_parameters()}))
+    (s0, g0), (s1, g1) = res
+    for k in ('Loss/scores/fake', 'Loss/scores/real', 'Loss/D/loss'):
+        assert torch.equal(s0[k], s1[k]), k
+    # the stacked statistic is not the statistic of the stacked batch: a plain 16-sample pass gives other logits
+    with torch.no_grad():
+        plain = D(torch.cat([real4, real4.flip(0)]), None)
+        halves = D(torch.cat([real4, real4.flip(0)]), None, segments=2)
+        assert torch.equal(halves[:8], D(real4, None)) and not torch.equal(plain[:8], halves[:8])
+    worst = max(float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-20)) for n in g0)
+    print(f'Dmain, one stacked critic pass vs two passes ({"fp16 blocks" if fp16 else "float32"}): worst relative gradient difference {worst:.2e}')
+    assert worst < (2e-2 if fp16 else 1e-5)

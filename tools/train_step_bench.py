@@ -19,8 +19,10 @@ ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--fp16', action='store_true', help='the use_fp16 blocks of the reference: encoder > 64, synthesis > 32, discriminator > 32')
 ap.add_argument('--host-enqueue', action='store_true', help='also time how long the host needs to enqueue a G phase (one extra G phase)')
+ap.add_argument('--two-pass-critic', action='store_true', help='generated and real batch through the critic separately (A/B)')
 ap.add_argument('--direct-convt', action='store_true', help='transposed convolutions on the direct interleaved kernel (A/B)')
 a = ap.parse_args()
+TWO_PASS_CRITIC = a.two_pass_critic
 if a.direct_convt:
     from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix as _gf
     _gf.PLANAR_CONVT = False
@@ -61,7 +63,11 @@ def d_phase():
     with torch.no_grad():
         img = G(x=x, z=z, c=cnd, noise_mode='random')
     with torch.enable_grad():
-        loss = F.softplus(D(d_in(img), None)).mean() + F.softplus(-D(d_in(real), None)).mean()
+        if TWO_PASS_CRITIC:
+            loss = F.softplus(D(d_in(img), None)).mean() + F.softplus(-D(d_in(real), None)).mean()
+        else:                               # as losses.StyleGAN2Loss (batch_critic): one pass over the stacked batch, statistic per half
+            lg = D(torch.cat([d_in(img), d_in(real)]), None, segments=2)
+            loss = F.softplus(lg[:img.shape[0]]).mean() + F.softplus(-lg[img.shape[0]:]).mean()
         loss.backward()
     syncD.finish(); optD.step()
     return float(loss)
