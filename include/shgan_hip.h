@@ -172,6 +172,13 @@ int shg_matmul_tn_f32(const float* a, const float* b, float* out, float* colsum,
 int shg_demod_weight_f32(const float* w, float* wn, float* wsq, float* sfac, int O, int I, int K, int prenorm, void* stream);
 int shg_demod_weight_backward_f32(const float* wn, const float* sfac, const float* gwn, const float* gwsq, float* gw, int O, int I, int K,
                                   void* stream);
+/* Style side of modulated_conv2d under autograd (stylegan.py:138,147,155): sn = s1 * rsqrt(mean_{n,i} s1^2), s1 = s / max_i |s| per row when
+ * `prenorm` else s; d[n,o] = rsqrt(sum_i sn^2 wsq[o,i] + 1e-8) (d may be NULL); aux [N+1] = {row maxima (1 without prenorm), rsqrt(mean)}.
+ * Backward: gs [N,I], gwsq [O,I] (may be NULL) from gsn [N,I] / gd [N,O] (either may be NULL); partq = scratch of ceil(O/64)*N*I floats.
+ * N <= 32, N*I <= 8192 (64 KB of LDS in the backward pass). */
+int shg_style_factors_f32(const float* s, const float* wsq, float* sn, float* d, float* aux, int N, int I, int O, int prenorm, void* stream);
+int shg_style_factors_backward_f32(const float* sn, const float* d, const float* wsq, const float* aux, const float* gsn, const float* gd,
+                                   float* gs, float* gwsq, float* partq, int N, int I, int O, int prenorm, void* stream);
 int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream);
 /* ---- A4: per-forward style side of modulated_conv2d (stylegan.py:147-155):
  * s_out = styles*pre_gain*rsqrt(mean(.^2)) when demod (else styles*pre_gain); dcoef[n,o] = rsqrt(sum_i s^2*wsq[i,o] + 1e-8). */

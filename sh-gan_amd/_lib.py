@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -61,6 +61,8 @@ _SIGS = {
     'shg_dense_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_fp],
     'shg_demod_weight_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_demod_weight_backward_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'shg_style_factors_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'shg_style_factors_backward_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_matmul_nn_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_matmul_tn_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_fp],
     'shg_normalize_2nd_moment_f32': [c_fp, c_fp, c_i, c_i, c_f, c_fp],

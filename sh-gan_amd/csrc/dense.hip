@@ -255,6 +255,249 @@ extern "C" int shg_demod_weight_backward_f32(const float* wn, const float* sfac,
     return SHG_OK;
 }
 
+// ---- style side of modulated_conv2d under autograd (stylegan.py:138,147,155): sn = s1 * rsqrt(mean(s1^2)) with s1 = s / max_i |s| per
+// row when `prenorm` (the fp16 pre-normalisation) else s, and dcoef[n][o] = rsqrt(sum_i sn[n][i]^2 wsq[o][i] + 1e-8).  ~11 tensor ops
+// forward and ~25 backward per layer and pass in the composed form; here one launch forward, two backward.  All three are latency
+// problems (a few hundred kFLOP): many small workgroups, every global load of a thread issued before the first use.
+// Forward: grid = ceil(O / 8) workgroups (a wave owns 2 output channels); every workgroup recomputes the (tiny) batch-global statistic,
+// workgroup 0 writes sn and aux = {M_n (row maxima, 1 without prenorm), r}.  LDS: q = sn^2 [N][I], then the workgroup's 8 wsq rows.
+// The loops stay rolled: straight-line code that runs once costs more in instruction fetch than it saves (25 -> see MEASUREMENTS).
+template <int NB>
+__global__ __launch_bounds__(256) void style_factors_kernel(const float* s, const float* wsq, float* sn, float* d, float* aux, int N, int I, int O,
+                                                            int prenorm) {
+    extern __shared__ float q[];
+    __shared__ float red[256];
+    __shared__ float rowmax[NB];                  // row maxima (1 without prenorm)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wl = q + N * I;                        // [8][I]
+    // every global load of the kernel is requested up front: flat, independent (a row-by-row walk pays one memory latency per step)
+#pragma unroll 8
+    for (int e = tid; e < N * I; e += 256) q[e] = s[e];
+    if (d) {
+        const int rows = min(8, O - (int)blockIdx.x * 8);
+        const float* wr = wsq + (long)blockIdx.x * 8 * I;
+#pragma unroll 8
+        for (int e = tid; e < rows * I; e += 256) wl[e] = wr[e];
+    }
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {
+        float mx = 0.f;
+        if (prenorm)
+            for (int i = lane; i < I; i += 64) mx = fmaxf(mx, fabsf(q[n * I + i]));
+        for (int st = 32; st > 0; st >>= 1) mx = fmaxf(mx, __shfl_xor(mx, st));
+        if (lane == 0) {
+            rowmax[n] = prenorm ? mx : 1.f;
+            if (blockIdx.x == 0) aux[n] = prenorm ? mx : 1.f;
+        }
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int n = wave; n < N; n += 4) {
+        // (divided by, not multiplied with the inverse: the row's maximum must become exactly +-1 -- the backward pass finds it again as |sn| == r)
+        const float m = rowmax[n];
+        for (int i = lane; i < I; i += 64) {
+            const float v = q[n * I + i] / m;
+            q[n * I + i] = v;
+            acc += v * v;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    const float r = rsqrtf(red[0] / (float)(N * I));
+    if (blockIdx.x == 0 && tid == 0) aux[N] = r;
+    for (int e = tid; e < N * I; e += 256) {
+        const float v = q[e] * r;
+        if (blockIdx.x == 0) sn[e] = v;
+        q[e] = v * v;
+    }
+    __syncthreads();
+    if (!d) return;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        const int ol = wave * 2 + k, o = blockIdx.x * 8 + ol;
+        if (o >= O) break;
+        float a[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) a[n] = 0.f;
+#pragma unroll 1
+        for (int i = lane; i < I; i += 64) {
+            const float wv = wl[ol * I + i];
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                if (n < N) a[n] += q[n * I + i] * wv;
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            float v = a[n];
+            for (int st = 32; st > 0; st >>= 1) v += __shfl_xor(v, st);
+            if (lane == 0 && n < N) d[(long)n * O + o] = rsqrtf(v + 1e-8f);
+        }
+    }
+}
+
+// Backward, pass 1: grid = (ceil(I / 64), ceil(O / 64)); workgroup (ib, ob) owns 64 style columns x 64 output channels, a wave 16 of the
+// channels.  gt = -1/2 gd d^3 for its channels in LDS; gwsq[o][i] = sum_n gt[n][o] sn[n][i]^2 is written directly (every (o, i) has one
+// owner); its share of gq[n][i] = sum_o gt[n][o] wsq[o][i] goes to partq[ob][n][i].
+template <int NB>
+__global__ __launch_bounds__(256) void style_factors_backward1_kernel(const float* sn, const float* d, const float* wsq, const float* gd, float* gwsq,
+                                                                      float* partq, int N, int I, int O) {
+    __shared__ float gt[NB * 64];
+    __shared__ float pq[4 * NB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 64 + lane, ob = blockIdx.y * 64;
+    const bool in = i < I;
+    for (int e = tid; e < N * 64; e += 256) {
+        const int n = e >> 6, o = ob + (e & 63);
+        float v = 0.f;
+        if (gd && o < O) {
+            const float dv = d[(long)n * O + o];
+            v = -0.5f * gd[(long)n * O + o] * dv * dv * dv;
+        }
+        gt[e] = v;
+    }
+    float q[NB], acc[NB], wv[16];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const float v = (in && n < N) ? sn[(long)n * I + i] : 0.f;
+        q[n] = v * v;
+        acc[n] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int o = ob + wave * 16 + k;
+        wv[k] = (in && o < O) ? wsq[(long)o * I + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ol = wave * 16 + k, o = ob + ol;
+        float gw = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            if (n < N) {
+                const float g = gt[n * 64 + ol];
+                acc[n] += g * wv[k];
+                gw += g * q[n];
+            }
+        if (in && o < O && gwsq) gwsq[(long)o * I + i] = gw;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) pq[(wave * NB + n) * 64 + lane] = acc[n];
+    __syncthreads();
+    for (int e = tid; e < N * 64; e += 256) {
+        const int n = e >> 6, l = e & 63, ii = blockIdx.x * 64 + l;
+        if (ii < I)
+            partq[((long)blockIdx.y * N + n) * I + ii] = pq[n * 64 + l] + pq[(NB + n) * 64 + l] + pq[(2 * NB + n) * 64 + l] + pq[(3 * NB + n) * 64 + l];
+    }
+}
+
+// Backward, pass 2: workgroup n finishes row n.  g_tot = gsn + 2 sn gq for ALL rows (LDS; every workgroup needs the batch-global c).
+// With A_n = (1/r) sum_i g_tot sn, c = sum_n A_n, B_n = sum_i sn^2:
+//   g1 = r g_tot - (r^2 c / (N I)) sn                              (through sn = s1 * rsqrt(mean s1^2))
+//   gs = g1 / M_n - [|sn_i| == r] sign(sn_i) R_n / (M_n ties),  R_n = r A_n - (r c / (N I)) B_n        (through s1 = s / max|s|, prenorm only)
+__global__ __launch_bounds__(256) void style_factors_backward2_kernel(const float* sn, const float* aux, const float* gsn, const float* partq, float* gs,
+                                                                      int N, int I, int S, int prenorm) {
+    extern __shared__ float gtot[];                // [N][I] g_tot, then [N][I] sn
+    __shared__ float A[32];
+    __shared__ float red[256];
+    __shared__ int redi[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+    float* snl = gtot + N * I;
+    const float r = aux[N], M = aux[n];
+    const int NI = N * I;
+    for (int e0 = tid; e0 < NI; e0 += 1024) {      // batches of 4 elements x 8 slices: 40 independent loads requested before the first use
+        float pv[4][8], sv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            sv[u] = e < NI ? sn[e] : 0.f;
+            gv[u] = (gsn && e < NI) ? gsn[e] : 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) pv[u][sb] = (e < NI && sb < S) ? partq[(long)sb * NI + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            float gq = ((pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3])) + ((pv[u][4] + pv[u][5]) + (pv[u][6] + pv[u][7]));
+            for (int sb = 8; sb < S; ++sb) gq += e < NI ? partq[(long)sb * NI + e] : 0.f;       // (O > 512)
+            if (e < NI) {
+                snl[e] = sv[u];
+                gtot[e] = gv[u] + 2.f * sv[u] * gq;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = wave; k < N; k += 4) {
+        float a = 0.f;
+        for (int i = lane; i < I; i += 64) a += gtot[k * I + i] * snl[k * I + i];
+        for (int st = 32; st > 0; st >>= 1) a += __shfl_xor(a, st);
+        if (lane == 0) A[k] = a / r;
+    }
+    __syncthreads();
+    float c = 0.f;
+    for (int k = 0; k < N; ++k) c += A[k];
+    const float ni = (float)N * (float)I, coef = r * r * c / ni;
+    float Rn = 0.f;
+    int ties = 1;
+    if (prenorm) {
+        float b = 0.f;
+        int t = 0;
+        for (int i = tid; i < I; i += 256) {
+            const float v = snl[n * I + i];
+            b += v * v;
+            t += (fabsf(v) == r) ? 1 : 0;
+        }
+        red[tid] = b; redi[tid] = t;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) { red[tid] += red[tid + st]; redi[tid] += redi[tid + st]; }
+            __syncthreads();
+        }
+        Rn = r * A[n] - (r * c / ni) * red[0];
+        ties = redi[0] > 0 ? redi[0] : 1;
+    }
+    for (int i = tid; i < I; i += 256) {
+        const float v = snl[n * I + i];
+        float g = r * gtot[n * I + i] - coef * v;
+        if (prenorm) {
+            g /= M;
+            if (fabsf(v) == r) g -= (v > 0.f ? 1.f : -1.f) * Rn / (M * (float)ties);
+        }
+        gs[(long)n * I + i] = g;
+    }
+}
+
+extern "C" int shg_style_factors_f32(const float* s, const float* wsq, float* sn, float* d, float* aux, int N, int I, int O, int prenorm, void* stream) {
+    SHG_CHECK_ARG(s && sn && aux && N >= 1 && N <= 32 && I >= 1 && I <= 1024 && (long)N * I <= 8192 && (!d || (wsq && O >= 1)), "style_factors: N <= 32, N * I <= 8192, I <= 1024");
+    const dim3 grid(d ? (O + 7) / 8 : 1);
+    const size_t lds = ((size_t)N * I + (d ? 8 * (size_t)I : 0)) * sizeof(float);          // <= 32 KB + 32 KB
+    if (N <= 8) hipLaunchKernelGGL((style_factors_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, s, wsq, sn, d, aux, N, I, O, prenorm);
+    else if (N <= 16) hipLaunchKernelGGL((style_factors_kernel<16>), grid, dim3(256), lds, (hipStream_t)stream, s, wsq, sn, d, aux, N, I, O, prenorm);
+    else hipLaunchKernelGGL((style_factors_kernel<32>), grid, dim3(256), lds, (hipStream_t)stream, s, wsq, sn, d, aux, N, I, O, prenorm);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// gs [N,I], gwsq [O,I] (may be null) from gsn [N,I] / gd [N,O] (either may be null); partq: scratch of ceil(O/64) * N * I floats
+extern "C" int shg_style_factors_backward_f32(const float* sn, const float* d, const float* wsq, const float* aux, const float* gsn, const float* gd,
+                                              float* gs, float* gwsq, float* partq, int N, int I, int O, int prenorm, void* stream) {
+    SHG_CHECK_ARG(sn && d && wsq && aux && gs && partq && (gsn || gd) && N >= 1 && N <= 32 && I >= 1 && O >= 1 && (long)N * I <= 8192,
+                  "style_factors_backward: N <= 32, N * I <= 8192");
+    const dim3 grid((I + 63) / 64, (O + 63) / 64);
+    if (N <= 8) hipLaunchKernelGGL((style_factors_backward1_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, sn, d, wsq, gd, gwsq, partq, N, I, O);
+    else if (N <= 16) hipLaunchKernelGGL((style_factors_backward1_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, sn, d, wsq, gd, gwsq, partq, N, I, O);
+    else hipLaunchKernelGGL((style_factors_backward1_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, sn, d, wsq, gd, gwsq, partq, N, I, O);
+    SHG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(style_factors_backward2_kernel, dim3(N), dim3(256), (size_t)2 * N * I * sizeof(float), (hipStream_t)stream, sn, aux, gsn, partq, gs, N, I,
+                       (int)grid.y, prenorm);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 extern "C" int shg_normalize_2nd_moment_f32(const float* x, float* y, int N, int K, float eps, void* stream) {
     SHG_CHECK_ARG(x && y && N >= 1 && K >= 1, "normalize_2nd_moment: bad arguments");
     hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, y, K, eps);

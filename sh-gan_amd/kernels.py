@@ -717,6 +717,38 @@ def demod_weight_backward(wn, sfac, gwn, gwsq):
     return gw
 
 
+def style_factors_supported(styles, wsq):
+    n, i = styles.shape
+    return (styles.is_cuda and styles.dtype == torch.float32 and styles.ndim == 2 and wsq is not None and wsq.ndim == 2 and wsq.shape[1] == i
+            and n <= 32 and n * i <= 8192 and i <= 1024)
+
+
+def style_factors(styles, wsq, prenorm=False):
+    """-> (sn [N,I], dcoefs [N,O], aux [N+1]): the style side of modulated_conv2d (csrc/dense.hip: style_factors_kernel)."""
+    L = _Launch()
+    styles, wsq = L.req(styles, 'styles'), L.req(wsq, 'wsq')
+    n, i = styles.shape
+    o = wsq.shape[0]
+    sn, d, aux = L.new((n, i)), L.new((n, o)), L.new((n + 1,))
+    with L:
+        check(_lib.get_lib().shg_style_factors_f32(_ptr(styles), _ptr(wsq), _ptr(sn), _ptr(d), _ptr(aux), n, i, o, int(bool(prenorm)), L.stream()),
+              'style_factors')
+    return sn, d, aux
+
+
+def style_factors_backward(sn, d, wsq, aux, gsn, gd, prenorm=False, want_wsq=True):
+    """-> (g_styles [N,I], g_wsq [O,I] | None)."""
+    L = _Launch()
+    sn, d, wsq, aux, gsn, gd = L.req(sn, 'sn'), L.req(d, 'd'), L.req(wsq, 'wsq'), L.req(aux, 'aux'), L.req(gsn, 'gsn'), L.req(gd, 'gd')
+    n, i = sn.shape
+    o = wsq.shape[0]
+    gs, gw, part = L.new((n, i)), (L.new((o, i)) if want_wsq else None), L.new(((o + 63) // 64, n, i))
+    with L:
+        check(_lib.get_lib().shg_style_factors_backward_f32(_ptr(sn), _ptr(d), _ptr(wsq), _ptr(aux), _ptr(gsn), _ptr(gd), _ptr(gs), _ptr(gw), _ptr(part),
+                                                            n, i, o, int(bool(prenorm)), L.stream()), 'style_factors_backward')
+    return gs, gw
+
+
 def matmul_nn(a, b, scale=1.0):
     """scale * a[N,M] @ b[M,K] (csrc/dense.hip: the input gradient of a dense layer)."""
     L = _Launch()

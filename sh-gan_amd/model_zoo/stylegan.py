@@ -275,11 +275,55 @@ def _weight_factors(half, weight, demodulate):
     return weight, wsq
 
 
+def _style_factors_composed(half, styles, wsq):
+    """The style side of a demodulated layer (stylegan.py:138,147,155) from differentiable tensor operators."""
+    if half:
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I, :138
+    styles = styles * styles.square().mean().rsqrt()                                       # :147
+    if styles.is_cuda and styles.dtype == torch.float32 and styles.ndim == 2:
+        from .stylegan_utils import dense_ops
+        return styles, (dense_ops.nt(styles.square(), wsq) + 1e-8).rsqrt()                 # :155, [N,O] -- s^2 @ wsq^T on the dense kernels
+    return styles, (styles.square().matmul(wsq.t()) + 1e-8).rsqrt()
+
+
+class _StyleFactorsFn(torch.autograd.Function):
+    """(normalised styles, demodulation coefficients) in ONE kernel, their first-order backward in two (csrc/dense.hip) -- instead of ~11
+    + ~25 launches of 4 us per layer and pass.  Under ``create_graph`` (path-length regulariser: the gradient with respect to the styles is
+    differentiated again) the backward re-derives both outputs from the saved INPUTS with the composed operators and differentiates that,
+    so it stays a differentiable function of the styles, the weights and the incoming gradients."""
+    @staticmethod
+    def forward(ctx, styles, wsq, half):
+        sn, d, aux = kernels.style_factors(styles.detach(), wsq.detach(), half)
+        ctx.save_for_backward(styles, wsq, sn, d, aux)
+        ctx.half = half
+        return sn, d
+
+    @staticmethod
+    def backward(ctx, gsn, gd):
+        styles, wsq, sn, d, aux = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                s_in = styles if styles.requires_grad else styles.detach().requires_grad_(True)
+                w_in = wsq if wsq.requires_grad else wsq.detach().requires_grad_(True)
+                sn2, d2 = _style_factors_composed(ctx.half, s_in, w_in)
+                gs, gw = torch.autograd.grad([sn2, d2], [s_in, w_in], [gsn, gd], create_graph=True, allow_unused=True)
+            return (gs if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), None
+        gs, gw = kernels.style_factors_backward(sn, d, wsq, aux, gsn, gd, ctx.half, want_wsq=ctx.needs_input_grad[1])
+        return (gs if ctx.needs_input_grad[0] else None), gw, None
+
+
+FUSED_STYLE_FACTORS = os.environ.get('SHG_FUSED_STYLE', '1') == '1'       # (A/B switch; SHG_FUSED_STYLE=0: the tensor-op composition)
+
+
 def _modulation_factors(half, weight, styles, demodulate, wfac=None):
     """(normalised weight, normalised styles, demodulation coefficients [N,O] | None) of stylegan.py:136-155; ``wfac`` = a cached
     ``_weight_factors`` result."""
     dcoefs = None
     weight, wsq = wfac if wfac is not None else _weight_factors(half, weight, demodulate)
+    if (FUSED_STYLE_FACTORS and demodulate and grad_ops.wants_grad(styles, wsq) and kernels.style_factors_supported(styles, wsq)
+            and wsq.dtype == torch.float32):
+        styles, dcoefs = _StyleFactorsFn.apply(styles.contiguous(), wsq.contiguous(), bool(half))
+        return weight, styles, dcoefs
     if half and demodulate:
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)                                              # max_I, :138
     if demodulate:

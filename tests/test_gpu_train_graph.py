@@ -336,3 +336,40 @@ def test_dmain_one_critic_pass_over_the_stacked_batch_equals_the_two_passes_of_t
     worst = max(float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-20)) for n in g0)
     print(f'Dmain, one stacked critic pass vs two passes ({"fp16 blocks" if fp16 else "float32"}): worst relative gradient difference {worst:.2e}')
     assert worst < (2e-2 if fp16 else 1e-5)
+
+
+@pytest.mark.parametrize('half', [False, True])
+@pytest.mark.parametrize('n,i,o', [(8, 512, 512), (4, 64, 128), (16, 512, 64), (3, 100, 70)])
+def test_fused_style_factors_vs_float64_autograd(half, n, i, o):
+    """``_StyleFactorsFn`` (csrc/dense.hip style_factors kernels: normalised styles + demodulation coefficients, stylegan.py:138,147,155)
+    against the same formulas evaluated by torch autograd in float64: both outputs, the first-order gradients with respect to the
+    styles and to wsq, and a second-order quantity (the gradient of a function of the styles' gradient -- what the path-length
+    regulariser needs; that pass runs the composed form under create_graph)."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo import stylegan as sg
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + i + o)
+    s64 = (torch.randn(n, i, generator=g, dtype=torch.float64) + 1.0).to(DEV)
+    w64 = torch.rand(o, i, generator=g, dtype=torch.float64).to(DEV) * 0.01
+    a64, b64 = torch.randn(n, i, generator=g, dtype=torch.float64).to(DEV), torch.randn(n, o, generator=g, dtype=torch.float64).to(DEV)
+
+    def ref(s, w):
+        if half:
+            s = s / s.norm(float('inf'), dim=1, keepdim=True)
+        s = s * s.square().mean().rsqrt()
+        return s, (s.square().matmul(w.t()) + 1e-8).rsqrt()
+
+    def run(fn, s, w, a, b):
+        s, w = s.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        with torch.enable_grad():
+            sn, d = fn(s, w)
+            loss = (sn * a).sum() + (d * b).sum()
+            gs, gw = torch.autograd.grad(loss, [s, w], create_graph=False)
+            sn2, d2 = fn(s, w)
+            (g1,) = torch.autograd.grad((sn2 * a).sum() + (d2 * b).sum(), [s], create_graph=True)
+            (gg,) = torch.autograd.grad(g1.square().sum(), [s])
+        return sn.detach(), d.detach(), gs, gw, gg
+    want = run(ref, s64, w64, a64, b64)
+    got = run(lambda s, w: sg._StyleFactorsFn.apply(s, w, half), s64.float(), w64.float(), a64.float(), b64.float())
+    for name, x, y in zip(('sn', 'dcoefs', 'g_styles', 'g_wsq', 'second-order g_styles'), got, want):
+        err = float((x.double() - y).abs().max() / (y.abs().max() + 1e-30))
+        assert err < 2e-5, (name, err)
