@@ -471,7 +471,7 @@ class conv2d_layer(nn.Module):
                                             down=self.down, padding=self.padding, flip_weight=(self.up == 1))
         if ak is None or (y.dtype == torch.float16 and y.shape[1] % 8):
             if self.bias is not None:
-                y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+                y = grad_ops.add_channel_bias(y, self.bias)
             return self.activation(y, gain=gain) if self.activation is not None else y * gain
         return grad_ops.bias_act(y, self.bias, **ak)
 
@@ -634,7 +634,7 @@ class torgb_layer(conv2d_layer):
             # training rows and float16 blocks (stylegan.py:325-337) + the skip architecture's upsample2d(img) + y (comodgan.py:331-338);
             # the RGB branch itself is float32 (`y.to(torch.float32)`, comodgan.py:337)
             y = modulated_conv2d(x=x, weight=self.weight, styles=self.affine(w) * self.weight_gain, demodulate=False)
-            y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+            y = grad_ops.add_channel_bias(y, self.bias)
             y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
         if styles_sd is not None:
