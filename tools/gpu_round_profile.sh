@@ -5,12 +5,13 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# (bench runs warmup + steps + 3 single-stream latency steps = 10 forward passes here: the divisor of prof_summary.py)
+# (bench runs warmup + steps + 3 single-stream latency steps = 10 forward passes here: the divisor of prof_summary.py; --graph off: the
+#  auto mode would add its trial steps and the capture warm-up)
 # kernel durations: one batch at a time on one stream (what bench.py's roofline block times with HIP events), then the same command
 # with the default three-stream pipeline (kernels of different batches overlap: longer individual durations, shorter wall time)
 for MODE in single pipelined; do
   D=1; [ $MODE = pipelined ] && D=3
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step > $OUT/prof_stdout_$MODE.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --graph off --no-cpu-baseline --no-second-config --no-train-step > $OUT/prof_stdout_$MODE.log 2>&1 )
   cd $GRAFT_REPO_ROOT
   F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   SUF=""; [ $MODE = pipelined ] && SUF="_pipelined"
