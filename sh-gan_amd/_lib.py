@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -100,6 +100,7 @@ _SIGS = {
     'shg_conv2d_wgrad_f16_workspace_bytes': [c_i] * 6,
     'shg_conv2d_wgrad_f16': [c_fp, c_fp, c_fp] + [c_i] * 10 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_upfirdn2d_f16': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],
+    'shg_relayout_f32_f16': [c_fp, c_fp, c_i, c_i, c_l, c_i, c_fp],
     'shg_bias_act_f16': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_f, c_f, c_f, c_fp],
     'shg_bias_act_backward_f16': [c_fp, c_fp, c_fp, c_l, c_i, c_f, c_f, c_f, c_fp],
     'shg_modtail_backward_f32_blocks': [c_l],

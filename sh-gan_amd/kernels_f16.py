@@ -207,6 +207,23 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
     return y if xp.shape[1] == c else y[:, :c].contiguous(memory_format=CL)
 
 
+def relayout_supported(x):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.ndim == 4 and x.shape[1] % 8 == 0 and x.shape[0] <= 65535 and x.numel() > 0
+            and ((x.dtype == torch.float32 and x.is_contiguous()) or (x.dtype == torch.float16 and x.is_contiguous(memory_format=CL))))
+
+
+def relayout(x):
+    """float32 NCHW -> float16 channels_last, or float16 channels_last -> float32 NCHW (the other layout of the other dtype), one pass."""
+    L = kernels._Launch()
+    n, c, h, w = x.shape
+    to_half = x.dtype == torch.float32
+    x = L.req(x, 'x') if to_half else _h(L, x, 'x')
+    y = _new_cl(L, n, c, h, w) if to_half else torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    with kernels._timed(L, 'relayout', 6.0 * x.numel()):
+        check(_lib.get_lib().shg_relayout_f32_f16(kernels._ptr(x), kernels._ptr(y), n, c, h * w, int(to_half), L.stream()), 'relayout')
+    return y
+
+
 def bias_act(x, bias=None, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
     L = kernels._Launch()
     x = _h(L, x, 'x')

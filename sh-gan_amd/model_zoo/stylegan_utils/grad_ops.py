@@ -31,9 +31,30 @@ def to_block_dtype(x, use_fp16):
     channels-last (NHWC) -- the layout the fp16 kernels take --, float32 ones NCHW-contiguous."""
     if x is None:
         return None
+    want = torch.float16 if use_fp16 else torch.float32
+    if RELAYOUT_KERNEL and x.dtype != want and x.dtype in (torch.float16, torch.float32) and kernels_f16.relayout_supported(x):
+        return _RelayoutFn.apply(x)
     if use_fp16:
         return x.to(dtype=torch.float16, memory_format=CL)
     return x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
+
+RELAYOUT_KERNEL = True       # (A/B switch: False = torch's .to(dtype, memory_format))
+
+
+class _RelayoutFn(torch.autograd.Function):
+    """The cast between the two activation layouts as one transposing kernel; its gradient is the opposite cast."""
+    @staticmethod
+    def forward(ctx, x):
+        return kernels_f16.relayout(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.dtype == torch.float32:
+            g = g.contiguous()
+        else:
+            g = g.contiguous(memory_format=CL)
+        return _RelayoutFn.apply(g)
 
 
 class _BiasActBwdFn(torch.autograd.Function):

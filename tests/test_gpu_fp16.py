@@ -401,3 +401,30 @@ def test_fp16_blocks_full_width_512_batch16_properties():
     assert rel_err(c(sub), c(a[:2])) < 5e-3
     m = mask.astype(bool)
     assert np.array_equal(np.where(m, u8.cpu().numpy(), 0), np.where(m, real_u8, 0))
+
+
+@pytest.mark.parametrize('shape', [(8, 512, 64, 64), (3, 64, 33, 17), (2, 72, 8, 8), (1, 8, 1, 1), (4, 128, 256, 256)])
+def test_block_boundary_cast_kernel_is_the_torch_cast(shape):
+    """`x.to(dtype)` at the block boundaries (stylegan.py:486-495,659-663) as the transposing relayout kernel: bit-identical to torch's
+    `.to(dtype, memory_format)` in both directions (round-to-nearest-even, overflow to inf), the result in the layout of its dtype, and
+    its gradient the opposite cast."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels_f16
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    g = torch.Generator(device='cpu').manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 300).to('cuda:0')
+    x.view(-1)[::7] *= 1e3                                   # some values beyond the half range
+    h = kernels_f16.relayout(x)
+    ref = x.to(dtype=torch.float16, memory_format=torch.channels_last)
+    assert h.dtype == torch.float16 and h.is_contiguous(memory_format=torch.channels_last) and torch.equal(h, ref)
+    back = kernels_f16.relayout(ref)
+    assert back.dtype == torch.float32 and back.is_contiguous() and torch.equal(back, ref.to(torch.float32))
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        y = grad_ops.to_block_dtype(xr, True)
+        assert y.dtype == torch.float16 and y.grad_fn is not None and 'Relayout' in type(y.grad_fn).__name__
+        w = torch.randn(shape, generator=g).to('cuda:0').to(dtype=torch.float16, memory_format=torch.channels_last)
+        (gx,) = torch.autograd.grad((y * w).sum(), [xr])
+        assert gx.dtype == torch.float32 and torch.equal(gx, w.to(torch.float32))
+        z = grad_ops.to_block_dtype(y, False)
+        assert z.dtype == torch.float32 and torch.equal(z, ref.to(torch.float32))
