@@ -268,6 +268,10 @@ int shg_minibatch_std_f32(const float* x, float* y, float* stat, int N, int C, i
  *   (2H+1) x (2W+1) result are NOT written (shg_conv2d_f16_needs_clear: zero y first). */
 long shg_conv2d_f16_packed_weight_elems(int T, int O, int I);
 int shg_conv2d_f16_pack_weight(const void* w, void* wp, int T, int O, int I, void* stream);
+/* the same operand order straight from a torch-layout weight: src [O][I][T] halves, or [I][O][T] when `transposed` (conv_transpose2d layout /
+ * the channel-transposed weight of an input gradient); `flip` reverses the taps (180-degree rotation); input channels are zero-padded to a
+ * multiple of 32 (wp holds shg_conv2d_f16_packed_weight_elems(T, O, roundup(I, 32)) halves). */
+int shg_conv2d_f16_pack_weight_oihw(const void* src, void* wp, int T, int O, int I, int transposed, int flip, void* stream);
 int shg_conv2d_f16(const void* x, const void* w, const float* bias, void* y, int N, int I, int O, int H, int W, int k, int stride, int pad,
                    int mode, int crop, int OH, int OW, void* stream);
 int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW);

@@ -1247,6 +1247,38 @@ extern "C" int shg_conv2d_f16_pack_weight(const void* w, void* wp, int T, int O,
     return SHG_OK;
 }
 
+// The same operand order straight from a torch-layout weight: src [A][B][T] halves (T = k*k), logical W[o][i][t] = src[o][i][t] (A = O, B = I)
+// or, `transposed`, src[i][o][t] (A = I, B = O: the conv_transpose2d layout / the channel-transposed weight of an input gradient); `flip`
+// reverses the taps (t -> T-1-t: the 180-degree rotation of an input gradient).  Input channels beyond I read zero (Ip = I rounded up to 32).
+// One gather pass instead of flip + permute-copy + pack (three launches per fp16 data-gradient convolution).
+__global__ __launch_bounds__(256) void pack_weight_oihw_f16_kernel(const _Float16* src, _Float16* wp, int T, int O, int I, int Ip, int transposed, int flip,
+                                                                   long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int c16n = Ip >> 4, c16 = (int)(r % c16n);
+        r /= c16n;
+        const int t = (int)(r % T), ob = (int)(r / T);
+        const int o = ob * 32 + (lane & 31), i = c16 * 16 + (lane >> 5) * 8 + el;
+        const int ts = flip ? T - 1 - t : t;
+        _Float16 v = (_Float16)0.f;
+        if (o < O && i < I) v = transposed ? src[((long)i * O + o) * T + ts] : src[((long)o * I + i) * T + ts];
+        wp[e] = v;
+    }
+}
+
+extern "C" int shg_conv2d_f16_pack_weight_oihw(const void* src, void* wp, int T, int O, int I, int transposed, int flip, void* stream) {
+    SHG_CHECK_ARG(src && wp && (T == 1 || T == 9) && O >= 1 && I >= 1, "conv2d_f16_pack_weight_oihw: bad arguments");
+    const int Ip = (I + 31) / 32 * 32;
+    const long total = shg_conv2d_f16_packed_weight_elems(T, O, Ip);
+    int grid = shg_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_weight_oihw_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, (_Float16*)wp, T, O, I, Ip,
+                       transposed, flip, total);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 // the transposed form writes every pixel of its crop window only where the (2H+1) x (2W+1) result exists: callers zero y first when
 // crop + OH > 2H + 1 (shg_conv2d_f16_needs_clear says so)
 extern "C" int shg_conv2d_f16_needs_clear(int H, int W, int crop, int OH, int OW) {

@@ -46,16 +46,35 @@ def _pad_channels(x, mult):
     return y
 
 
-def _taps_weight(L, w_oihw, i_mult):
+PACK_DIRECT = True        # (A/B switch) pack straight from the torch-layout tensor; False: permute-copy + pack as before
+
+
+def _taps_weight(L, w_oihw, i_mult, flip=False):
     """[O,I,kh,kw] halves -> the MFMA-operand-order tensor shg_conv2d_f16 takes ([ceil(O/32)][kh*kw][Ip/16][64][8], input channels
-    zero-padded to a multiple of ``i_mult``): a [kh*kw][O][Ip] staging copy, then shg_conv2d_f16_pack_weight."""
+    zero-padded to a multiple of ``i_mult``).  A contiguous tensor, or the ``transpose(0, 1)`` view of one, is packed by ONE gather kernel
+    (``flip``: taps reversed -- the rotated weight of an input gradient); anything else through a [kh*kw][O][Ip] staging copy."""
     o, i, kh, kw = w_oihw.shape
+    lib = _lib.get_lib()
+    if PACK_DIRECT and i_mult == 32 and kh == kw and kh in (1, 3):
+        src, tr = None, 0
+        if w_oihw.is_contiguous():
+            src = w_oihw
+        elif w_oihw.transpose(0, 1).is_contiguous():
+            src, tr = w_oihw.transpose(0, 1), 1
+        if src is not None:
+            ip = (i + 31) // 32 * 32
+            wp = torch.empty(lib.shg_conv2d_f16_packed_weight_elems(kh * kw, o, ip), device=w_oihw.device, dtype=torch.float16)
+            with L:
+                check(lib.shg_conv2d_f16_pack_weight_oihw(kernels._ptr(src), kernels._ptr(wp), kh * kw, o, i, tr, int(bool(flip)), L.stream()),
+                      'conv2d_f16_pack_weight_oihw')
+            return wp
+    if flip:
+        w_oihw = w_oihw.flip(2, 3)
     wt = w_oihw.permute(2, 3, 0, 1)
     ip = (i + i_mult - 1) // i_mult * i_mult
     if ip != i:
         wt = F.pad(wt, (0, ip - i))
     wt = wt.contiguous()
-    lib = _lib.get_lib()
     wp = torch.empty(lib.shg_conv2d_f16_packed_weight_elems(kh * kw, o, ip), device=w_oihw.device, dtype=torch.float16)
     with L:
         check(lib.shg_conv2d_f16_pack_weight(kernels._ptr(wt), kernels._ptr(wp), kh * kw, o, ip, L.stream()), 'conv2d_f16_pack_weight')
@@ -71,14 +90,15 @@ class PackedWeight:
         self.wp, self.o, self.i, self.k = wp, o, i, k
 
 
-def pack_weight(weight, transposed=False):
-    """weight [O,I,k,k] halves (``transposed``: the torch conv_transpose2d layout [Cin,Cout,3,3]) -> PackedWeight."""
+def pack_weight(weight, transposed=False, flip=False):
+    """weight [O,I,k,k] halves (``transposed``: the torch conv_transpose2d layout [Cin,Cout,3,3]; ``flip``: taps rotated by 180 degrees --
+    ``pack_weight(w, transposed=True, flip=True)`` is the weight of the input gradient of ``conv2d(x, w)``) -> PackedWeight."""
     if weight.dtype != torch.float16 or weight.ndim != 4 or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (1, 3):
         raise _lib.ShgError('pack_weight: weight must be float16 [O,I,k,k] with k = 1 or 3')
     L = kernels._Launch()
     L._own(weight, 'weight')
     w = weight.detach().transpose(0, 1) if transposed else weight.detach()
-    return PackedWeight(_taps_weight(L, w, 32), w.shape[0], w.shape[1], w.shape[2])
+    return PackedWeight(_taps_weight(L, w, 32, flip=flip), w.shape[0], w.shape[1], w.shape[2])
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, in_scale=None, out_scale=None, noise=None, noise_strength=1.0, act=None, gain=1.0,

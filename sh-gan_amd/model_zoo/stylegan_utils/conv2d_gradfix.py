@@ -125,6 +125,11 @@ def _conv_input_grad(g, weight, x_shape, stride, padding):
     the input extent (the output_padding rule of conv2d_gradfix.py:96-105)."""
     k = weight.shape[2]
     if stride == 1:
+        if g.dtype == torch.float16 and g.is_cuda and not _wants_grad(g, weight):
+            # first-order pass of a half layer: the rotated, channel-transposed weight is built by the pack kernel itself (one gather
+            # instead of flip + permute-copy + pack)
+            pw = kernels_f16.pack_weight(weight.detach().to(torch.float16), transposed=True, flip=True)
+            return kernels_f16.conv2d(g, pw, None, 1, k - 1 - padding)
         return conv2d(g, weight.transpose(0, 1).flip(2, 3), stride=1, padding=k - 1 - padding)
     if k != 3:
         raise NotImplementedError('conv2d backward: 1x1 stride-2 convolutions (the forward decimates with upfirdn2d first)')

@@ -428,3 +428,34 @@ def test_block_boundary_cast_kernel_is_the_torch_cast(shape):
         assert gx.dtype == torch.float32 and torch.equal(gx, w.to(torch.float32))
         z = grad_ops.to_block_dtype(y, False)
         assert z.dtype == torch.float32 and torch.equal(z, ref.to(torch.float32))
+
+
+@pytest.mark.parametrize('o,i,k', [(64, 64, 3), (128, 40, 3), (8, 72, 1), (96, 512, 3)])
+def test_direct_weight_pack_equals_the_staged_pack(o, i, k):
+    """``pack_weight`` straight from the torch-layout tensor (one gather kernel; transposed / rotated forms for the transposed convolution
+    and the input gradient) against the staged form (torch flip + permute-copy, then the [T][O][I] pack kernel): identical operand tensors."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels_f16
+    g = torch.Generator(device='cpu').manual_seed(o + i + k)
+    w = torch.randn(o, i, k, k, generator=g).to('cuda:0', torch.float16)
+    for tr in (False, True):
+        for fl in (False, True):
+            src = w.transpose(0, 1).contiguous() if tr else w          # the [Cin, Cout, k, k] layout when transposed
+            kernels_f16.PACK_DIRECT = True
+            a = kernels_f16.pack_weight(src, transposed=tr, flip=fl)
+            kernels_f16.PACK_DIRECT = False
+            try:
+                b = kernels_f16.pack_weight(src, transposed=tr, flip=fl)
+            finally:
+                kernels_f16.PACK_DIRECT = True
+            assert (a.o, a.i, a.k) == (b.o, b.i, b.k) == (o, i, k) and torch.equal(a.wp, b.wp), (tr, fl)
+    # and the input gradient of a half convolution through it: against torch autograd in float32
+    x = torch.randn(2, i, 12, 10, generator=g).to('cuda:0')
+    gy = torch.randn(2, o, 12 if k == 3 else 12, 10, generator=g).to('cuda:0')
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = torch.nn.functional.conv2d(xr, w.float(), padding=k // 2)
+        (want,) = torch.autograd.grad(y, [xr], [gy])
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    got = conv2d_gradfix._conv_input_grad(gy.to(dtype=torch.float16, memory_format=torch.channels_last), w, x.shape, 1, k // 2)
+    assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
