@@ -76,11 +76,12 @@ class _BiasActBwdFn(torch.autograd.Function):
 
 
 def channel_sum(t):
-    """Sum over every axis but the channel axis, accumulated in float32 (differentiable).  A reduction to C values runs on C workgroups:
+    """Sum over every axis but the channel axis, accumulated in float32 (float64 inputs: float64; differentiable).  A reduction to C values runs on C workgroups:
     the RGB branch's [8, 3, 512, 512] bias gradient took 670 us as one reduction; rows first, then the rest, is two launches of ~6 us."""
+    acc = t.dtype if t.dtype == torch.float64 else torch.float32
     if t.ndim == 4 and t.shape[1] <= 32 and t.shape[2] * t.shape[3] >= 16384:
-        return t.sum(3, dtype=torch.float32).sum([0, 2])
-    return t.sum([0] + list(range(2, t.ndim)), dtype=torch.float32)
+        return t.sum(3, dtype=acc).sum([0, 2])
+    return t.sum([0] + list(range(2, t.ndim)), dtype=acc)
 
 
 class _ChannelBiasFn(torch.autograd.Function):

@@ -218,3 +218,26 @@ def test_activation_arguments_reach_the_kernels():
         assert seen['thin']['alpha'] == 0.3 and seen['thin']['clamp'] == 7 and seen['thin']['gain'] == 0.5
     finally:
         kernels.dense, kernels.conv1x1_thin_in = old
+
+
+def test_channel_sum_and_channel_bias_node_on_cpu():
+    """``grad_ops.channel_sum`` (the two-step form for thin tensors) equals the plain reduction, and ``add_channel_bias`` has the gradients
+    of ``y + bias.view(1, -1, 1, 1)`` -- first and second order (pure tensor code: runs without the HIP library)."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    g = torch.Generator().manual_seed(3)
+    for shape in ((2, 3, 128, 128), (2, 3, 8, 8), (1, 40, 128, 130)):
+        t = torch.randn(shape, generator=g, dtype=torch.float64)
+        assert torch.allclose(grad_ops.channel_sum(t.float()).double(), t.sum([0, 2, 3]), rtol=1e-5, atol=1e-4)
+    w = torch.randn(2, 3, 130, 128, generator=g, dtype=torch.float64)
+    res = []
+    with torch.enable_grad():
+        for fn in (grad_ops.add_channel_bias, lambda yy, bb: yy + bb.view(1, -1, 1, 1)):
+            y = torch.randn(2, 3, 130, 128, generator=torch.Generator().manual_seed(4), dtype=torch.float64, requires_grad=True)
+            b = torch.randn(3, generator=torch.Generator().manual_seed(5), dtype=torch.float64, requires_grad=True)
+            out = fn(y, b)
+            gy, gb = torch.autograd.grad((out.square() * w).sum(), [y, b], create_graph=True)
+            ggy, ggb = torch.autograd.grad(gb.square().sum() + gy.sum(), [y, b])
+            res.append((out.detach(), gy.detach(), gb.detach(), ggy, ggb))
+    for got, want in zip(*res):
+        assert torch.allclose(got.double(), want.double(), rtol=1e-6, atol=1e-6)
