@@ -810,6 +810,9 @@ class Generator(nn.Module):
 # discriminator-style down blocks (the co-modulation encoder is built from these)
 # ------------------------------------------------------------------------------------------------
 
+JOIN_INPUT_GRADS = os.environ.get('SHG_JOIN_GRADS', '1') == '1'       # (A/B switch: grad_ops.InputGradJoin in the residual down blocks)
+
+
 class discrim_block(nn.Module):
     """[fromrgb] -> conv0 3x3 -> conv1 3x3 stride-2 with FIR pre-filter (stylegan.py:624-684)."""
 
@@ -835,6 +838,15 @@ class discrim_block(nn.Module):
             x = _add(x, y) if x is not None else y
         img = None
         if self.reslink:
+            if JOIN_INPUT_GRADS and grad_ops.wants_grad(x) and x.is_cuda:
+                # training rows: x feeds the skip branch and conv0; the skip branch (called last = first in backward) leaves its input
+                # gradient with the join and conv0's input-gradient kernel adds it in its store pass (grad_ops.InputGradJoin)
+                join = grad_ops.InputGradJoin()
+                with grad_ops.InputGradJoin.consumer(join):
+                    h = self.conv0(x)
+                h = self.conv1(h, gain=np.sqrt(0.5))
+                y = self.skip(grad_ops.stash_input_grad(x, join), gain=np.sqrt(0.5))
+                return _add(h, y), None
             y = self.skip(x, gain=np.sqrt(0.5))
             x = self.conv1(self.conv0(x), gain=np.sqrt(0.5))
             x = _add(x, y)

@@ -119,11 +119,21 @@ def _convt_fwd(x, weight, bias, padding, groups, out_hw=None):
     return y
 
 
-def _conv_input_grad(g, weight, x_shape, stride, padding):
+def _conv_input_grad(g, weight, x_shape, stride, padding, residual=None):
     """dL/dx of y = conv2d(x, weight, stride, padding) from g = dL/dy, through the public (differentiable) operators: a stride-1
     convolution with the flipped, channel-transposed weights, or the stride-2 transposed convolution cropped / zero-extended to
     the input extent (the output_padding rule of conv2d_gradfix.py:96-105)."""
     k = weight.shape[2]
+    if residual is not None:
+        # ``residual`` (grad_ops.InputGradJoin: the other consumer's input gradient, first-order passes only) is added in the store pass of
+        # the kernel where the geometry has one (3x3 stride 1), by a tensor op otherwise
+        if stride == 1 and k == 3 and g.is_cuda and not _wants_grad(g, weight, residual) and tuple(residual.shape) == tuple(x_shape):
+            if g.dtype == torch.float16:
+                pw = kernels_f16.pack_weight(weight.detach().to(torch.float16), transposed=True, flip=True)
+                return kernels_f16.conv2d(g, pw, None, 1, k - 1 - padding, residual=_dense(residual.to(torch.float16)))
+            pw = kernels.conv_weight_prep(weight.detach().transpose(0, 1).flip(2, 3).contiguous())
+            return kernels.conv2d(g, pw, mode=kernels.MODE_SAME, pad=k - 1 - padding, residual=residual.contiguous())
+        return _conv_input_grad(g, weight, x_shape, stride, padding) + residual
     if stride == 1:
         if g.dtype == torch.float16 and g.is_cuda and not _wants_grad(g, weight):
             # first-order pass of a half layer: the rotated, channel-transposed weight is built by the pack kernel itself (one gather
@@ -170,6 +180,10 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, padding, bias is not None)
+        ctx.join = grad_ops.InputGradJoin.pending             # (a residual block's first convolution: see grad_ops.InputGradJoin)
+        if ctx.join is not None:
+            grad_ops.InputGradJoin.pending = None
+            ctx.join.armed = bool(ctx.needs_input_grad[0])
         return _conv_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach(), stride, padding, 1)
 
     @staticmethod
@@ -178,8 +192,15 @@ class _Conv2dFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.geom
         g = _dense(g)
         gx = gw = gb = None
+        other = None
+        if ctx.join is not None:
+            if ctx.join.grad is not None and not torch.is_grad_enabled():
+                other, ctx.join.grad = ctx.join.grad, None
+            ctx.join.consumer_done = True
         if ctx.needs_input_grad[0]:
-            gx = _conv_input_grad(g, weight, x.shape, stride, padding)
+            gx = _conv_input_grad(g, weight, x.shape, stride, padding, residual=other)
+        elif other is not None:
+            raise RuntimeError('InputGradJoin: a gradient was stashed for a convolution whose input needs none')
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             gw = _WgradFn.apply(g, x, weight.shape[2], stride, padding)
         if has_bias and ctx.needs_input_grad[2]:

@@ -75,6 +75,49 @@ class _BiasActBwdFn(torch.autograd.Function):
         return _BiasActBwdFn.apply(gg, y, ctx.cfg), None, None
 
 
+class InputGradJoin:
+    """A tensor with two consumers -- a residual block's input feeds its skip branch and its first convolution -- gets the sum of their
+    input gradients; autograd forms it with an extra pass over the tensor (0.58 ms for the critic's [16, 64, 512, 512] input).  The
+    convolution kernels can add a tensor in their store pass instead: the branch that finishes FIRST in backward leaves its gradient here
+    (``stash``), the convolution registered as consumer (conv2d_gradfix._Conv2dFn, via ``pending``) adds it as the ``residual`` of its
+    input-gradient kernel.  Whatever the engine's order, the result is the same sum: a gradient that arrives after the consumer has run
+    takes autograd's ordinary path.  Under ``create_graph`` both sides stay on the ordinary path."""
+    pending = None                 # the join the next _Conv2dFn.forward adopts (set by ``consumer``, cleared when adopted)
+
+    def __init__(self):
+        self.grad, self.armed, self.consumer_done = None, False, False
+
+    class consumer:
+        def __init__(self, join):
+            self.join = join
+
+        def __enter__(self):
+            InputGradJoin.pending = self.join
+
+        def __exit__(self, *exc):
+            InputGradJoin.pending = None
+
+
+class _StashGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, join):
+        ctx.join = join
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        j = ctx.join
+        if torch.is_grad_enabled() or not j.armed or j.consumer_done or j.grad is not None:
+            return g, None
+        j.grad = g
+        return None, None
+
+
+def stash_input_grad(x, join):
+    """Identity whose gradient goes to ``join`` (see InputGradJoin) instead of autograd's accumulation, when a consumer is waiting."""
+    return _StashGradFn.apply(x, join) if wants_grad(x) else x
+
+
 def channel_sum(t):
     """Sum over every axis but the channel axis, accumulated in float32 (float64 inputs: float64; differentiable).  A reduction to C values runs on C workgroups:
     the RGB branch's [8, 3, 512, 512] bias gradient took 670 us as one reduction; rows first, then the rest, is two launches of ~6 us."""

@@ -373,3 +373,54 @@ def test_fused_style_factors_vs_float64_autograd(half, n, i, o):
     for name, x, y in zip(('sn', 'dcoefs', 'g_styles', 'g_wsq', 'second-order g_styles'), got, want):
         err = float((x.double() - y).abs().max() / (y.abs().max() + 1e-30))
         assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize('fp16', [False, True])
+def test_residual_block_input_gradients_joined_in_the_convolution_kernel(fp16):
+    """``grad_ops.InputGradJoin``: in the critic's residual blocks the skip branch's input gradient is added by conv0's input-gradient
+    kernel (its ``residual`` operand) instead of by autograd's accumulation pass.  Same gradients as the ordinary path (switch off) for
+    the parameters and for the image; the kernel path is really taken (every block joins once); the R1 pass (create_graph) is unchanged."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo import stylegan
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    torch.manual_seed(31)
+    D = stylegan.Discriminator(resolution=256, ic_n=4, ch_base=2048, ch_max=32, mbstd_group_size=4, mbstd_c_n=1,
+                               use_fp16_before_res=(32 if fp16 else None)).to(DEV).train()
+    img = real_batch(4, 32)
+    calls = []
+    orig = conv2d_gradfix._conv_input_grad
+
+    def spy(g, weight, x_shape, stride, padding, residual=None):
+        calls.append(residual is not None)
+        return orig(g, weight, x_shape, stride, padding, residual=residual)
+    res = {}
+    for on in (True, False):
+        stylegan.JOIN_INPUT_GRADS = on
+        calls.clear()
+        conv2d_gradfix._conv_input_grad = spy
+        try:
+            with torch.enable_grad():
+                x = img.clone().requires_grad_(True)
+                for p in D.parameters():
+                    p.grad = None
+                torch.nn.functional.softplus(D(x, None)).mean().backward()
+                first = ([p.grad.clone() for p in D.parameters()], x.grad.clone(), sum(calls))
+                x2 = img.clone().requires_grad_(True)
+                with conv2d_gradfix.no_weight_gradients():
+                    (r1,) = torch.autograd.grad(D(x2, None).sum(), [x2], create_graph=True)
+                for p in D.parameters():
+                    p.grad = None
+                r1.square().sum().backward()
+                second = [None if p.grad is None else p.grad.clone() for p in D.parameters()]
+        finally:
+            conv2d_gradfix._conv_input_grad = orig
+            stylegan.JOIN_INPUT_GRADS = True
+        res[on] = (first, second)
+    (ga, xa, na), sa = res[True]
+    (gb, xb, nb), sb = res[False]
+    assert na == 6 and nb == 0, (na, nb)                   # six residual blocks (256 .. 8), each joined once
+    tol = 2e-2 if fp16 else 1e-5
+    worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-20)) for a, b in zip(ga, gb))
+    assert worst < tol and float((xa - xb).abs().max() / xb.abs().max()) < tol, worst
+    for a, b in zip(sa, sb):
+        assert (a is None) == (b is None) and (a is None or float((a - b).abs().max() / (b.abs().max() + 1e-20)) < tol)
