@@ -25,7 +25,7 @@ import torch.nn as nn
 from .. import kernels
 from .common import utils
 from .common.get_model import get_model, register
-from .stylegan_utils import grad_ops, conv2d_resample, fma, misc, upfirdn2d  # noqa: F401
+from .stylegan_utils import grad_ops, conv2d_gradfix, conv2d_resample, fma, misc, upfirdn2d  # noqa: F401
 
 version = '0'
 symbol = 'stylegan'
@@ -467,6 +467,13 @@ class conv2d_layer(nn.Module):
     def _forward_train(self, x, gain=1):
         """Differentiable composition (training rows): convolution / FIR / bias + activation through their autograd forms."""
         ak = _act_kwargs(self.activation, gain)
+        if self.up == 1 and self.down == 1 and conv2d_gradfix.conv_bias_act_supported(x, self.weight, ak):
+            # 3x3 stride-1 layers: convolution + bias + activation as one node on one forward kernel
+            return conv2d_gradfix.conv2d_bias_act(x, (self.weight * self.weight_gain).to(x.dtype), self.bias, self.padding, **ak)
+        if self.up == 1 and self.down == 2 and self.padding == 1:
+            y = conv2d_resample.conv2d_down_bias_act(x, (self.weight * self.weight_gain).to(x.dtype), self.resample_filter, self.bias, ak)
+            if y is not None:
+                return y
         y = conv2d_resample.conv2d_resample(x=x, w=(self.weight * self.weight_gain).to(x.dtype), f=self.resample_filter, up=self.up,
                                             down=self.down, padding=self.padding, flip_weight=(self.up == 1))
         if ak is None or (y.dtype == torch.float16 and y.shape[1] % 8):

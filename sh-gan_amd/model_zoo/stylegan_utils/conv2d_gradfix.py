@@ -11,6 +11,8 @@ Supported geometry is what the generator / discriminator need: 3x3 / 1x1 kernels
 padding, groups = 1 under autograd (grouped forward only), and the stride-2 3x3 transposed form.  The backward passes are
 themselves written with these operators (and ``_WgradFn`` has the derivatives of ``Conv2dGradWeight.backward``,
 conv2d_gradfix.py:148-163), so gradients of gradients work: the R1 and path-length regularisers differentiate twice."""
+import os
+
 import torch
 
 from ... import kernels, kernels_f16
@@ -206,6 +208,67 @@ class _Conv2dFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = grad_ops.channel_sum(g).to(g.dtype)
         return gx, gw, gb, None, None
+
+
+class _ConvBiasActFn(torch.autograd.Function):
+    """y = lrelu_agc(conv2d(x, w, stride 1 | 2, padding) + b) (or ``(..) * gain`` without activation) as ONE node on ONE forward kernel: the
+    convolution kernels apply bias and activation in their store pass, as on the inference route.  The composed form (``_Conv2dFn``, then
+    ``grad_ops._BiasActFn``) wrote the convolution result and read it back for the activation -- a tensor nobody needs again: the backward
+    pass takes the activation's slope from the OUTPUT (``bias_act_grads``) and the convolution's gradients from x and w.  Backward is built
+    from the same differentiable pieces as the two nodes it replaces, so R1 differentiates it twice."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, cfg):
+        act, gain, alpha, act_gain, clamp = cfg
+        b = None if bias is None else bias.detach()
+        if x.dtype == torch.float16:
+            y = kernels_f16.conv2d(x.detach(), weight.detach().to(torch.float16), None if b is None else b.to(torch.float32), stride, padding, act=act,
+                                   gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        else:
+            pw = kernels.conv_weight_prep(weight.detach())
+            y = kernels.conv2d(x.detach().contiguous(), pw, mode=kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2, pad=padding, bias=b, act=act, gain=gain, alpha=alpha,
+                               act_gain=act_gain, clamp=clamp)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg, ctx.padding, ctx.stride = cfg, padding, stride
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.join = grad_ops.InputGradJoin.pending             # (a residual block's first convolution: see grad_ops.InputGradJoin)
+        if ctx.join is not None:
+            grad_ops.InputGradJoin.pending = None
+            ctx.join.armed = bool(ctx.needs_input_grad[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        need_b = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
+        gz, gb = grad_ops.bias_act_grads(_dense(gy), y, ctx.cfg, need_b, ctx.bias_dtype)
+        other = None
+        if ctx.join is not None:
+            if ctx.join.grad is not None and not torch.is_grad_enabled():
+                other, ctx.join.grad = ctx.join.grad, None
+            ctx.join.consumer_done = True
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_input_grad(gz, weight, x.shape, ctx.stride, ctx.padding, residual=other)
+        elif other is not None:
+            raise RuntimeError('InputGradJoin: a gradient was stashed for a convolution whose input needs none')
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            gw = _WgradFn.apply(gz, x, weight.shape[2], ctx.stride, ctx.padding)
+        return gx, gw, gb, None, None, None
+
+
+FUSED_CONV_ACT = os.environ.get('SHG_FUSED_CONV_ACT', '1') == '1'        # (A/B switch: 0 = convolution and bias / activation as two nodes)
+
+
+def conv_bias_act_supported(x, weight, act_kwargs):
+    return (FUSED_CONV_ACT and act_kwargs is not None and x.is_cuda and x.ndim == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and x.dtype in (torch.float16, torch.float32) and (x.dtype == torch.float32 or weight.shape[0] % 8 == 0)
+            and _wants_grad(x, weight))
+
+
+def conv2d_bias_act(x, weight, bias, padding, stride=1, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+    """lrelu_agc(conv2d(x, weight, stride, padding) + bias) for 3x3 layers (stride 1 | 2) under autograd (see _ConvBiasActFn)."""
+    return _ConvBiasActFn.apply(x, weight, bias, int(stride), int(padding), (bool(act), float(gain), float(alpha), float(act_gain), clamp))
 
 
 class _ConvTranspose2dFn(torch.autograd.Function):

@@ -3,7 +3,7 @@ padding arithmetic as lib/model_zoo/stylegan_utils/conv2d_resample.py:57-154."""
 import torch
 
 from ... import kernels
-from . import conv2d_gradfix, upfirdn2d
+from . import conv2d_gradfix, grad_ops, upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
@@ -81,20 +81,49 @@ class _UpConvFirFn(torch.autograd.Function):
         return gx, gw, None, None
 
 
+def conv2d_down_bias_act(x, w, f, bias, ak, flip_filter=False):
+    """The down path (pad-2 low-pass, stride-2 3x3 convolution: conv2d_resample.py:116-120) with bias + activation in the convolution's store
+    pass, under autograd; None when the geometry is not the model's (callers then compose ``conv2d_resample`` and ``bias_act``)."""
+    if not (conv2d_gradfix.conv_bias_act_supported(x, w, ak) and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+        return None
+    cfg = (bool(ak.get('act', False)), float(ak.get('gain', 1.0)), float(ak.get('alpha', 0.2)), float(ak.get('act_gain', kernels.SQRT2)),
+           ak.get('clamp', 256.0))
+    if FUSED_TRAIN_RESAMPLE and _fusable(x, w, f, 1):
+        return _FirDownConvFn.apply(x, w, f, flip_filter, bias, cfg)
+    xf = upfirdn2d.upfirdn2d(x=x, f=f, padding=[2, 2, 2, 2], flip_filter=flip_filter)
+    return conv2d_gradfix._ConvBiasActFn.apply(xf, w, bias, 2, 0, cfg)
+
+
 class _FirDownConvFn(torch.autograd.Function):
     """The down path (conv2d_resample.py:116-120: pad-2 low-pass, then the stride-2 convolution) for float32 training rows as one
     node.  Forward: the two kernels as before.  First-order backward: the input gradient is conv_transpose2d followed by the FIR's
     transpose -- exactly the phase-plane pair of the up path with gain 1 -- instead of planes -> interleaved image -> same-size FIR."""
     @staticmethod
-    def forward(ctx, x, w, f, flip_filter):
+    def forward(ctx, x, w, f, flip_filter, bias=None, act_cfg=None):
         xf = upfirdn2d.upfirdn2d(x.detach(), f, padding=[2, 2, 2, 2], flip_filter=flip_filter)
-        ctx.save_for_backward(xf, w, f)
         ctx.cfg = (tuple(x.shape), flip_filter)
-        return conv2d_gradfix.conv2d(xf, w.detach(), stride=2, padding=0)
+        ctx.act_cfg = act_cfg
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        if act_cfg is None:
+            ctx.save_for_backward(xf, w, f)
+            return conv2d_gradfix.conv2d(xf, w.detach(), stride=2, padding=0)
+        # bias + activation in the store pass of the strided convolution (``conv2d_down_bias_act``); the output is saved for their backward
+        act, gain, alpha, act_gain, clamp = act_cfg
+        pw = kernels.conv_weight_prep(w.detach())
+        y = kernels.conv2d(xf, pw, mode=kernels.MODE_DOWN2, pad=0, bias=None if bias is None else bias.detach(), act=act, gain=gain, alpha=alpha,
+                           act_gain=act_gain, clamp=clamp)
+        ctx.save_for_backward(xf, w, f, y)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        xf, w, f = ctx.saved_tensors
+        gb = None
+        if ctx.act_cfg is not None:
+            xf, w, f, y = ctx.saved_tensors
+            g, gb = grad_ops.bias_act_grads(g.contiguous(), y, ctx.act_cfg, ctx.bias_dtype is not None and ctx.needs_input_grad[4], ctx.bias_dtype)
+        else:
+            xf, w, f = ctx.saved_tensors
         x_shape, flip = ctx.cfg
         g = g.contiguous()
         gx = gw = None
@@ -108,7 +137,7 @@ class _FirDownConvFn(torch.autograd.Function):
                 gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip)
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             gw = conv2d_gradfix._WgradFn.apply(g, xf, 3, 2, 0)
-        return gx, gw, None, None
+        return gx, gw, None, None, gb, None
 
 
 FUSED_TRAIN_RESAMPLE = True      # (A/B switch for the two nodes above)

@@ -180,6 +180,23 @@ class _BiasActFn(torch.autograd.Function):
         return dx, db, None, None, None, None, None
 
 
+def bias_act_grads(g, y, cfg, need_bias, bias_dtype):
+    """(dL/dz, dL/dbias | None) of y = A(z + bias) from g = dL/dy and the saved OUTPUT y: what ``_BiasActFn.backward`` computes, for nodes
+    that fuse the activation into their producer (conv2d_gradfix._ConvBiasActFn).  First-order passes take dz and the per-(n, c) sums from
+    one kernel; under ``create_graph`` dz is the differentiable ``_BiasActBwdFn`` and the bias gradient a tensor reduction of it."""
+    act, gain, alpha, act_gain, clamp = cfg
+    if need_bias and not torch.is_grad_enabled() and modtail_supported(y):
+        if y.dtype == torch.float16:
+            dz, _, s0, _ = kernels_f16.modtail_backward(g.detach().to(torch.float16), y, None, None, want_sums=True, want_noise=False, act=act,
+                                                        gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        else:
+            dz, _, s0, _ = kernels.modtail_backward(g.detach().contiguous(), y, None, None, want_sums=True, want_noise=False, act=act, gain=gain,
+                                                    alpha=alpha, act_gain=act_gain, clamp=clamp)
+        return dz, s0.sum(0).to(bias_dtype)
+    dz = _BiasActBwdFn.apply(g, y, cfg)
+    return dz, (channel_sum(dz).to(bias_dtype) if need_bias else None)
+
+
 def bias_act(x, bias=None, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
     """y = lrelu_agc(x + bias[c]) (or (x + bias) * gain without activation), differentiable in x and bias.  x: [N,C,...]."""
     shape = x.shape

@@ -424,3 +424,54 @@ def test_residual_block_input_gradients_joined_in_the_convolution_kernel(fp16):
     assert worst < tol and float((xa - xb).abs().max() / xb.abs().max()) < tol, worst
     for a, b in zip(sa, sb):
         assert (a is None) == (b is None) and (a is None or float((a - b).abs().max() / (b.abs().max() + 1e-20)) < tol)
+
+
+@pytest.mark.parametrize('fp16', [False, True])
+def test_conv_bias_act_as_one_training_node_equals_the_two_nodes(fp16):
+    """3x3 stride-1 layers under autograd: ``_ConvBiasActFn`` (bias + lrelu_agc in the convolution's store pass, one node) against
+    convolution node + bias/activation node -- critic logits, parameter gradients, image gradient, and the R1 second-order gradients."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo import stylegan
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
+    torch.manual_seed(41)
+    D = stylegan.Discriminator(resolution=256, ic_n=4, ch_base=2048, ch_max=32, mbstd_group_size=4, mbstd_c_n=1,
+                               use_fp16_before_res=(32 if fp16 else None)).to(DEV).train()
+    with torch.no_grad():
+        for n_, p_ in D.named_parameters():
+            if n_.endswith('bias'):
+                p_.normal_(0, 0.2)
+    img = real_batch(4, 42)
+    res, taken = {}, {}
+    orig = conv2d_gradfix.conv2d_bias_act
+
+    def counted(*a, **k):
+        taken[True] = taken.get(True, 0) + 1
+        return orig(*a, **k)
+    for on in (True, False):
+        conv2d_gradfix.FUSED_CONV_ACT = on
+        conv2d_gradfix.conv2d_bias_act = counted if on else orig
+        try:
+            with torch.enable_grad():
+                x = img.clone().requires_grad_(True)
+                for p in D.parameters():
+                    p.grad = None
+                logits = D(x, None)
+                torch.nn.functional.softplus(logits).mean().backward()
+                first = [logits.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in D.parameters()]
+                x2 = img.clone().requires_grad_(True)
+                with conv2d_gradfix.no_weight_gradients():
+                    (r1,) = torch.autograd.grad(D(x2, None).sum(), [x2], create_graph=True)
+                for p in D.parameters():
+                    p.grad = None
+                r1.square().sum().backward()
+                second = [r1.detach().clone()] + [p.grad.clone() for p in D.parameters() if p.grad is not None]
+        finally:
+            conv2d_gradfix.FUSED_CONV_ACT = True
+            conv2d_gradfix.conv2d_bias_act = orig
+        res[on] = first + second
+    assert taken.get(True, 0) == 2 * 7                     # conv0 of the six residual blocks + the 4x4 tail's convolution, two critic passes
+    tol = 3e-2 if fp16 else 2e-5
+    assert len(res[True]) == len(res[False])
+    worst = max(float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-20)) for a, b in zip(res[True], res[False]))
+    print(f'fused conv+bias+act node vs two nodes ({"fp16 blocks" if fp16 else "float32"}): worst relative difference {worst:.2e}')
+    assert worst < tol
