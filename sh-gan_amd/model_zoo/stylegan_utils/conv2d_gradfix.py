@@ -224,6 +224,11 @@ class _ConvBiasActFn(torch.autograd.Function):
         if x.dtype == torch.float16:
             y = kernels_f16.conv2d(x.detach(), weight.detach().to(torch.float16), None if b is None else b.to(torch.float32), stride, padding, act=act,
                                    gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        elif (THIN_1X1 and weight.shape[2] == 1 and stride == 1 and padding == 0 and weight.shape[1] <= 8 and (x.shape[2] * x.shape[3]) % 4 == 0
+              and x.shape[0] <= 65535):
+            # fromrgb (4 -> 64): the HBM-bound pointwise kernel, bias + activation in the same pass
+            y = kernels.conv1x1_thin_in(x.detach().contiguous(), weight.detach().reshape(weight.shape[0], weight.shape[1]), b, act=act, gain=gain,
+                                        alpha=alpha, act_gain=act_gain, clamp=clamp)
         else:
             pw = kernels.conv_weight_prep(weight.detach())
             y = kernels.conv2d(x.detach().contiguous(), pw, mode=kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2, pad=padding, bias=b, act=act, gain=gain, alpha=alpha,
@@ -261,13 +266,13 @@ FUSED_CONV_ACT = os.environ.get('SHG_FUSED_CONV_ACT', '1') == '1'        # (A/B 
 
 
 def conv_bias_act_supported(x, weight, act_kwargs):
-    return (FUSED_CONV_ACT and act_kwargs is not None and x.is_cuda and x.ndim == 4 and tuple(weight.shape[2:]) == (3, 3)
+    return (FUSED_CONV_ACT and act_kwargs is not None and x.is_cuda and x.ndim == 4 and tuple(weight.shape[2:]) in ((3, 3), (1, 1))
             and x.dtype in (torch.float16, torch.float32) and (x.dtype == torch.float32 or weight.shape[0] % 8 == 0)
             and _wants_grad(x, weight))
 
 
 def conv2d_bias_act(x, weight, bias, padding, stride=1, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
-    """lrelu_agc(conv2d(x, weight, stride, padding) + bias) for 3x3 layers (stride 1 | 2) under autograd (see _ConvBiasActFn)."""
+    """lrelu_agc(conv2d(x, weight, stride, padding) + bias) for 3x3 (stride 1 | 2) and 1x1 (stride 1) layers under autograd (see _ConvBiasActFn)."""
     return _ConvBiasActFn.apply(x, weight, bias, int(stride), int(padding), (bool(act), float(gain), float(alpha), float(act_gain), clamp))
 
 

@@ -84,7 +84,7 @@ class _UpConvFirFn(torch.autograd.Function):
 def conv2d_down_bias_act(x, w, f, bias, ak, flip_filter=False):
     """The down path (pad-2 low-pass, stride-2 3x3 convolution: conv2d_resample.py:116-120) with bias + activation in the convolution's store
     pass, under autograd; None when the geometry is not the model's (callers then compose ``conv2d_resample`` and ``bias_act``)."""
-    if not (conv2d_gradfix.conv_bias_act_supported(x, w, ak) and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4)
+    if not (conv2d_gradfix.conv_bias_act_supported(x, w, ak) and tuple(w.shape[2:]) == (3, 3) and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4)
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
         return None
     cfg = (bool(ak.get('act', False)), float(ak.get('gain', 1.0)), float(ak.get('alpha', 0.2)), float(ak.get('act_gain', kernels.SQRT2)),
