@@ -469,7 +469,7 @@ def test_conv_bias_act_as_one_training_node_equals_the_two_nodes(fp16):
             conv2d_gradfix.FUSED_CONV_ACT = True
             conv2d_gradfix.conv2d_bias_act = orig
         res[on] = first + second
-    assert taken.get(True, 0) == 2 * 8                     # fromrgb, conv0 of the six residual blocks, the 4x4 tail's convolution; two critic passes
+    assert taken.get(True, 0) == 2 * 14                    # fromrgb, conv0 and skip of the six residual blocks, the 4x4 tail's convolution; two critic passes
     tol = 3e-2 if fp16 else 2e-5
     assert len(res[True]) == len(res[False])
     worst = max(float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-20)) for a, b in zip(res[True], res[False]))
