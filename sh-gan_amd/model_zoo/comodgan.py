@@ -13,6 +13,7 @@ from .stylegan import Generator as Generator_StyleGan
 from .stylegan import Mapping as Mapping_StyleGan
 from .stylegan import _add, dense, discrim_block, discrim_epilogue, synthesis_layer, torgb_layer
 from .stylegan import synthesis_block as stylegan_synthesis_block
+from . import stylegan as stylegan_mod
 from .stylegan_utils import grad_ops, upfirdn2d
 
 version = '0'
@@ -40,6 +41,13 @@ class encoder_block(discrim_block):
             x = _add(self.conv1(feat, gain=np.sqrt(0.5)), y)
         else:
             feat = self.conv0(x)
+            if stylegan_mod.JOIN_INPUT_GRADS and grad_ops.wants_grad(feat) and feat.is_cuda:
+                # training rows: the feature map feeds conv1 and, later, the synthesis network; the gradient that comes back from there
+                # first is added by conv1's input-gradient kernel in its store pass (grad_ops.InputGradJoin)
+                join = grad_ops.InputGradJoin(feat)
+                with grad_ops.InputGradJoin.consumer(join):
+                    x = self.conv1(feat)
+                return x, None, grad_ops.stash_input_grad(feat, join)
             x = self.conv1(feat)
         return x, None, feat
 

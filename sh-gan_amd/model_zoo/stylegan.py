@@ -853,7 +853,7 @@ class discrim_block(nn.Module):
             if JOIN_INPUT_GRADS and grad_ops.wants_grad(x) and x.is_cuda:
                 # training rows: x feeds the skip branch and conv0; the skip branch (called last = first in backward) leaves its input
                 # gradient with the join and conv0's input-gradient kernel adds it in its store pass (grad_ops.InputGradJoin)
-                join = grad_ops.InputGradJoin()
+                join = grad_ops.InputGradJoin(x)
                 with grad_ops.InputGradJoin.consumer(join):
                     h = self.conv0(x)
                 h = self.conv1(h, gain=np.sqrt(0.5))

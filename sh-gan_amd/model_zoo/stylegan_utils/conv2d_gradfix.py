@@ -182,10 +182,7 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, padding, bias is not None)
-        ctx.join = grad_ops.InputGradJoin.pending             # (a residual block's first convolution: see grad_ops.InputGradJoin)
-        if ctx.join is not None:
-            grad_ops.InputGradJoin.pending = None
-            ctx.join.armed = bool(ctx.needs_input_grad[0])
+        ctx.join = grad_ops.InputGradJoin.adopt(x, ctx.needs_input_grad[0])      # (a residual block's first convolution: see grad_ops.InputGradJoin)
         return _conv_fwd(x.detach(), weight.detach(), None if bias is None else bias.detach(), stride, padding, 1)
 
     @staticmethod
@@ -194,11 +191,7 @@ class _Conv2dFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.geom
         g = _dense(g)
         gx = gw = gb = None
-        other = None
-        if ctx.join is not None:
-            if ctx.join.grad is not None and not torch.is_grad_enabled():
-                other, ctx.join.grad = ctx.join.grad, None
-            ctx.join.consumer_done = True
+        other = ctx.join.take() if ctx.join is not None else None
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(g, weight, x.shape, stride, padding, residual=other)
         elif other is not None:
@@ -236,10 +229,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y)
         ctx.cfg, ctx.padding, ctx.stride = cfg, padding, stride
         ctx.bias_dtype = None if bias is None else bias.dtype
-        ctx.join = grad_ops.InputGradJoin.pending             # (a residual block's first convolution: see grad_ops.InputGradJoin)
-        if ctx.join is not None:
-            grad_ops.InputGradJoin.pending = None
-            ctx.join.armed = bool(ctx.needs_input_grad[0])
+        ctx.join = grad_ops.InputGradJoin.adopt(x, ctx.needs_input_grad[0])      # (a residual block's first convolution: see grad_ops.InputGradJoin)
         return y
 
     @staticmethod
@@ -247,11 +237,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         need_b = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
         gz, gb = grad_ops.bias_act_grads(_dense(gy), y, ctx.cfg, need_b, ctx.bias_dtype)
-        other = None
-        if ctx.join is not None:
-            if ctx.join.grad is not None and not torch.is_grad_enabled():
-                other, ctx.join.grad = ctx.join.grad, None
-            ctx.join.consumer_done = True
+        other = ctx.join.take() if ctx.join is not None else None
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _conv_input_grad(gz, weight, x.shape, ctx.stride, ctx.padding, residual=other)

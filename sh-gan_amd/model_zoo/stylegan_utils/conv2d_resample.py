@@ -104,6 +104,7 @@ class _FirDownConvFn(torch.autograd.Function):
         xf = upfirdn2d.upfirdn2d(x.detach(), f, padding=[2, 2, 2, 2], flip_filter=flip_filter)
         ctx.cfg = (tuple(x.shape), flip_filter)
         ctx.act_cfg = act_cfg
+        ctx.join = grad_ops.InputGradJoin.adopt(x, ctx.needs_input_grad[0])      # (an encoder block's feature map: its other consumer is the synthesis network)
         ctx.bias_dtype = None if bias is None else bias.dtype
         if act_cfg is None:
             ctx.save_for_backward(xf, w, f)
@@ -127,6 +128,7 @@ class _FirDownConvFn(torch.autograd.Function):
         x_shape, flip = ctx.cfg
         g = g.contiguous()
         gx = gw = None
+        other = ctx.join.take() if ctx.join is not None else None
         if ctx.needs_input_grad[0]:
             if torch.is_grad_enabled():          # create_graph: compose the differentiable operators
                 gm = conv2d_gradfix._conv_input_grad(g, w, xf.shape, 2, 0)
@@ -134,7 +136,7 @@ class _FirDownConvFn(torch.autograd.Function):
             else:
                 pw = kernels.conv_weight_prep(w.detach().transpose(0, 1).contiguous())
                 mid = kernels.conv2d(g, pw, mode=kernels.MODE_UP2T, planar=True)
-                gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip)
+                gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip, residual=None if other is None else other.contiguous())
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             gw = conv2d_gradfix._WgradFn.apply(g, xf, 3, 2, 0)
         return gx, gw, None, None, gb, None

@@ -79,13 +79,32 @@ class InputGradJoin:
     """A tensor with two consumers -- a residual block's input feeds its skip branch and its first convolution -- gets the sum of their
     input gradients; autograd forms it with an extra pass over the tensor (0.58 ms for the critic's [16, 64, 512, 512] input).  The
     convolution kernels can add a tensor in their store pass instead: the branch that finishes FIRST in backward leaves its gradient here
-    (``stash``), the convolution registered as consumer (conv2d_gradfix._Conv2dFn, via ``pending``) adds it as the ``residual`` of its
-    input-gradient kernel.  Whatever the engine's order, the result is the same sum: a gradient that arrives after the consumer has run
+    (``stash``), the node registered as consumer (conv2d_gradfix._Conv2dFn / _ConvBiasActFn, conv2d_resample._FirDownConvFn, via ``pending`` /
+    ``adopt``) adds it as the ``residual`` of its input-gradient kernel.  Whatever the engine's order, the result is the same sum: a gradient that arrives after the consumer has run
     takes autograd's ordinary path.  Under ``create_graph`` both sides stay on the ordinary path."""
     pending = None                 # the join the next _Conv2dFn.forward adopts (set by ``consumer``, cleared when adopted)
 
-    def __init__(self):
+    def __init__(self, x):
         self.grad, self.armed, self.consumer_done = None, False, False
+        self.key = (x.data_ptr(), tuple(x.shape), x.dtype)           # the consumer must be a node whose INPUT is this tensor
+
+    @classmethod
+    def adopt(cls, x, needs_input_grad):
+        """Called by a node's forward with its input: the pending join if it was opened for this very tensor, else None."""
+        j = cls.pending
+        if j is None or j.key != (x.data_ptr(), tuple(x.shape), x.dtype):
+            return None
+        cls.pending = None
+        j.armed = bool(needs_input_grad)
+        return j
+
+    def take(self):
+        """Called by the consumer's backward: the stashed gradient (first-order passes only) or None; later arrivals go autograd's way."""
+        g = None
+        if self.grad is not None and not torch.is_grad_enabled():
+            g, self.grad = self.grad, None
+        self.consumer_done = True
+        return g
 
     class consumer:
         def __init__(self, join):
@@ -107,7 +126,7 @@ class _StashGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         j = ctx.join
-        if torch.is_grad_enabled() or not j.armed or j.consumer_done or j.grad is not None:
+        if torch.is_grad_enabled() or not j.armed or j.consumer_done or j.grad is not None or tuple(g.shape) != j.key[1]:
             return g, None
         j.grad = g
         return None, None

@@ -475,3 +475,46 @@ def test_conv_bias_act_as_one_training_node_equals_the_two_nodes(fp16):
     worst = max(float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-20)) for a, b in zip(res[True], res[False]))
     print(f'fused conv+bias+act node vs two nodes ({"fp16 blocks" if fp16 else "float32"}): worst relative difference {worst:.2e}')
     assert worst < tol
+
+
+def test_encoder_feature_gradients_joined_in_the_down_layer():
+    """The co-modulation encoder's feature maps feed the block's stride-2 layer and the synthesis network: the gradient arriving from the
+    synthesis side is added by the down layer's input-gradient kernel (``upfir_planar`` residual operand) -- same generator gradients as
+    with the switch off, and the kernel path is taken once per float32 encoder block."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels
+    from shgan_amd.model_zoo import stylegan
+    G, _ = small_networks(51)
+    real4 = real_batch(2, 52)
+    x = torch.cat([real4[:, 0:1], real4[:, 1:4] * (real4[:, 0:1] + 0.5)], dim=1)
+    z, c = torch.randn(2, 64, device=DEV), torch.zeros(2, 0, device=DEV)
+    w = torch.randn(2, 3, 256, 256, device=DEV)
+    used = []
+    orig = kernels.upfir_planar
+
+    def spy(*a, **k):
+        used.append(k.get('residual') is not None)
+        return orig(*a, **k)
+    res = {}
+    for on in (True, False):
+        stylegan.JOIN_INPUT_GRADS = on
+        used.clear()
+        kernels.upfir_planar = spy
+        try:
+            G.requires_grad_(True)
+            for p in G.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                img = G(x=x, z=z, c=c, noise_mode='const')
+                (img * w).sum().backward()
+            res[on] = ([None if p.grad is None else p.grad.clone() for p in G.parameters()], sum(used))
+        finally:
+            kernels.upfir_planar = orig
+            stylegan.JOIN_INPUT_GRADS = True
+            G.requires_grad_(False)
+    (ga, na), (gb, nb) = res[True], res[False]
+    assert na == 6 and nb == 0, (na, nb)                 # encoder blocks 256 .. 8
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
