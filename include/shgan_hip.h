@@ -291,7 +291,8 @@ int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, int C, int 
                       int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
 /* y = lrelu_agc(x + bias[c]) (act = 0: (x + bias) * gain) over `pixels` x C halves, and dL/dx from dL/dy and the saved OUTPUT y. */
 /* Block-boundary casts `x.to(dtype)` (stylegan.py:486-495,659-663; comodgan.py:39-43,305-312) between the two activation layouts of this
- * library: float32 [N,C,H*W] (NCHW) -> float16 [N,H*W,C] (NHWC, torch.channels_last) when to_half, the reverse otherwise.  C % 8 == 0. */
+ * library: float32 [N,C,H*W] (NCHW) -> float16 [N,H*W,C] (NHWC, torch.channels_last) when to_half, the reverse otherwise.  C % 8 == 0, or C <= 16
+ * (thin tensors: the 4-channel network inputs). */
 int shg_relayout_f32_f16(const void* src, void* dst, int N, int C, long HW, int to_half, void* stream);
 int shg_bias_act_f16(const void* x, const float* bias, void* y, long pixels, int C, int act, float alpha, float gain, float clamp, void* stream);
 int shg_bias_act_backward_f16(const void* g, const void* y, void* dx, long total, int act, float alpha, float gain, float clamp, void* stream);

@@ -1147,6 +1147,23 @@ __global__ __launch_bounds__(256) void relayout_to_float_kernel(const _Float16* 
         if (c0 + c < C && p0 + pl < HW) yn[(long)(c0 + c) * HW + p0 + pl] = t[c][pl];
 }
 
+// thin tensors (the 4-channel network inputs, RGB): a lane owns a pixel, C <= 16 planes on the float32 side, 2 C contiguous bytes on the other
+template <bool TO_HALF>
+__global__ __launch_bounds__(256) void relayout_thin_kernel(const void* src, void* dst, int C, long HW, long total) {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+        const long n = p / HW, q = p - n * HW;
+        if (TO_HALF) {
+            const float* x = (const float*)src + n * C * HW + q;
+            _Float16* y = (_Float16*)dst + p * C;
+            for (int c = 0; c < C; ++c) y[c] = (_Float16)x[(long)c * HW];
+        } else {
+            const _Float16* x = (const _Float16*)src + p * C;
+            float* y = (float*)dst + n * C * HW + q;
+            for (int c = 0; c < C; ++c) y[(long)c * HW] = (float)x[c];
+        }
+    }
+}
+
 }  // namespace f16
 
 // x [N,H,W,I] halves, bias fp32 [O] or null, y halves.  w: k*k tap slots (cross-correlation taps in row-major (ky,kx) order) packed in MFMA operand
@@ -1385,7 +1402,16 @@ extern "C" int shg_upfirdn2d_f16(const void* x, const float* f, void* y, int N, 
 
 // src float32 [N,C,HW] (NCHW) -> dst float16 [N,HW,C] (NHWC) when to_half, the reverse otherwise; C % 8 == 0.
 extern "C" int shg_relayout_f32_f16(const void* src, void* dst, int N, int C, long HW, int to_half, void* stream) {
-    SHG_CHECK_ARG(src && dst && N >= 1 && C >= 8 && C % 8 == 0 && HW >= 1 && HW <= 0x7fffffffL && N <= 65535, "relayout: C % 8 == 0");
+    SHG_CHECK_ARG(src && dst && N >= 1 && C >= 1 && (C % 8 == 0 || C <= 16) && HW >= 1 && HW <= 0x7fffffffL && N <= 65535, "relayout: C % 8 == 0 or C <= 16");
+    if (C % 8) {
+        const long total = (long)N * HW;
+        long grid = (total + 255) / 256;
+        if (grid > 65536) grid = 65536;
+        if (to_half) hipLaunchKernelGGL(f16::relayout_thin_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, total);
+        else hipLaunchKernelGGL(f16::relayout_thin_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, total);
+        SHG_CHECK_LAUNCH();
+        return SHG_OK;
+    }
     SHG_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "relayout: 16-byte aligned tensors");
     const dim3 grid((unsigned)((HW + 63) / 64), (C + 63) / 64, N);
     if (to_half) hipLaunchKernelGGL(f16::relayout_to_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (_Float16*)dst, C, (int)HW);

@@ -228,7 +228,7 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
 
 
 def relayout_supported(x):
-    return (isinstance(x, torch.Tensor) and x.is_cuda and x.ndim == 4 and x.shape[1] % 8 == 0 and x.shape[0] <= 65535 and x.numel() > 0
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.ndim == 4 and (x.shape[1] % 8 == 0 or x.shape[1] <= 16) and x.shape[0] <= 65535 and x.numel() > 0
             and ((x.dtype == torch.float32 and x.is_contiguous()) or (x.dtype == torch.float16 and x.is_contiguous(memory_format=CL))))
 
 

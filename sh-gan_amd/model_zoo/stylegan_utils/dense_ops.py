@@ -61,7 +61,7 @@ class _TN(torch.autograd.Function):
         ctx.cfg = (s, cs)
         out, col = kernels.matmul_tn(_c(a.detach()), _c(b.detach()), s, cs)
         if col is None:
-            col = out.new_zeros(())          # placeholder output (never differentiated)
+            col = out.new_empty(())          # placeholder output (never read, never differentiated: no fill kernel for it)
             ctx.mark_non_differentiable(col)
         return out, col
 

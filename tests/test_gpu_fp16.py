@@ -403,7 +403,7 @@ def test_fp16_blocks_full_width_512_batch16_properties():
     assert np.array_equal(np.where(m, u8.cpu().numpy(), 0), np.where(m, real_u8, 0))
 
 
-@pytest.mark.parametrize('shape', [(8, 512, 64, 64), (3, 64, 33, 17), (2, 72, 8, 8), (1, 8, 1, 1), (4, 128, 256, 256)])
+@pytest.mark.parametrize('shape', [(8, 512, 64, 64), (3, 64, 33, 17), (2, 72, 8, 8), (1, 8, 1, 1), (4, 128, 256, 256), (8, 4, 512, 512), (3, 3, 17, 9), (2, 1, 5, 5)])
 def test_block_boundary_cast_kernel_is_the_torch_cast(shape):
     """`x.to(dtype)` at the block boundaries (stylegan.py:486-495,659-663) as the transposing relayout kernel: bit-identical to torch's
     `.to(dtype, memory_format)` in both directions (round-to-nearest-even, overflow to inf), the result in the layout of its dtype, and
