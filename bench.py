@@ -137,6 +137,9 @@ def parse():
     ap.add_argument('--pipeline-depth', type=int, default=None,
                     help='HIP streams the consecutive (independent) batches are issued on round-robin; 1 = one stream')
     ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
+    ap.add_argument('--digest-out', default=None,
+                    help='write {sample id: sha256 of its uint8 output} of this rank\'s last timed step to <path>.rank<r>.json '
+                         '(tests/test_gpu_bench_ranks.py compares the ranks of an N = 2 run with the single-process run id by id)')
     return ap.parse_args()
 
 
@@ -299,6 +302,8 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             'ms_per_step': round(ms_main, 2), 'images_per_s': round(world * b / ms_main * 1e3, 2), 'steps': a.train_steps, 'n_gpus': world,
             'ms_iteration_with_both_lazy_regularisers': round(ms_all, 2),
             'lazy_regularisers': 'Greg (path length, batch/2) every 4th, Dreg (R1) every 16th iteration (stylegan_default.py:304-321)',
+            'objective': 'stylegan_default_loss.py:53-128 on the raw generator output (InpaintingLoss composite_fake=False, the mode the '
+                         'reference-autograd fixtures pin); Dmain judges fake + real as one stacked critic pass (same logits and gradients)',
             'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
             'grad_all_reduce': (backend if world > 1 else None), 'hip_graph': graph_info, 'kernel_classes_one_step_rank0': cls,
             'conv_kernel_ms': round(sum(v['ms_per_step'] for k, v in cls.items() if k.startswith('conv')), 2) if cls else None}
@@ -381,7 +386,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
     if a.graph != 'off':
         try:
             gpipe = eval_harness.GraphPipeline(dev, lambda x_, z_: eval_harness.run_generator(G, x_, z_, noise_mode=a.noise_mode), (x, z),
-                                               depth=a.pipeline_depth)
+                                               depth=a.pipeline_depth, watch=list(G.parameters()) + list(G.buffers()))
             loop(gpipe, max(a.pipeline_depth, 2), True)
             torch.cuda.synchronize()
         except Exception as e:
@@ -425,6 +430,11 @@ def worker(local_rank, a, spawned_world=None, port=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         ranks_counted = int(t.item())
     assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
+    if a.digest_out:
+        import hashlib
+        o8 = out.cpu().numpy()
+        with open(f'{a.digest_out}.rank{rank}.json', 'w') as fh:
+            json.dump({str(i): hashlib.sha256(o8[k].tobytes()).hexdigest() for k, i in enumerate(ids)}, fh)
     # one batch alone on one stream (latency of a step; not the headline)
     lat_ms = None
     if rank == 0:

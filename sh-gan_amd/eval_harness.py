@@ -139,29 +139,52 @@ class GraphPipeline:
         for x, z in batches: out = pipe.run(x, z); ...
         pipe.join()"""
 
-    def __init__(self, device, fn, example_args, depth=None, warmup=2):
+    def __init__(self, device, fn, example_args, depth=None, warmup=2, watch=None):
+        """``watch``: the parameters / buffers ``fn`` reads (e.g. ``list(G.parameters())``).  A captured graph bakes in the ADDRESSES of
+        the per-parameter caches of the modules (prepared weight layouts, packed fp16 weights, the host-read noise strength): when a
+        parameter changes -- optimiser step, EMA update, ``load_state_dict`` (version counters) or a replayed training graph
+        (``_ParamCache.invalidate_all()``: the epoch) -- the next eager call rebuilds those caches and frees the tensors the graph still
+        points at.  With ``watch`` the pipeline compares that signature before every replay and re-captures all slots when it moved;
+        without it the parameters must stay frozen for the pipeline's lifetime."""
         depth = PIPELINE_DEPTH if depth is None else max(1, depth)
         self.device = torch.device(device)
-        cur = torch.cuda.current_stream(self.device)
+        self.fn, self.warmup = fn, max(1, warmup)
+        self.watch = None if watch is None else list(watch)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
-        self.graphs, self.ins, self.outs = [], [], []
+        self.ins = [[a.clone() if torch.is_tensor(a) else a for a in example_args] for _ in self.streams]
         self.k = 0
-        for s in self.streams:
+        self.captures = 0
+        self._capture()
+
+    def _signature(self):
+        if self.watch is None:
+            return None
+        from .model_zoo.stylegan import _ParamCache
+        return (_ParamCache.epoch,) + tuple((t.data_ptr(), t._version) for t in self.watch)
+
+    def _capture(self):
+        cur = torch.cuda.current_stream(self.device)
+        self.graphs, self.outs = [], []            # (drops the previous graphs and their private pools)
+        for s, ins in zip(self.streams, self.ins):
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                ins = [a.clone() if torch.is_tensor(a) else a for a in example_args]
-                for _ in range(warmup):
-                    fn(*ins)
+                for _ in range(self.warmup):       # eager: rebuilds the per-parameter caches from the live parameters
+                    self.fn(*ins)
             s.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                out = fn(*ins)
+                out = self.fn(*ins)
             self.graphs.append(g)
-            self.ins.append(ins)
             self.outs.append(out)
         cur.wait_stream(self.streams[-1])
+        self.sig = self._signature()
+        self.captures += 1
 
     def run(self, *args):
+        if self.watch is not None and self._signature() != self.sig:
+            self.join()
+            torch.cuda.current_stream(self.device).synchronize()
+            self._capture()
         i = self.k % len(self.streams)
         self.k += 1
         s = self.streams[i]

@@ -138,6 +138,11 @@ class _FirDownConvFn(torch.autograd.Function):
                 mid = kernels.conv2d(g, pw, mode=kernels.MODE_UP2T, planar=True)
                 gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip, residual=None if other is None else other.contiguous())
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            if torch.is_grad_enabled() and ctx.needs_input_grad[0]:
+                # the saved ``xf`` is detached from x: d(gw)/dx would be dropped silently (the reference's Conv2dGradWeight is differentiable in
+                # the input, conv2d_gradfix.py:140-146).  The shipped regularisers differentiate twice under no_weight_gradients and never come here.
+                raise NotImplementedError('second-order use of the fused FIR + stride-2 node with weight gradients enabled: set '
+                                          'conv2d_resample.FUSED_TRAIN_RESAMPLE = False (composed, fully differentiable route)')
             gw = conv2d_gradfix._WgradFn.apply(g, xf, 3, 2, 0)
         return gx, gw, None, None, gb, None
 

@@ -7,6 +7,8 @@ never comes here: the modules switch to these only when gradients are requested 
   upfirdn2d.py:174-192); convolutions in ``conv2d_gradfix.py``.
 Every backward is written with differentiable operators again, so second derivatives (the R1 / path-length regularisers,
 stylegan_default_loss.py:76-91, 118-124) work."""
+import threading
+
 import torch
 
 from ... import kernels, kernels_f16
@@ -75,34 +77,42 @@ class _BiasActBwdFn(torch.autograd.Function):
         return _BiasActBwdFn.apply(gg, y, ctx.cfg), None, None
 
 
+def _backward_pass_id():
+    f = getattr(torch._C, '_current_graph_task_id', None)
+    return f() if f is not None else 0
+
+
 class InputGradJoin:
     """A tensor with two consumers -- a residual block's input feeds its skip branch and its first convolution -- gets the sum of their
     input gradients; autograd forms it with an extra pass over the tensor (0.58 ms for the critic's [16, 64, 512, 512] input).  The
     convolution kernels can add a tensor in their store pass instead: the branch that finishes FIRST in backward leaves its gradient here
     (``stash``), the node registered as consumer (conv2d_gradfix._Conv2dFn / _ConvBiasActFn, conv2d_resample._FirDownConvFn, via ``pending`` /
     ``adopt``) adds it as the ``residual`` of its input-gradient kernel.  Whatever the engine's order, the result is the same sum: a gradient that arrives after the consumer has run
-    takes autograd's ordinary path.  Under ``create_graph`` both sides stay on the ordinary path."""
-    pending = None                 # the join the next _Conv2dFn.forward adopts (set by ``consumer``, cleared when adopted)
+    takes autograd's ordinary path.  Under ``create_graph`` both sides stay on the ordinary path.  A stash is tagged with the id of the
+    backward pass that left it (``torch._C._current_graph_task_id``): a gradient left behind by a pass that died before its consumer ran is
+    never added to a later pass.  ``pending`` is per thread (threaded data-parallel forwards do not see each other's joins)."""
+    _tls = threading.local()       # .pending: the join the next _Conv2dFn.forward adopts (set by ``consumer``, cleared when adopted)
 
     def __init__(self, x):
-        self.grad, self.armed, self.consumer_done = None, False, False
+        self.grad, self.armed, self.consumer_done, self.task = None, False, False, None
         self.key = (x.data_ptr(), tuple(x.shape), x.dtype)           # the consumer must be a node whose INPUT is this tensor
 
     @classmethod
     def adopt(cls, x, needs_input_grad):
         """Called by a node's forward with its input: the pending join if it was opened for this very tensor, else None."""
-        j = cls.pending
+        j = getattr(cls._tls, 'pending', None)
         if j is None or j.key != (x.data_ptr(), tuple(x.shape), x.dtype):
             return None
-        cls.pending = None
+        cls._tls.pending = None
         j.armed = bool(needs_input_grad)
         return j
 
     def take(self):
         """Called by the consumer's backward: the stashed gradient (first-order passes only) or None; later arrivals go autograd's way."""
         g = None
-        if self.grad is not None and not torch.is_grad_enabled():
-            g, self.grad = self.grad, None
+        if self.grad is not None and not torch.is_grad_enabled() and self.task == _backward_pass_id():
+            g = self.grad
+        self.grad = None                                            # (a stash of another pass is dropped, not added)
         self.consumer_done = True
         return g
 
@@ -111,10 +121,10 @@ class InputGradJoin:
             self.join = join
 
         def __enter__(self):
-            InputGradJoin.pending = self.join
+            InputGradJoin._tls.pending = self.join
 
         def __exit__(self, *exc):
-            InputGradJoin.pending = None
+            InputGradJoin._tls.pending = None
 
 
 class _StashGradFn(torch.autograd.Function):
@@ -126,9 +136,11 @@ class _StashGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         j = ctx.join
-        if torch.is_grad_enabled() or not j.armed or j.consumer_done or j.grad is not None or tuple(g.shape) != j.key[1]:
+        if torch.is_grad_enabled() or not j.armed or j.consumer_done or tuple(g.shape) != j.key[1]:
             return g, None
-        j.grad = g
+        if j.grad is not None and j.task == _backward_pass_id():   # a second stash in the same pass: autograd's way
+            return g, None
+        j.grad, j.task = g, _backward_pass_id()
         return None, None
 
 

@@ -163,7 +163,12 @@ class PhaseGraphs:
         self.graphs = {}
         self.seen = {ph.name: 0 for ph in phases}
         self.warmup = warmup
+        if warmup < 1:
+            raise ValueError('PhaseGraphs: warmup >= 1 (lazily built constants, Adam state and allocator pools must exist before the capture)')
         for ph in phases:
+            if ph.sync is not None and ph.sync.reduce:
+                raise ValueError('PhaseGraphs is single-process: a captured RCCL all-reduce (async handles, untouched()) is not supported; '
+                                 'with more than one rank use run_phases')
             for g in ph.opt.param_groups:
                 if not g.get('capturable', False):
                     raise ValueError('PhaseGraphs: build the optimisers with capturable=True (the step counter must live on the device)')

@@ -1,0 +1,55 @@
+"""The multi-rank path of ``bench.py`` on ONE device (the driver's GPU test box has a single MI355X): ``--gpus 2`` spawns two ranks that
+share the GPU (``ranks_share_devices``; the process group falls back to gloo because RCCL needs a device per rank), so the spawn, the
+all-reduced rank count, the per-rank step times, the all-reduced HIP-graph decision and the rank-strided sample ids
+(lib/data_factory/common/ds_sampler.py:58-68, main.py:86-89, lib/utils.py:304-309) all execute here.  The two ``nccl`` tests of
+tests/test_gpu_multi.py keep activating themselves wherever two GPUs exist."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+COMMON = ['--steps', '2', '--warmup', '1', '--no-train-step', '--no-second-config', '--no-cpu-baseline', '--profile-steps', '0',
+          '--resolution', '256', '--batch', '4', '--noise-mode', 'const']
+
+
+def _bench(tmp_path, tag, gpus):
+    dig = str(tmp_path / tag)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--digest-out', dig] + COMMON, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    digests = {}
+    for r in range(gpus):
+        with open(f'{dig}.rank{r}.json') as fh:
+            digests[r] = json.load(fh)
+    return line, digests
+
+
+def test_bench_two_ranks_share_one_device(tmp_path):
+    line2, dig2 = _bench(tmp_path, 'two', 2)
+    cfg = line2['config']
+    assert line2['n_gpus'] == 2 and cfg['global_batch'] == 8 and cfg['launcher'] == 'self-spawn'
+    assert cfg['ranks_all_reduced'] == 2 and cfg['ranks_share_devices'] and cfg['collective_backend'] == 'gloo'
+    assert len(cfg['ms_per_step_by_rank']['all']) == 2 and all(v > 0 for v in cfg['ms_per_step_by_rank']['all'])
+    # the graph-versus-eager decision was taken, and taken together (all-reduce MIN over the ranks)
+    g = cfg['hip_graph']
+    assert g['mode'] == 'auto' and 'captured_on_all_ranks' in g and isinstance(g['used'], bool)
+    if g['captured_on_all_ranks']:
+        assert set(g['trial_ms_per_step']) == {'eager', 'graph'}
+    # rank r holds the ids r, r + 2, r + 4, ... (ds_sampler.py:67): disjoint, together 0..7
+    assert sorted(int(i) for i in dig2[0]) == [0, 2, 4, 6] and sorted(int(i) for i in dig2[1]) == [1, 3, 5, 7]
+    # the same sample gives the same uint8 image whichever rank / batch position / launcher processed it, bit for bit
+    line1, dig1 = _bench(tmp_path, 'one', 1)
+    assert line1['n_gpus'] == 1 and line1['config']['ranks_all_reduced'] == 1 and not line1['config']['ranks_share_devices']
+    assert sorted(int(i) for i in dig1[0]) == [0, 1, 2, 3]
+    for i in ('0', '2'):
+        assert dig2[0][i] == dig1[0][i], f'sample {i}: rank 0 of the two-rank run differs from the single-process run'
+    for i in ('1', '3'):
+        assert dig2[1][i] == dig1[0][i], f'sample {i}: rank 1 of the two-rank run differs from the single-process run'

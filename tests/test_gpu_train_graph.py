@@ -269,6 +269,38 @@ def test_graph_pipeline_replays_the_evaluation_step_bit_exactly():
     assert not torch.equal(got[0], got[1])
 
 
+def test_graph_pipeline_recaptures_when_the_parameters_move():
+    """A captured slot holds the ADDRESSES of the per-parameter caches (prepared weight layouts, the host-read noise strength).  With
+    ``watch`` the pipeline notices an in-place parameter update (version counters: optimiser step, EMA, ``load_state_dict``) and a
+    replayed training graph (``_ParamCache.invalidate_all()``) and re-captures; the replay then equals the eager step on the NEW weights.
+    Carried by ``test_graph_pipeline_replays_the_evaluation_step_bit_exactly`` (eager == replay) and, through ``run_generator``, by the
+    reference-pinned generator goldens of tests/test_gpu_generator.py."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import configs, eval_harness as hz
+    from shgan_amd.model_zoo.stylegan import _ParamCache
+    G = configs.seeded_init_(configs.build_generator(256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128), seed=2,
+                             noise_strength=0.1).to(DEV).eval().requires_grad_(False)
+    x, z = hz.synthetic_batch(2, 256, 64, seed=7, device=DEV, masks='bernoulli')[:2]
+
+    def step(x_, z_):
+        return hz.run_generator(G, x_, z_, noise_mode='const')
+    pipe = hz.GraphPipeline(DEV, step, (x, z), depth=2, watch=list(G.parameters()) + list(G.buffers()))
+    before = pipe.run(x, z).clone()
+    pipe.join()
+    assert pipe.captures == 1 and torch.equal(before, step(x, z))
+    for p in G.parameters():                       # what an EMA update / optimiser step does: in place, new version counters
+        p.mul_(1.25)
+    for _ in range(3):
+        after = pipe.run(x, z).clone()
+        pipe.join()
+    assert pipe.captures == 2                      # one re-capture, then plain replays
+    assert torch.equal(after, step(x, z)) and not torch.equal(after, before)
+    _ParamCache.invalidate_all()                   # what train_stage.PhaseGraphs does around its replays
+    again = pipe.run(x, z).clone()
+    pipe.join()
+    assert pipe.captures == 3 and torch.equal(again, after)
+
+
 @pytest.mark.parametrize('o,i,k,half', [(64, 32, 3, False), (512, 512, 3, True), (70, 13, 3, True), (128, 64, 1, False)])
 def test_fused_demodulation_weight_kernel_vs_tensor_ops(o, i, k, half):
     """``_weight_factors`` under autograd: the one-kernel form (csrc/dense.hip demod_weight / demod_weight_backward) against the tensor-op
