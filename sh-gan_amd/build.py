@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libshgan_hip.so'
 VARDIR = os.path.join(os.path.dirname(HERE), 'tools', '_variants')      # study builds (-DSHG_ABLATE, A/B knobs) live with the tools, never beside the product library
-SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_f16.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
+SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_f16.hip', 'conv_f16_ring.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-inline-asm']
 
 

@@ -23,6 +23,7 @@
 //   bias_act_f16 (+bwd)  x + bias[c] -> lrelu_agc, and its gradient from the saved output (common/utils.py:135-143).
 #include <type_traits>
 #include "shg_common.h"
+#include "conv_f16_p.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -56,28 +57,6 @@ constexpr int TH = 8, TW = 16;       // output-pixel tile of a workgroup (4 wave
 constexpr int KC = 32;               // channels per LDS chunk (two MFMA k-steps)
 constexpr int PSTR = 40;             // halves per staged pixel: 32 + 8 padding -> 80-byte stride, conflict-free ds_read_b128
 
-struct ConvP {
-    const _Float16* x;
-    const _Float16* w;               // MFMA operand order [OB][wslots][I/16][64 lanes][8]: element = W[slot][ob*32 + (lane & 31)][c16*16 + (lane >> 5)*8 + e]
-    int OB, wslots;                  // 32-channel output blocks (O rounded up), tap slots of the weight tensor
-    const float* bias;               // optional [O]
-    _Float16* y;
-    int N, I, O, H, W;               // input tensor
-    int OHt, OWt;                    // output tensor extent
-    int GH, GW;                      // extent of the computed pixel grid (oy', ox')
-    int tiles_x, tiles_y;
-    int s_in, s_out, oy0, ox0;
-    int ntaps;
-    int tdy[9], tdx[9], tw[9];       // input offset of tap t (already minus the patch origin) and its weight slot
-    int org_y, org_x;                // patch origin: input row of patch row 0 for grid row 0 = org_y
-    int PH, PW;                      // patch extent
-    int wlds_off;                    // halves: start of the staged weight slab behind the patch / output tile (WLDS kernels)
-    // fused layer tail of the inference route (all optional): x * in_scale[n,i] while the patch is staged; then
-    // y = A(conv * out_scale[n,o] + noise * noise_strength + bias[o]) + residual in the store pass
-    const float* in_scale; const float* out_scale; const float* noise; const _Float16* residual;
-    int noise_mode, act, tail;       // noise: 0 none, 1 [OH,OW], 2 [N,OH,OW]; tail: any of the epilogue operands present
-    float noise_strength, alpha, gain, clamp;
-};
 
 template <int MB, int NT, int NB, bool WLDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB == 2 && NB == 2 && !WLDS) ? 3 : 1))) void conv_f16_kernel(const ConvP p) {
@@ -1084,6 +1063,8 @@ static int conv_taps(ConvP p, int ntaps, const int* dy, const int* dx, const int
     p.ntaps = ntaps;
     for (int t = 0; t < ntaps; ++t) { p.tdy[t] = dy[t] - mny; p.tdx[t] = dx[t] - mnx; p.tw[t] = slot[t]; }
     p.org_y = mny; p.org_x = mnx;
+    p.GH = GH; p.GW = GW;
+    if (conv_ring_eligible(p, mxy - mny + 1, mxx - mnx + 1)) return conv_ring_launch(p, mxy - mny + 1, mxx - mnx + 1, st);
     // wide grids of stride-1 reads: 8 x 32 pixel tiles, two pixel blocks per wave (each weight operand feeds two MFMAs); stride-2 reads
     // (a 4x larger patch) and narrow grids keep 8 x 16
     const int nb = (p.s_in == 1 && GW > TW) ? 2 : 1;

@@ -1,0 +1,296 @@
+// fp16 gather convolution, persistent LDS-DMA form ("ring" kernel) -- the stride-1-read launches of conv_f16.hip's conv_taps (3x3 stride-1
+// layers forward and as input gradients; reference: the cuDNN half convolutions behind stylegan.py:136-138,172-181, comodgan.py:40-47,305-309,
+// conv2d_gradfix.py:118-139).  gfx950 only.  Same arithmetic as conv_f16_kernel in the same order (chunk -> tap -> k-step on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation, one rounding): bit-identical results.
+//
+// What is different from conv_f16_kernel (profiles/r05_f16_pmc_base_summary.txt: matrix pipe busy 0.41, half the wave cycles in issue stalls,
+// 8 192 workgroups of 2 chunks each at 64 channels with a 4 000-cycle entry and an 8 000-cycle LDS-transposing epilogue per workgroup):
+//   * one PERSISTENT 512-thread workgroup per CU walks a list of tiles (16 x 32 output pixels x 64 output channels); a step = one 32-channel
+//     chunk of one tile; the operands of step s+1 -- the 18 x 34-pixel input patch AND the chunk's weight slab (36 KiB in MFMA operand order)
+//     -- are moved global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, the descriptor's range check writes the zero padding)
+//     while step s is multiplied, straight through tile boundaries: no per-tile entry latency;
+//   * BOTH operands come from LDS (the four waves of conv_f16_kernel each loaded every weight operand from L1/L2: 64 B/clk/CU, the whole
+//     vector-L1 rate).  Weight pieces are lane-linear (conflict-free ds_read_b128); the patch is stored as two k-step planes of 32 bytes per
+//     pixel with the two 16-byte halves of a pixel exchanged where bit 3 of the pixel index is set: the 16 lanes of a ds_read_b128 group then
+//     hit 16 different 16-byte slots of the 256-byte bank row for every tap shift (the swizzle is applied on the GLOBAL side of the DMA, the
+//     LDS image of a DMA piece is lane-linear by construction);
+//   * with I = 64 and one output-channel tile the two weight slabs stay resident (loaded once per workgroup): the layer is one pass over the
+//     NHWC tensor (HBM-bound regime);
+//   * the accumulators leave through v_permlane32_swap pairs as 16-byte channel runs (no LDS transpose, no epilogue barriers); the stores of
+//     tile T are issued after the DMA requests of the following step, so the vmcnt(0) that ends a step never waits for a fresh store.
+// LDS map (bytes): [0, 73 728) two weight stages | [73 728, 155 648) two patch stages of 2 planes x 640 pixels x 32 B | 2 x 1 KiB per-tile
+// parameters (bias; out_scale / noise rows of the fused tail).
+#include "shg_common.h"
+#include "conv_f16_p.h"
+
+namespace f16 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace ring {
+
+constexpr int TH = 16, TW = 32;                 // output pixels of a tile: wave w owns rows 2w, 2w + 1 (two 32-pixel MFMA column blocks)
+constexpr int PPX = 640;                        // patch pixels (<= 18 x 34 = 612) rounded up to whole 32-pixel DMA pieces
+constexpr int PLANE = PPX * 32;                 // bytes of one k-step plane (16 channels = 32 B per pixel)
+constexpr int PSTAGE = 2 * PLANE;               // 40 960
+constexpr int WSTAGE = 36 * 1024;               // 9 taps x 2 k-steps x 2 channel blocks x 1 KiB
+constexpr int L_W = 0, L_P = 2 * WSTAGE, L_PRM = L_P + 2 * PSTAGE;
+constexpr int LDS_BYTES = L_PRM + 2 * 1024;     // 157 696 of the CU's 163 840
+constexpr unsigned OOB = 0x80000000u;           // a byte offset no descriptor range admits: the DMA writes zeros for that lane
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 s;
+    s[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    s[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    s[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    s[3] = 0x00020000;                          // raw buffer, dword data format (tools/micro/lds_dma_probe.hip pins the semantics used here)
+    return s;
+}
+
+// 64 lanes x 16 bytes global -> LDS [lds_addr + 16 lane]; lanes whose voff + soff fails the range check deliver zeros
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 srd, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+struct Coord { int n, ty, tx, ot; };
+
+template <int NT>
+__global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const int ntiles, const int n_ot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int nchunks = p.I >> 5, c16n = p.I >> 4, npix = p.PH * p.PW;
+    const bool resident = n_ot == 1 && nchunks <= 2;            // weight stage of step s = chunk's own slab: loaded by the first two steps only
+
+    auto decode = [&](int tile) __attribute__((always_inline)) -> Coord {
+        Coord c;
+        c.ot = tile % n_ot; tile /= n_ot;
+        c.tx = tile % p.tiles_x; tile /= p.tiles_x;
+        c.ty = tile % p.tiles_y; c.n = tile / p.tiles_y;
+        return c;
+    };
+
+    // ---- what this lane moves in a patch DMA piece: wave w owns pieces 5w .. 5w+4 of the 40 (plane = w / 4, pixel group = 5 (w & 3) + i);
+    // lane l of a piece = patch pixel 32 grp + l / 2, 16-byte half (l & 1) ^ bit 3 of the pixel index
+    const int ks_dma = wave >> 2;
+    int ppy[5], ppx[5], pch[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int pp = ((wave & 3) * 5 + i) * 32 + (lane >> 1);
+        ppy[i] = pp < npix ? pp / p.PW : -100000;            // (pixels beyond the patch: never inside the image)
+        ppx[i] = pp - (pp / p.PW) * p.PW;
+        pch[i] = (ks_dma * 16 + (((lane & 1) ^ ((pp >> 3) & 1)) << 3)) * 2;
+    }
+    unsigned pvoff[5];
+    i32x4 srd_x = make_srd(p.x, 0);
+    auto tile_addresses = [&](const Coord& c) __attribute__((always_inline)) {
+        const int iy0 = c.ty * TH + p.org_y, ix0 = c.tx * TW + p.org_x;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int iy = iy0 + ppy[i], ix = ix0 + ppx[i];
+            pvoff[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (unsigned)((iy * p.W + ix) * p.I * 2 + pch[i]) : OOB;
+        }
+        srd_x = make_srd(p.x + (long)c.n * p.H * p.W * p.I, (unsigned)(p.H * p.W * p.I * 2));
+    };
+    const i32x4 srd_w = make_srd(p.w, (unsigned)((long)((p.OB + 3) / 4 * 4) * p.wslots * c16n * 1024));
+    const i32x4 srd_b = make_srd(p.bias ? (const void*)p.bias : (const void*)p.w, p.bias ? (unsigned)(p.O * 4) : 0u);
+
+    // everything step `(c, chunk)` reads, requested into stage `stage`; first chunk of a tile: its parameters into slot `tpar`
+    auto issue = [&](const Coord& c, int chunk, int stage, int tpar, bool with_weights) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int grp = (wave & 3) * 5 + i;
+            if (grp * 32 < npix) dma16(lds0 + L_P + stage * PSTAGE + (ks_dma * 20 + grp) * 1024, pvoff[i], srd_x, (unsigned)(chunk * 64));
+        }
+        if (with_weights) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int pi = wave * 5 + i;                  // piece = (t * 2 + ks) * 2 + m
+                if (pi < NT * 4) {
+                    const int t = pi >> 2, ks = (pi >> 1) & 1, m = pi & 1;
+                    const unsigned g = (unsigned)((((c.ot * 2 + m) * p.wslots + p.tw[t]) * c16n + chunk * 2 + ks) * 1024);
+                    dma16(lds0 + L_W + stage * WSTAGE + pi * 1024, (unsigned)(lane * 16), srd_w, g);
+                }
+            }
+        }
+        if (chunk == 0 && p.bias && wave == 7)                 // 64 floats of this tile's channels (beyond O: zeros); lanes >= 16 deliver zeros
+            dma16(lds0 + L_PRM + tpar * 1024, lane < 16 ? (unsigned)(c.ot * 256 + lane * 16) : OOB, srd_b, 0u);
+    };
+
+    // ---- B-operand addresses inside a patch stage (plane 0): lane (j, kg), tap t, pixel block q -> pixel p, half kg ^ bit 3 of p
+    unsigned baddr[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pp = (wave * 2 + q + p.tdy[t]) * p.PW + j + p.tdx[t];
+            baddr[t][q] = (unsigned)(pp * 32 + ((kg ^ ((pp >> 3) & 1)) << 4));
+        }
+
+    f16x acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    // the finished tile waiting for its stores: fp16 channel runs (4 halves) of [channel block][pixel block][row group]
+    u32x2 pk[2][2][4];
+    Coord pc = {0, 0, 0, 0};
+    bool pend = false;
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gy = pc.ty * TH + wave * 2 + q, gx = pc.tx * TW + j;
+            const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
+            const bool pix_ok = gy < p.GH && gx < p.GW && oy >= 0 && oy < p.OHt && ox >= 0 && ox < p.OWt;
+            const int oyc = oy < 0 ? 0 : (oy < p.OHt ? oy : p.OHt - 1), oxc = ox < 0 ? 0 : (ox < p.OWt ? ox : p.OWt - 1);
+            _Float16* yp = p.y + (((long)pc.n * p.OHt + oyc) * p.OWt + oxc) * p.O;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    // lanes 0-31 hold channels 8g .. 8g+3 of group g, lanes 32-63 channels 8g+4 .. 8g+7: after the half exchange the lower
+                    // lanes own the 16 bytes of group 2 gp, the upper lanes those of group 2 gp + 1
+                    u32x2 a = pk[m][q][2 * gp], b = pk[m][q][2 * gp + 1];
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    u32x4 v;
+                    v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
+                    const int o = pc.ot * 64 + m * 32 + (2 * gp + kg) * 8;
+                    if (pix_ok && o < p.O) *(u32x4*)(yp + o) = v;
+                }
+        }
+    };
+
+    int tile = blockIdx.x;
+    Coord cur = decode(tile);
+    tile_addresses(cur);
+    int chunk = 0, s = 0, tpar = 0;
+    issue(cur, 0, 0, 0, true);
+    while (true) {
+        // step s is in LDS once every wave's requests have landed; the same barrier says every wave has finished reading stage (s+1) & 1
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        int nchunk = chunk + 1, ntile = tile;
+        if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
+        const bool has_next = ntile < ntiles;
+        Coord nc = cur;
+        if (has_next) {
+            if (nchunk == 0) { nc = decode(ntile); tile_addresses(nc); }
+            issue(nc, nchunk, (s + 1) & 1, nchunk == 0 ? tpar ^ 1 : tpar, !(resident && s + 1 >= 2));
+        }
+        if (pend) { store_tile(); pend = false; }
+        {
+            // operands of k-iteration it + 1 (tap, k-step) are read while the four MFMAs of iteration it run: one ds_read_b128 behind each
+            // MFMA (sched_group_barrier pins the interleave; left alone the scheduler reads, waits lgkmcnt(0) and multiplies in turn)
+            const unsigned char* wa = lds + L_W + (s & 1) * WSTAGE + lane * 16;
+            const unsigned char* pa = lds + L_P + (s & 1) * PSTAGE;
+            h8 a[2][2], b[2][2];
+            a[0][0] = *(const h8*)(wa); b[0][0] = *(const h8*)(pa + baddr[0][0]);
+            b[0][1] = *(const h8*)(pa + baddr[0][1]); a[0][1] = *(const h8*)(wa + 1024);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int it = 0; it < NT * 2; ++it) {
+                const int cb = it & 1, nb = cb ^ 1;
+                if (it + 1 < NT * 2) {
+                    const int t = (it + 1) >> 1, ks = (it + 1) & 1;
+                    // (in the order the next iteration's MFMAs consume them: a0 b0 | b1 | a1)
+                    a[nb][0] = *(const h8*)(wa + ((it + 1) * 2 + 0) * 1024); b[nb][0] = *(const h8*)(pa + ks * PLANE + baddr[t][0]);
+                    b[nb][1] = *(const h8*)(pa + ks * PLANE + baddr[t][1]); a[nb][1] = *(const h8*)(wa + ((it + 1) * 2 + 1) * 1024);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][1], acc[1][1], 0, 0, 0);
+                if (it + 1 < NT * 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        }
+        if (chunk == nchunks - 1) {
+            // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            const unsigned char* prm = lds + L_PRM + tpar * 1024;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bv = *(const f4*)(prm + (m * 32 + g * 8 + kg * 4) * 4);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        h4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][g * 4 + e] + bv[e]);
+                        pk[m][q][g] = __builtin_bit_cast(u32x2, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[m][q][g * 4 + e] = 0.f;
+                    }
+                }
+            pc = cur;
+            pend = true;
+        }
+        if (!has_next) break;
+        if (nchunk == 0) { tile = ntile; cur = nc; tpar ^= 1; }
+        chunk = nchunk;
+        ++s;
+    }
+    if (pend) store_tile();
+}
+
+}  // namespace ring
+
+// The ring kernel serves: patches read with stride 1 (stride-1 convolutions; span = extent of the tap offsets) of at most 18 x 34 pixels,
+// 9 taps (for now), whole 8-channel output pieces, no fused tail / input scale (those stay on conv_f16_kernel).
+bool conv_ring_eligible(const ConvP& p, int span_y, int span_x) {
+#ifdef SHG_F16_NO_RING
+    return false;
+#else
+    if (p.s_in != 1 || p.ntaps != 9 || (p.O & 7) || (p.I & 31) || p.in_scale || p.tail) return false;
+    return ring::TH - 1 + span_y <= 18 && ring::TW - 1 + span_x <= 34;
+#endif
+}
+
+int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
+    ConvP p = p0;
+    p.PH = ring::TH - 1 + span_y;
+    p.PW = ring::TW - 1 + span_x;
+    p.tiles_y = shg_cdiv(p.GH, ring::TH);
+    p.tiles_x = shg_cdiv(p.GW, ring::TW);
+    const int n_ot = (p.O + 63) / 64;
+    const long ntiles = (long)p.N * p.tiles_y * p.tiles_x * n_ot;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES) != hipSuccess) {
+            shg_set_error("conv2d_f16 (ring): cannot reserve %d bytes of LDS", ring::LDS_BYTES);
+            return SHG_ERR_LAUNCH;
+        }
+        attr = true;
+    }
+    const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES, st, p, (int)ntiles, n_ot);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+}  // namespace f16

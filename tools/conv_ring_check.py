@@ -1,0 +1,50 @@
+"""Ring kernel (csrc/conv_f16_ring.hip) against conv_f16_kernel (variant library built with -DSHG_F16_NO_RING) -- bit-exact by construction
+(same MFMA sequence per accumulator) -- and against a float64 torch convolution of the same half operands.
+usage: python sh-gan_amd/build.py --variant=noring -DSHG_F16_NO_RING=1 && python tools/conv_ring_check.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import shgan_amd
+from shgan_amd import _lib
+from shgan_amd import kernels_f16 as kf
+
+dev = 'cuda:0'
+CL = torch.channels_last
+VAR = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_noring.so')
+PROD = _lib.LIB_PATH
+
+
+def run(lib_path, fn):
+    if lib_path:
+        _lib.use_library(lib_path)
+    out = fn()
+    torch.cuda.synchronize()
+    return out
+
+
+bad = 0
+cases = [(1, 32, 64, 16, 32, True), (2, 64, 64, 64, 64, False), (1, 64, 64, 40, 72, True), (3, 128, 128, 32, 32, True), (2, 96, 200, 19, 45, False),
+         (8, 64, 64, 512, 512, True), (8, 128, 128, 256, 256, False), (8, 512, 512, 64, 64, True), (2, 256, 512, 33, 31, True), (1, 32, 8, 7, 5, False)]
+for (n, i, o, h, w, with_bias) in cases:
+    torch.manual_seed(n * 1000 + i + o + h)
+    x = torch.randn(n, i, h, w, device=dev).half().to(memory_format=CL)
+    wt = (torch.randn(o, i, 3, 3, device=dev) / (i * 9) ** 0.5).half()
+    b = torch.randn(o, device=dev) if with_bias else None
+    y_new = run(None, lambda: kf.conv2d(x, wt, b, 1, 1))
+    ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), 1, 1)
+    err = float((y_new.double() - ref).abs().max() / ref.abs().max())
+    line = f'n{n} {i:4d}->{o:4d} {h:4d}x{w:<4d} bias={int(with_bias)}: vs float64 {err:.2e}'
+    if os.path.exists(VAR):
+        _lib.use_library(VAR)
+        y_old = kf.conv2d(x, wt, b, 1, 1)
+        torch.cuda.synchronize()
+        _lib.use_library(PROD)
+        same = torch.equal(y_old, y_new)
+        nd = int((y_old != y_new).sum())
+        line += f' | bit-exact vs conv_f16_kernel: {same} ({nd} of {y_new.numel()} differ)'
+        bad += 0 if same else 1
+    bad += 0 if err < 2e-3 else 1
+    print(line, flush=True)
+print('FAILED' if bad else 'ok')
+sys.exit(1 if bad else 0)
