@@ -20,6 +20,7 @@
 //     tile T are issued after the DMA requests of the following step, so the vmcnt(0) that ends a step never waits for a fresh store.
 // LDS map (bytes): [0, 73 728) two weight stages | [73 728, 155 648) two patch stages of 2 planes x 640 pixels x 32 B | 2 x 1 KiB per-tile
 // parameters (bias; out_scale / noise rows of the fused tail).
+#include <type_traits>
 #include "shg_common.h"
 #include "conv_f16_p.h"
 
@@ -33,6 +34,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef SHG_RING_TRACE
+// timeline study (python sh-gan_amd/build.py --variant=ringtrace -DSHG_RING_TRACE=1, tools/ring_trace.py): workgroup 0 records s_memtime of waves 0 and 7 at
+// four points of its first 64 steps: step entry | past vmcnt(0) + barrier | requests of the next step issued (+ deferred stores) | multiplied (+ packed)
+__device__ long long shg_ring_trace_buf[2 * 64 * 4];
+extern "C" int shg_ring_trace_read(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shg_ring_trace_buf), sizeof(shg_ring_trace_buf)); }
+#define RING_TRACE(slot) do { if (blockIdx.x == 0 && s < 64 && (wave == 0 || wave == 7) && lane == 0) shg_ring_trace_buf[((wave ? 1 : 0) * 64 + s) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RING_TRACE(slot) do { } while (0)
+#endif
+
 namespace ring {
 
 constexpr int TH = 16, TW = 32;                 // output pixels of a tile: wave w owns rows 2w, 2w + 1 (two 32-pixel MFMA column blocks)
@@ -41,7 +52,7 @@ constexpr int PLANE = PPX * 32;                 // bytes of one k-step plane (16
 constexpr int PSTAGE = 2 * PLANE;               // 40 960
 constexpr int WSTAGE = 36 * 1024;               // 9 taps x 2 k-steps x 2 channel blocks x 1 KiB
 constexpr int L_W = 0, L_P = 2 * WSTAGE, L_PRM = L_P + 2 * PSTAGE;
-constexpr int LDS_BYTES = L_PRM + 2 * 1024;     // 157 696 of the CU's 163 840
+constexpr int LDS_BYTES = L_PRM + 2 * 1024;     // 157 696 (+ a 1 KiB dump slot behind it: 158 720 of the CU's 163 840)
 constexpr unsigned OOB = 0x80000000u;           // a byte offset no descriptor range admits: the DMA writes zeros for that lane
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
@@ -56,7 +67,7 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
 
 // 64 lanes x 16 bytes global -> LDS [lds_addr + 16 lane]; lanes whose voff + soff fails the range check deliver zeros
 __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 srd, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(srd), "s"(soff));
 }
 
 struct Coord { int n, ty, tx, ot; };
@@ -81,59 +92,56 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
     // ---- what this lane moves in a patch DMA piece: wave w owns pieces 5w .. 5w+4 of the 40 (plane = w / 4, pixel group = 5 (w & 3) + i);
     // lane l of a piece = patch pixel 32 grp + l / 2, 16-byte half (l & 1) ^ bit 3 of the pixel index
     const int ks_dma = wave >> 2;
-    int ppy[5], ppx[5], pch[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int pp = ((wave & 3) * 5 + i) * 32 + (lane >> 1);
-        ppy[i] = pp < npix ? pp / p.PW : -100000;            // (pixels beyond the patch: never inside the image)
-        ppx[i] = pp - (pp / p.PW) * p.PW;
-        pch[i] = (ks_dma * 16 + (((lane & 1) ^ ((pp >> 3) & 1)) << 3)) * 2;
-    }
     unsigned pvoff[5];
     i32x4 srd_x = make_srd(p.x, 0);
     auto tile_addresses = [&](const Coord& c) __attribute__((always_inline)) {
         const int iy0 = c.ty * TH + p.org_y, ix0 = c.tx * TW + p.org_x;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int iy = iy0 + ppy[i], ix = ix0 + ppx[i];
-            pvoff[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (unsigned)((iy * p.W + ix) * p.I * 2 + pch[i]) : OOB;
+        for (int i = 0; i < 5; ++i) {       // (recomputed per tile: five cached (row, column, channel) triples cost 15 registers for the whole kernel)
+            const int pp = ((wave & 3) * 5 + i) * 32 + (lane >> 1), py = pp / p.PW, px = pp - py * p.PW;
+            const int iy = iy0 + py, ix = ix0 + px, ch = ks_dma * 16 + (((lane & 1) ^ ((pp >> 3) & 1)) << 3);
+            pvoff[i] = (pp < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (unsigned)(((iy * p.W + ix) * p.I + ch) * 2) : OOB;
         }
         srd_x = make_srd(p.x + (long)c.n * p.H * p.W * p.I, (unsigned)(p.H * p.W * p.I * 2));
     };
     const i32x4 srd_w = make_srd(p.w, (unsigned)((long)((p.OB + 3) / 4 * 4) * p.wslots * c16n * 1024));
     const i32x4 srd_b = make_srd(p.bias ? (const void*)p.bias : (const void*)p.w, p.bias ? (unsigned)(p.O * 4) : 0u);
 
-    // everything step `(c, chunk)` reads, requested into stage `stage`; first chunk of a tile: its parameters into slot `tpar`
-    auto issue = [&](const Coord& c, int chunk, int stage, int tpar, bool with_weights) __attribute__((always_inline)) {
+    // ---- this wave's requests of a step: five patch pieces and five weight pieces (piece 8 i + wave; i = 4 exists for waves 0-3 only: the others
+    // send theirs -- every lane out of range, zeros -- to the dump slot, wave 7 uses that slot for the tile's bias when there is one).  The requests
+    // are issued one at a time BETWEEN the MFMAs of the running step: a `buffer_load ... lds` costs its wave 100-200 cycles at issue, and with the
+    // 80 requests of a step issued together after the barrier the matrix pipe idled 1 700-3 500 cycles per step (tools/ring_trace.py).
+    unsigned wsoff[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int grp = (wave & 3) * 5 + i;
-            if (grp * 32 < npix) dma16(lds0 + L_P + stage * PSTAGE + (ks_dma * 20 + grp) * 1024, pvoff[i], srd_x, (unsigned)(chunk * 64));
-        }
-        if (with_weights) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int pi = wave * 5 + i;                  // piece = (t * 2 + ks) * 2 + m
-                if (pi < NT * 4) {
-                    const int t = pi >> 2, ks = (pi >> 1) & 1, m = pi & 1;
-                    const unsigned g = (unsigned)((((c.ot * 2 + m) * p.wslots + p.tw[t]) * c16n + chunk * 2 + ks) * 1024);
-                    dma16(lds0 + L_W + stage * WSTAGE + pi * 1024, (unsigned)(lane * 16), srd_w, g);
-                }
-            }
-        }
-        if (chunk == 0 && p.bias && wave == 7)                 // 64 floats of this tile's channels (beyond O: zeros); lanes >= 16 deliver zeros
-            dma16(lds0 + L_PRM + tpar * 1024, lane < 16 ? (unsigned)(c.ot * 256 + lane * 16) : OOB, srd_b, 0u);
+    for (int i = 0; i < 5; ++i) {
+        const int pi = i * 8 + wave, t = (pi >> 2) < NT ? (pi >> 2) : 0, ks = (pi >> 1) & 1, m = pi & 1;
+        wsoff[i] = (unsigned)(((m * p.wslots + p.tw[t]) * c16n + ks) * 1024);
+    }
+    const bool w4_ok = 32 + wave < NT * 4;
+    const unsigned L_DUMP = LDS_BYTES;          // (1 KiB behind the map, part of the launch's LDS size)
+    auto dma_patch = [&](int i, int stage, unsigned chunk_off) __attribute__((always_inline)) {
+        dma16(lds0 + L_P + stage * PSTAGE + (ks_dma * 20 + (wave & 3) * 5 + i) * 1024, pvoff[i], srd_x, chunk_off);
+    };
+    auto dma_weight = [&](int i, int stage, unsigned tile_off) __attribute__((always_inline)) {
+        if (i < 4) dma16(lds0 + L_W + stage * WSTAGE + (i * 8 + wave) * 1024, (unsigned)(lane * 16), srd_w, wsoff[i] + tile_off);
+        else dma16(w4_ok ? lds0 + L_W + stage * WSTAGE + (32 + wave) * 1024 : lds0 + L_DUMP, w4_ok ? (unsigned)(lane * 16) : OOB, srd_w, wsoff[4] + tile_off);
+    };
+    auto dma_bias = [&](int ot, int tpar) __attribute__((always_inline)) {      // 64 floats of the tile's channels (beyond O: zeros); lanes >= 16 deliver zeros
+        dma16(lds0 + L_PRM + tpar * 1024, lane < 16 ? (unsigned)(ot * 256 + lane * 16) : OOB, srd_b, 0u);
     };
 
     // ---- B-operand addresses inside a patch stage (plane 0): lane (j, kg), tap t, pixel block q -> pixel p, half kg ^ bit 3 of p
-    unsigned baddr[NT][2];
+    // (NT = 9 is conv2d_f16_impl's 3x3 table: tap t reads patch row t / 3, column t % 3 -- q + row has four values, 12 addresses instead of 18)
+    constexpr int BR = NT == 9 ? 4 : NT * 2, BC = NT == 9 ? 3 : 1;
+    unsigned baddr_[BR][BC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < BR; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int pp = (wave * 2 + q + p.tdy[t]) * p.PW + j + p.tdx[t];
-            baddr[t][q] = (unsigned)(pp * 32 + ((kg ^ ((pp >> 3) & 1)) << 4));
+        for (int c = 0; c < BC; ++c) {
+            const int pp = NT == 9 ? (wave * 2 + r) * p.PW + j + c : (wave * 2 + (r & 1) + p.tdy[r >> 1]) * p.PW + j + p.tdx[r >> 1];
+            baddr_[r][c] = (unsigned)(pp * 32 + ((kg ^ ((pp >> 3) & 1)) << 4));
         }
+    auto baddr = [&](int t, int q) __attribute__((always_inline)) -> unsigned { return NT == 9 ? baddr_[q + t / 3][t % 3] : baddr_[t * 2 + q][0]; };
 
     f16x acc[2][2];
 #pragma unroll
@@ -143,85 +151,130 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-    // the finished tile waiting for its stores: fp16 channel runs (4 halves) of [channel block][pixel block][row group]
+    // ---- the finished tile waiting for its stores: fp16 channel runs (4 halves) of [channel block][pixel block][row group]; the eight 16-byte
+    // stores of a wave go out between the MFMAs of the NEXT step (buffer stores: a lane outside the tensor is dropped by the range check)
     u32x2 pk[2][2][4];
-    Coord pc = {0, 0, 0, 0};
+    unsigned pyoff[2] = {OOB, OOB};
+    int p_ot = 0;
+    i32x4 srd_y = make_srd(p.y, 0);
     bool pend = false;
-    auto store_tile = [&]() __attribute__((always_inline)) {
+    auto pend_addresses = [&](const Coord& c) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int gy = pc.ty * TH + wave * 2 + q, gx = pc.tx * TW + j;
+            const int gy = c.ty * TH + wave * 2 + q, gx = c.tx * TW + j;
             const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
-            const bool pix_ok = gy < p.GH && gx < p.GW && oy >= 0 && oy < p.OHt && ox >= 0 && ox < p.OWt;
-            const int oyc = oy < 0 ? 0 : (oy < p.OHt ? oy : p.OHt - 1), oxc = ox < 0 ? 0 : (ox < p.OWt ? ox : p.OWt - 1);
-            _Float16* yp = p.y + (((long)pc.n * p.OHt + oyc) * p.OWt + oxc) * p.O;
+            const bool ok = gy < p.GH && gx < p.GW && oy >= 0 && oy < p.OHt && ox >= 0 && ox < p.OWt;
+            pyoff[q] = ok ? (unsigned)((oy * p.OWt + ox) * p.O * 2) : OOB;
+        }
+        p_ot = c.ot;
+        srd_y = make_srd(p.y + (long)c.n * p.OHt * p.OWt * p.O, (unsigned)(p.OHt * p.OWt * p.O * 2));
+    };
+    auto store_piece = [&](int k) __attribute__((always_inline)) {          // k = (q, m, gp)
+        const int q = k >> 2, m = (k >> 1) & 1, gp = k & 1;
+        // lanes 0-31 hold channels 8g .. 8g+3 of group g, lanes 32-63 channels 8g+4 .. 8g+7: after the half exchange the lower lanes own the
+        // 16 bytes of group 2 gp, the upper lanes those of group 2 gp + 1
+        u32x2 a = pk[m][q][2 * gp], b = pk[m][q][2 * gp + 1];
+        auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+        u32x4 v;
+        v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
+        const int o = p_ot * 64 + m * 32 + (2 * gp + kg) * 8;
+        const unsigned voff = o < p.O ? pyoff[q] + (unsigned)(o * 2) : OOB;
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(srd_y));
+    };
+
+    // ---- one step: 18 k-iterations (tap, k-step) of four MFMAs; the operands of iteration it + 1 are read while iteration it multiplies (one
+    // ds_read_b128 behind each MFMA, pinned by sched_group_barrier); requests of the next step and stores of the previous tile in between
+    auto body = [&](auto w_tag, auto p_tag, int stage, unsigned chunk_off, unsigned tile_off, int b_ot, int b_tpar) __attribute__((always_inline)) {
+        constexpr bool WITH_W = decltype(w_tag)::value, PEND = decltype(p_tag)::value;
+        const unsigned char* wa = lds + L_W + stage * WSTAGE + lane * 16;
+        const unsigned char* pa = lds + L_P + stage * PSTAGE;
+        const int nstage = stage ^ 1;
+        h8 a[2][2], b[2][2];
+        a[0][0] = *(const h8*)(wa); b[0][0] = *(const h8*)(pa + baddr(0, 0));
+        b[0][1] = *(const h8*)(pa + baddr(0, 1)); a[0][1] = *(const h8*)(wa + 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int it = 0; it < NT * 2; ++it) {
+            const int cb = it & 1, nb = cb ^ 1;
+            if (it + 1 < NT * 2) {
+                const int t = (it + 1) >> 1, ks = (it + 1) & 1;
+                a[nb][0] = *(const h8*)(wa + ((it + 1) * 2 + 0) * 1024); b[nb][0] = *(const h8*)(pa + ks * PLANE + baddr(t, 0));
+                b[nb][1] = *(const h8*)(pa + ks * PLANE + baddr(t, 1)); a[nb][1] = *(const h8*)(wa + ((it + 1) * 2 + 1) * 1024);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][1], acc[1][1], 0, 0, 0);
+            if (it + 1 < NT * 2) {
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    // lanes 0-31 hold channels 8g .. 8g+3 of group g, lanes 32-63 channels 8g+4 .. 8g+7: after the half exchange the lower
-                    // lanes own the 16 bytes of group 2 gp, the upper lanes those of group 2 gp + 1
-                    u32x2 a = pk[m][q][2 * gp], b = pk[m][q][2 * gp + 1];
-                    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-                    u32x4 v;
-                    v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
-                    const int o = pc.ot * 64 + m * 32 + (2 * gp + kg) * 8;
-                    if (pix_ok && o < p.O) *(u32x4*)(yp + o) = v;
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // slots (NT = 9: 18 iterations): patch pieces behind iterations 0 4 8 12 16, weight pieces behind 2 6 10 14 17, stores behind 1 3 .. 15
+            constexpr int LAST = NT * 2 - 1;
+            if (it % 4 == 0 && it / 4 < 5 && it / 4 * 4 <= LAST) dma_patch(it / 4, nstage, chunk_off);
+            if (NT * 2 < 17 && it == LAST)
+                for (int i = LAST / 4 + 1; i < 5; ++i) dma_patch(i, nstage, chunk_off);
+            if constexpr (WITH_W) {
+                if (it % 4 == 2 && it / 4 < 4) dma_weight(it / 4, nstage, tile_off);
+                if (it == LAST) {
+                    for (int i = (LAST >= 2 ? (LAST - 2) / 4 + 1 : 0); i < 4; ++i) dma_weight(i, nstage, tile_off);
+                    if (b_ot >= 0 && wave == 7 && !w4_ok) dma_bias(b_ot, b_tpar);
+                    else dma_weight(4, nstage, tile_off);
+                }
+            }
+            if constexpr (PEND) {
+                if ((it & 1) && it / 2 < 8) store_piece(it / 2);
+                if (NT * 2 < 16 && it == LAST)
+                    for (int k = (LAST + 1) / 2; k < 8; ++k) store_piece(k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
 
     int tile = blockIdx.x;
     Coord cur = decode(tile);
     tile_addresses(cur);
     int chunk = 0, s = 0, tpar = 0;
-    issue(cur, 0, 0, 0, true);
+    {   // requests of step 0 (and, with resident weights, the bias of the one channel tile into both parameter slots)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_patch(i, 0, 0u);
+        const unsigned tile_off = (unsigned)(cur.ot * 2 * p.wslots * c16n * 1024);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_weight(i, 0, tile_off);
+        if (p.bias && wave == 7) { dma_bias(cur.ot, 0); if (resident) dma_bias(cur.ot, 1); }
+    }
     while (true) {
         // step s is in LDS once every wave's requests have landed; the same barrier says every wave has finished reading stage (s+1) & 1
+        RING_TRACE(0);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        RING_TRACE(1);
         int nchunk = chunk + 1, ntile = tile;
         if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
         const bool has_next = ntile < ntiles;
         Coord nc = cur;
-        if (has_next) {
-            if (nchunk == 0) { nc = decode(ntile); tile_addresses(nc); }
-            issue(nc, nchunk, (s + 1) & 1, nchunk == 0 ? tpar ^ 1 : tpar, !(resident && s + 1 >= 2));
+        if (!has_next) { nchunk = chunk; ntile = tile; }             // (the last step requests itself once more: no special case in the body)
+        else if (nchunk == 0) { nc = decode(ntile); tile_addresses(nc); }
+        const unsigned chunk_off = (unsigned)(nchunk * 64), tile_off = (unsigned)((nc.ot * 2 * p.wslots * c16n + nchunk * 2) * 1024);
+        const bool with_w = !(resident && s + 1 >= 2);
+        const int b_ot = (p.bias && !resident && nchunk == 0 && has_next) ? nc.ot : -1, b_tpar = tpar ^ 1;
+        RING_TRACE(2);
+        if (with_w) {
+            if (pend) body(T_{}, T_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
+            else body(T_{}, F_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
+        } else {
+            if (pend) body(F_{}, T_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
+            else body(F_{}, F_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
         }
-        if (pend) { store_tile(); pend = false; }
-        {
-            // operands of k-iteration it + 1 (tap, k-step) are read while the four MFMAs of iteration it run: one ds_read_b128 behind each
-            // MFMA (sched_group_barrier pins the interleave; left alone the scheduler reads, waits lgkmcnt(0) and multiplies in turn)
-            const unsigned char* wa = lds + L_W + (s & 1) * WSTAGE + lane * 16;
-            const unsigned char* pa = lds + L_P + (s & 1) * PSTAGE;
-            h8 a[2][2], b[2][2];
-            a[0][0] = *(const h8*)(wa); b[0][0] = *(const h8*)(pa + baddr[0][0]);
-            b[0][1] = *(const h8*)(pa + baddr[0][1]); a[0][1] = *(const h8*)(wa + 1024);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int it = 0; it < NT * 2; ++it) {
-                const int cb = it & 1, nb = cb ^ 1;
-                if (it + 1 < NT * 2) {
-                    const int t = (it + 1) >> 1, ks = (it + 1) & 1;
-                    // (in the order the next iteration's MFMAs consume them: a0 b0 | b1 | a1)
-                    a[nb][0] = *(const h8*)(wa + ((it + 1) * 2 + 0) * 1024); b[nb][0] = *(const h8*)(pa + ks * PLANE + baddr[t][0]);
-                    b[nb][1] = *(const h8*)(pa + ks * PLANE + baddr[t][1]); a[nb][1] = *(const h8*)(wa + ((it + 1) * 2 + 1) * 1024);
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[cb][1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][1], b[cb][1], acc[1][1], 0, 0, 0);
-                if (it + 1 < NT * 2) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                }
-            }
-        }
+        pend = false;
         if (chunk == nchunks - 1) {
             // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
             const unsigned char* prm = lds + L_PRM + tpar * 1024;
@@ -241,15 +294,19 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
                         for (int e = 0; e < 4; ++e) acc[m][q][g * 4 + e] = 0.f;
                     }
                 }
-            pc = cur;
+            pend_addresses(cur);
             pend = true;
         }
+        RING_TRACE(3);
         if (!has_next) break;
         if (nchunk == 0) { tile = ntile; cur = nc; tpar ^= 1; }
         chunk = nchunk;
         ++s;
     }
-    if (pend) store_tile();
+    if (pend)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) store_piece(k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (no request may outlive the workgroup: the last step's self-request, the stores)
 }
 
 }  // namespace ring
@@ -281,14 +338,14 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES + 1024) != hipSuccess) {
             shg_set_error("conv2d_f16 (ring): cannot reserve %d bytes of LDS", ring::LDS_BYTES);
             return SHG_ERR_LAUNCH;
         }
         attr = true;
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES, st, p, (int)ntiles, n_ot);
+    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES + 1024, st, p, (int)ntiles, n_ot);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

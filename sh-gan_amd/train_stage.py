@@ -104,7 +104,7 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
 # (path-length / R1 regularisers) are numbered by that thread's counter and the forward nodes by the main thread's; the two advance by
 # different amounts per iteration, so the ready-queue order of the double-backward graph -- and the order in which gradients with
 # several consumers (x_global, the encoder's skip features) are summed -- changed from one execution to the next: identical inputs
-# gave parameters that differed in the last bits (tools/probes/autograd_thread_order.py; every kernel is bit-repeatable).  One
+# gave parameters that differed in the last bits (tools/ARCHIVE.md: probes/autograd_thread_order.py; every kernel is bit-repeatable).  One
 # GPU per process means the worker thread bought no concurrency anyway.
 SINGLE_THREADED_BACKWARD = os.environ.get('SHG_ENGINE_THREADS', '0') != '1'
 

@@ -161,7 +161,7 @@ def test_config5_batch8_training_iteration_all_phases(fp16):
     all-reduce buckets, sanitised), each twice from the same state and BIT-IDENTICAL on replay: Gmain + Dmain (every iteration) and
     Gmain + Greg + Dmain + Dreg (the lazy regularisers on top).  The second-order passes are only repeatable because
     ``train_stage`` runs the backward on the calling thread (``SINGLE_THREADED_BACKWARD``): with torch's device worker thread the
-    order in which gradients of multi-consumer tensors are summed drifts between executions (tools/probes/autograd_thread_order.py;
+    order in which gradients of multi-consumer tensors are summed drifts between executions (tools/ARCHIVE.md: probes/autograd_thread_order.py;
     MEASUREMENTS.md, round 4)."""
     import copy
     from shgan_amd import losses, train_stage as ts
