@@ -138,8 +138,9 @@ def parse():
                     help='HIP streams the consecutive (independent) batches are issued on round-robin; 1 = one stream')
     ap.add_argument('--profile-steps', type=int, default=3, help='steps of the instrumented second pass (0 = skip)')
     ap.add_argument('--digest-out', default=None,
-                    help='write {sample id: sha256 of its uint8 output} of this rank\'s last timed step to <path>.rank<r>.json '
-                         '(tests/test_gpu_bench_ranks.py compares the ranks of an N = 2 run with the single-process run id by id)')
+                    help='write {sample id: sha256 of its uint8 output} of this rank\'s last timed step to <path>.rank<r>.json and the '
+                         'uint8 images to <path>.rank<r>.npy (tests/test_gpu_bench_ranks.py compares the ranks of an N = 2 run with the '
+                         'single-process run id by id)')
     return ap.parse_args()
 
 
@@ -432,9 +433,13 @@ def worker(local_rank, a, spawned_world=None, port=None):
     assert out.dtype == torch.uint8 and tuple(out.shape) == (batch, 3, res, res)
     if a.digest_out:
         import hashlib
+        import numpy as np
         o8 = out.cpu().numpy()
         with open(f'{a.digest_out}.rank{rank}.json', 'w') as fh:
             json.dump({str(i): hashlib.sha256(o8[k].tobytes()).hexdigest() for k, i in enumerate(ids)}, fh)
+        # the images themselves: a sample's output depends on its batch-mates at the 1e-6 level through the batch-global style RMS of
+        # stylegan.py:147, so digests of one id agree across batch compositions only up to a few truncation flips
+        np.save(f'{a.digest_out}.rank{rank}.npy', o8)
     # one batch alone on one stream (latency of a step; not the headline)
     lat_ms = None
     if rank == 0:

@@ -107,24 +107,24 @@ class _FirDownConvFn(torch.autograd.Function):
         ctx.join = grad_ops.InputGradJoin.adopt(x, ctx.needs_input_grad[0])      # (an encoder block's feature map: its other consumer is the synthesis network)
         ctx.bias_dtype = None if bias is None else bias.dtype
         if act_cfg is None:
-            ctx.save_for_backward(xf, w, f)
+            ctx.save_for_backward(xf, w, f, x)
             return conv2d_gradfix.conv2d(xf, w.detach(), stride=2, padding=0)
         # bias + activation in the store pass of the strided convolution (``conv2d_down_bias_act``); the output is saved for their backward
         act, gain, alpha, act_gain, clamp = act_cfg
         pw = kernels.conv_weight_prep(w.detach())
         y = kernels.conv2d(xf, pw, mode=kernels.MODE_DOWN2, pad=0, bias=None if bias is None else bias.detach(), act=act, gain=gain, alpha=alpha,
                            act_gain=act_gain, clamp=clamp)
-        ctx.save_for_backward(xf, w, f, y)
+        ctx.save_for_backward(xf, w, f, x, y)
         return y
 
     @staticmethod
     def backward(ctx, g):
         gb = None
         if ctx.act_cfg is not None:
-            xf, w, f, y = ctx.saved_tensors
+            xf, w, f, x, y = ctx.saved_tensors
             g, gb = grad_ops.bias_act_grads(g.contiguous(), y, ctx.act_cfg, ctx.bias_dtype is not None and ctx.needs_input_grad[4], ctx.bias_dtype)
         else:
-            xf, w, f = ctx.saved_tensors
+            xf, w, f, x = ctx.saved_tensors
         x_shape, flip = ctx.cfg
         g = g.contiguous()
         gx = gw = None
@@ -139,10 +139,10 @@ class _FirDownConvFn(torch.autograd.Function):
                 gx = kernels.upfir_planar(mid, f, fir_gain=1.0, flip=not flip, residual=None if other is None else other.contiguous())
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             if torch.is_grad_enabled() and ctx.needs_input_grad[0]:
-                # the saved ``xf`` is detached from x: d(gw)/dx would be dropped silently (the reference's Conv2dGradWeight is differentiable in
-                # the input, conv2d_gradfix.py:140-146).  The shipped regularisers differentiate twice under no_weight_gradients and never come here.
-                raise NotImplementedError('second-order use of the fused FIR + stride-2 node with weight gradients enabled: set '
-                                          'conv2d_resample.FUSED_TRAIN_RESAMPLE = False (composed, fully differentiable route)')
+                # create_graph with weight gradients: the saved ``xf`` is detached from x, and the reference's Conv2dGradWeight is differentiable
+                # in the input (conv2d_gradfix.py:140-146) -- filter the saved input again, on the differentiable operator (x itself is an
+                # input of this node: saving it holds no extra memory).  The shipped regularisers run under no_weight_gradients and skip this.
+                xf = upfirdn2d.upfirdn2d(x=x, f=f, padding=[2, 2, 2, 2], flip_filter=flip)
             gw = conv2d_gradfix._WgradFn.apply(g, xf, 3, 2, 0)
         return gx, gw, None, None, gb, None
 
