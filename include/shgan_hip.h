@@ -213,6 +213,14 @@ int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N
 size_t shg_conv2d_wgrad_workspace_bytes(int NB, int I, int O, int OH, int OW, int kh, int kw);
 int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, int NB, int I, int O, int H, int W, int OH, int OW,
                          int kh, int kw, int stride, int pad, void* workspace, size_t ws_bytes, void* stream);
+/* The same weight gradient for the stride-1 3x3 'same' layers (pad 1, OH = H, OW = W, W % 4 == 0, W >= 16) in the Winograd domain -- the
+ * transpose of F(4x4,3x3): dw = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G, a quarter of the multiplications, both operands transformed
+ * in the kernel, fp32 MFMA; deterministic; ~5e-6 relative against float64 (the direct form: ~2e-6).  shg_conv2d_wgrad_wino_supported
+ * tells whether a geometry is served (1 / 0); x and g 16-byte aligned. */
+int shg_conv2d_wgrad_wino_supported(int H, int W, int OH, int OW, int kh, int kw, int stride, int pad);
+size_t shg_conv2d_wgrad_wino_workspace_bytes(int NB, int I, int O, int H, int W);
+int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* dw, int NB, int I, int O, int H, int W, void* workspace,
+                              size_t ws_bytes, void* stream);
 /* SHU spectral stage in one launch (shgan.py:320-321 conv0 + ReLU, :143-160 heterogeneous filter incl. the band sum):
  * S[n,o,p] = sum_k cw[k,p] * sum_i W1[o*bands+k, i] * relu(sum_j W0[i,j] T[n,j,p] + b0[i]);  T, S: [N,64,P], P % 64 == 0;
  * w0p [32][2][64] / w1p [bands*32][2][64]: weights in MFMA operand order, element [ks][mo][l] = W[mo*32 + (l & 31)][2*ks + (l >> 5)]

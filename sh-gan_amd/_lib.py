@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -73,6 +73,9 @@ _SIGS = {
     'shg_bias_act_backward_f32': [c_fp, c_fp, c_fp, c_l, c_i, c_f, c_f, c_f, c_fp],
     'shg_conv2d_wgrad_workspace_bytes': [c_i] * 7,
     'shg_conv2d_wgrad_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_fp, ctypes.c_size_t, c_fp],
+    'shg_conv2d_wgrad_wino_supported': [c_i] * 8,
+    'shg_conv2d_wgrad_wino_workspace_bytes': [c_i] * 5,
+    'shg_conv2d_wgrad_wino_f32': [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_shu_spectral_f32': [c_fp] * 6 + [c_i] * 4 + [c_fp],
     'shg_shu_split_irfft2_f32': [c_fp, c_fp, c_pp, c_pp, ctypes.POINTER(c_l), c_i, c_i, c_i, c_i, c_fp],
     'shg_shu_split_adjoint_f32': [c_pp, ctypes.POINTER(c_l), c_pp, c_fp, c_i, c_i, c_fp],
@@ -143,6 +146,7 @@ def get_lib():
     lib.shg_last_error.restype = ctypes.c_char_p
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_wgrad_wino_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_f16_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_f16_packed_weight_elems.restype = c_l
     lib.shg_conv_wino4_weight_elems.restype = c_l

@@ -13,7 +13,10 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libshgan_hip.so'
 VARDIR = os.path.join(os.path.dirname(HERE), 'tools', '_variants')      # study builds (-DSHG_ABLATE, A/B knobs) live with the tools, never beside the product library
-SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_f16.hip', 'conv_f16_ring.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
+SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_wgrad_wino.hip', 'conv_f16.hip', 'conv_f16_ring.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
+# per-source extras: the Winograd weight-gradient transforms are scalar fp32 chains beside MFMAs -- SLP-packed (v_pk_*) forms cost register
+# moves and issue slots there
+SRC_FLAGS = {'conv_wgrad_wino.hip': ['-fno-slp-vectorize']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-inline-asm']
 
 
@@ -35,7 +38,7 @@ def _digest(extra=()):
             with open(os.path.join(d, name), 'rb') as fh:
                 h.update(name.encode())
                 h.update(fh.read())
-    h.update(' '.join(list(FLAGS) + list(extra)).encode())
+    h.update(' '.join(list(FLAGS) + [f'{k}:{v}' for k, v in sorted(SRC_FLAGS.items())] + list(extra)).encode())
     return h.hexdigest()
 
 
@@ -67,7 +70,7 @@ def build(force=False, verbose=True, ablate=False, variant=None, defines=()):
     for src in SOURCES:
         obj = os.path.join(outdir, src.replace('.hip', (f'.{variant}.o' if variant else '.abl.o') if ablate else '.o'))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + SRC_FLAGS.get(src, []) + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print('[build]', ' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

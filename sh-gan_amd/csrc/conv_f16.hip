@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB == 2 &&
                 const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float z = (float)v[k] * dd[k] + nz + bb[k];
+                    float z = __builtin_fmaf((float)v[k], dd[k], nz) + bb[k];     // (spelled out: conv_f16_ring.hip's tail is the same expression)
                     z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
                     v[k] = (_Float16)((float)(_Float16)z + (float)rs[k]);
                 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB == 2 &&
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float z = (float)v[k] * dd[k] + nz + bb[k];
+                float z = __builtin_fmaf((float)v[k], dd[k], nz) + bb[k];     // (spelled out: conv_f16_ring.hip's tail is the same expression)
                 z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
                 v[k] = (_Float16)((float)(_Float16)z + (float)rs[k]);
             }

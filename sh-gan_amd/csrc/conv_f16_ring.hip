@@ -18,8 +18,11 @@
 //     NHWC tensor (HBM-bound regime);
 //   * the accumulators leave through v_permlane32_swap pairs as 16-byte channel runs (no LDS transpose, no epilogue barriers); the stores of
 //     tile T are issued after the DMA requests of the following step, so the vmcnt(0) that ends a step never waits for a fresh store.
-// LDS map (bytes): [0, 73 728) two weight stages | [73 728, 155 648) two patch stages of 2 planes x 640 pixels x 32 B | 2 x 1 KiB per-tile
-// parameters (bias; out_scale / noise rows of the fused tail).
+//   * the layer tail of conv_f16_kernel's store pass (y = A(half(conv) * out_scale[n,o] + noise * strength + bias[o]): the critic's and the encoder's
+//     bias + lrelu_agc, the modulated layers' demodulation / noise of the inference route) is applied to the accumulators in registers, same
+//     operations in the same order; its operands of a tile (64 bias and out_scale values, 16 x 32 noise values) arrive by DMA like everything else.
+// LDS map (bytes): [0, 73 728) two weight stages | [73 728, 155 648) two patch stages of 2 planes x 640 pixels x 32 B | 2 x 4 KiB per-tile
+// parameters (bias | out_scale | noise 16 rows x 128 B, each in its own KiB).
 #include <type_traits>
 #include "shg_common.h"
 #include "conv_f16_p.h"
@@ -52,7 +55,9 @@ constexpr int PLANE = PPX * 32;                 // bytes of one k-step plane (16
 constexpr int PSTAGE = 2 * PLANE;               // 40 960
 constexpr int WSTAGE = 36 * 1024;               // 9 taps x 2 k-steps x 2 channel blocks x 1 KiB
 constexpr int L_W = 0, L_P = 2 * WSTAGE, L_PRM = L_P + 2 * PSTAGE;
-constexpr int LDS_BYTES = L_PRM + 2 * 1024;     // 157 696 (+ a 1 KiB dump slot behind it: 158 720 of the CU's 163 840)
+constexpr int PRM = 4096, PRM_SCALE = 1024, PRM_NOISE = 2048;      // a tile's parameter slot: bias | out_scale | noise rows -- 1 KiB apart: a DMA request
+                                                                   // writes all 64 lanes' 16 bytes (zeros for the lanes out of range)
+constexpr int LDS_BYTES = L_PRM + 2 * PRM;      // 163 840: all of the CU's LDS
 constexpr unsigned OOB = 0x80000000u;           // a byte offset no descriptor range admits: the DMA writes zeros for that lane
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
@@ -105,8 +110,6 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         srd_x = make_srd(p.x + (long)c.n * p.H * p.W * p.I, (unsigned)(p.H * p.W * p.I * 2));
     };
     const i32x4 srd_w = make_srd(p.w, (unsigned)((long)((p.OB + 3) / 4 * 4) * p.wslots * c16n * 1024));
-    const i32x4 srd_b = make_srd(p.bias ? (const void*)p.bias : (const void*)p.w, p.bias ? (unsigned)(p.O * 4) : 0u);
-
     // ---- this wave's requests of a step: five patch pieces and five weight pieces (piece 8 i + wave; i = 4 exists for waves 0-3 only: the others
     // send theirs -- every lane out of range, zeros -- to the dump slot, wave 7 uses that slot for the tile's bias when there is one).  The requests
     // are issued one at a time BETWEEN the MFMAs of the running step: a `buffer_load ... lds` costs its wave 100-200 cycles at issue, and with the
@@ -118,16 +121,27 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         wsoff[i] = (unsigned)(((m * p.wslots + p.tw[t]) * c16n + ks) * 1024);
     }
     const bool w4_ok = 32 + wave < NT * 4;
-    const unsigned L_DUMP = LDS_BYTES;          // (1 KiB behind the map, part of the launch's LDS size)
     auto dma_patch = [&](int i, int stage, unsigned chunk_off) __attribute__((always_inline)) {
         dma16(lds0 + L_P + stage * PSTAGE + (ks_dma * 20 + (wave & 3) * 5 + i) * 1024, pvoff[i], srd_x, chunk_off);
     };
     auto dma_weight = [&](int i, int stage, unsigned tile_off) __attribute__((always_inline)) {
         if (i < 4) dma16(lds0 + L_W + stage * WSTAGE + (i * 8 + wave) * 1024, (unsigned)(lane * 16), srd_w, wsoff[i] + tile_off);
-        else dma16(w4_ok ? lds0 + L_W + stage * WSTAGE + (32 + wave) * 1024 : lds0 + L_DUMP, w4_ok ? (unsigned)(lane * 16) : OOB, srd_w, wsoff[4] + tile_off);
+        else if (w4_ok) dma16(lds0 + L_W + stage * WSTAGE + (32 + wave) * 1024, (unsigned)(lane * 16), srd_w, wsoff[4] + tile_off);
     };
-    auto dma_bias = [&](int ot, int tpar) __attribute__((always_inline)) {      // 64 floats of the tile's channels (beyond O: zeros); lanes >= 16 deliver zeros
-        dma16(lds0 + L_PRM + tpar * 1024, lane < 16 ? (unsigned)(ot * 256 + lane * 16) : OOB, srd_b, 0u);
+    // a tile's parameters, one request each from the waves without a fifth weight piece: wave 7 the 64 bias values of the channel tile, wave 6 its
+    // 64 out_scale values of sample n (beyond the tensor: zeros; those channels are never stored), waves 4 / 5 noise rows 0-7 / 8-15 of the
+    // tile (lane = row l / 8, columns 4 (l % 8) ..; OW % 4 == 0 keeps a piece inside or outside its row as a whole)
+    auto dma_params = [&](const Coord& c, int tpar) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + L_PRM + tpar * PRM;       // (descriptors are built here, once per tile: held for the whole kernel they cost 12 scalar registers)
+        if (wave == 7) { if (p.bias) dma16(dst, lane < 16 ? (unsigned)(c.ot * 256 + lane * 16) : OOB, make_srd(p.bias, (unsigned)(p.O * 4)), 0u); }
+        else if (wave == 6) {
+            if (p.out_scale) dma16(dst + PRM_SCALE, lane < 16 ? (unsigned)((c.n * p.O + c.ot * 64) * 4 + lane * 16) : OOB, make_srd(p.out_scale, (unsigned)((long)p.N * p.O * 4)), 0u);
+        } else if (wave >= 4 && p.noise_mode) {
+            const int gy = c.ty * TH + (wave - 4) * 8 + (lane >> 3), gx = c.tx * TW + (lane & 7) * 4;
+            const unsigned img = p.noise_mode == 2 ? (unsigned)c.n * (unsigned)(p.OHt * p.OWt) : 0u;
+            dma16(dst + PRM_NOISE + (wave - 4) * 1024, (gy < p.OHt && gx < p.OWt) ? (img + (unsigned)(gy * p.OWt + gx)) * 4u : OOB,
+                  make_srd(p.noise, (unsigned)((long)(p.noise_mode == 2 ? p.N : 1) * p.OHt * p.OWt * 4)), 0u);
+        }
     };
 
     // ---- B-operand addresses inside a patch stage (plane 0): lane (j, kg), tap t, pixel block q -> pixel p, half kg ^ bit 3 of p
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
 
     // ---- one step: 18 k-iterations (tap, k-step) of four MFMAs; the operands of iteration it + 1 are read while iteration it multiplies (one
     // ds_read_b128 behind each MFMA, pinned by sched_group_barrier); requests of the next step and stores of the previous tile in between
-    auto body = [&](auto w_tag, auto p_tag, int stage, unsigned chunk_off, unsigned tile_off, int b_ot, int b_tpar) __attribute__((always_inline)) {
+    auto body = [&](auto w_tag, auto p_tag, int stage, unsigned chunk_off, unsigned tile_off, bool prm_next, const Coord& b_c, int b_tpar) __attribute__((always_inline)) {
         constexpr bool WITH_W = decltype(w_tag)::value, PEND = decltype(p_tag)::value;
         const unsigned char* wa = lds + L_W + stage * WSTAGE + lane * 16;
         const unsigned char* pa = lds + L_P + stage * PSTAGE;
@@ -225,10 +239,10 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
                 if (it % 4 == 2 && it / 4 < 4) dma_weight(it / 4, nstage, tile_off);
                 if (it == LAST) {
                     for (int i = (LAST >= 2 ? (LAST - 2) / 4 + 1 : 0); i < 4; ++i) dma_weight(i, nstage, tile_off);
-                    if (b_ot >= 0 && wave == 7 && !w4_ok) dma_bias(b_ot, b_tpar);
-                    else dma_weight(4, nstage, tile_off);
+                    dma_weight(4, nstage, tile_off);
                 }
             }
+            if (it == LAST && prm_next) dma_params(b_c, b_tpar);
             if constexpr (PEND) {
                 if ((it & 1) && it / 2 < 8) store_piece(it / 2);
                 if (NT * 2 < 16 && it == LAST)
@@ -244,13 +258,14 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
     Coord cur = decode(tile);
     tile_addresses(cur);
     int chunk = 0, s = 0, tpar = 0;
-    {   // requests of step 0 (and, with resident weights, the bias of the one channel tile into both parameter slots)
+    const bool prm_any = p.bias || p.tail, prm_per_tile = prm_any && (!resident || p.tail);
+    {   // requests of step 0 (and, with resident weights and no tail, the bias of the one channel tile into both parameter slots)
 #pragma unroll
         for (int i = 0; i < 5; ++i) dma_patch(i, 0, 0u);
         const unsigned tile_off = (unsigned)(cur.ot * 2 * p.wslots * c16n * 1024);
 #pragma unroll
         for (int i = 0; i < 5; ++i) dma_weight(i, 0, tile_off);
-        if (p.bias && wave == 7) { dma_bias(cur.ot, 0); if (resident) dma_bias(cur.ot, 1); }
+        if (prm_any) { dma_params(cur, 0); if (!prm_per_tile) dma_params(cur, 1); }
     }
     while (true) {
         // step s is in LDS once every wave's requests have landed; the same barrier says every wave has finished reading stage (s+1) & 1
@@ -265,35 +280,65 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         else if (nchunk == 0) { nc = decode(ntile); tile_addresses(nc); }
         const unsigned chunk_off = (unsigned)(nchunk * 64), tile_off = (unsigned)((nc.ot * 2 * p.wslots * c16n + nchunk * 2) * 1024);
         const bool with_w = !(resident && s + 1 >= 2);
-        const int b_ot = (p.bias && !resident && nchunk == 0 && has_next) ? nc.ot : -1, b_tpar = tpar ^ 1;
+        const bool prm_next = prm_per_tile && nchunk == 0 && has_next;
+        const int b_tpar = tpar ^ 1;
         RING_TRACE(2);
         if (with_w) {
-            if (pend) body(T_{}, T_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
-            else body(T_{}, F_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
+            if (pend) body(T_{}, T_{}, s & 1, chunk_off, tile_off, prm_next, nc, b_tpar);
+            else body(T_{}, F_{}, s & 1, chunk_off, tile_off, prm_next, nc, b_tpar);
         } else {
-            if (pend) body(F_{}, T_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
-            else body(F_{}, F_{}, s & 1, chunk_off, tile_off, b_ot, b_tpar);
+            if (pend) body(F_{}, T_{}, s & 1, chunk_off, tile_off, prm_next, nc, b_tpar);
+            else body(F_{}, F_{}, s & 1, chunk_off, tile_off, prm_next, nc, b_tpar);
         }
         pend = false;
         if (chunk == nchunks - 1) {
             // C/D layout: column (pixel) = lane & 31, row (channel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-            const unsigned char* prm = lds + L_PRM + tpar * 1024;
+            const unsigned char* prm = lds + L_PRM + tpar * PRM;
+            if (!p.tail) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias) bv = *(const f4*)(prm + (m * 32 + g * 8 + kg * 4) * 4);
+                    for (int g = 0; g < 4; ++g) {
+                        f4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) bv = *(const f4*)(prm + (m * 32 + g * 8 + kg * 4) * 4);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        h4 v;
+                        for (int q = 0; q < 2; ++q) {
+                            h4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][g * 4 + e] + bv[e]);
-                        pk[m][q][g] = __builtin_bit_cast(u32x2, v);
+                            for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[m][q][g * 4 + e] + bv[e]);
+                            pk[m][q][g] = __builtin_bit_cast(u32x2, v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[m][q][g * 4 + e] = 0.f;
+                            for (int e = 0; e < 4; ++e) acc[m][q][g * 4 + e] = 0.f;
+                        }
                     }
-                }
+            } else {
+                // conv_f16_kernel's tail on the half-rounded result: z = half(acc) * d + noise * strength + bias -> lrelu_agc (or * gain) -> half
+                float nz[2] = {0.f, 0.f};
+                if (p.noise_mode)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) nz[q] = *(const float*)(prm + PRM_NOISE + ((wave * 2 + q) * 32 + j) * 4) * p.noise_strength;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f4 bv = {0.f, 0.f, 0.f, 0.f}, dv = {1.f, 1.f, 1.f, 1.f};
+                        if (p.bias) bv = *(const f4*)(prm + (m * 32 + g * 8 + kg * 4) * 4);
+                        if (p.out_scale) dv = *(const f4*)(prm + PRM_SCALE + (m * 32 + g * 8 + kg * 4) * 4);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            h4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float z = __builtin_fmaf((float)(_Float16)acc[m][q][g * 4 + e], dv[e], nz[q]) + bv[e];
+                                z = p.act ? shg_lrelu_agc(z, p.alpha, p.gain, p.clamp) : z * p.gain;
+                                v[e] = (_Float16)z;
+                            }
+                            pk[m][q][g] = __builtin_bit_cast(u32x2, v);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[m][q][g * 4 + e] = 0.f;
+                        }
+                    }
+            }
             pend_addresses(cur);
             pend = true;
         }
@@ -312,12 +357,16 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
 }  // namespace ring
 
 // The ring kernel serves: patches read with stride 1 (stride-1 convolutions; span = extent of the tap offsets) of at most 18 x 34 pixels,
-// 9 taps (for now), whole 8-channel output pieces, no fused tail / input scale (those stay on conv_f16_kernel).
+// 9 taps (for now), whole 8-channel output pieces; of the fused tail everything but the input scale and the residual (those stay on
+// conv_f16_kernel), noise with whole 16-byte pieces per row.
 bool conv_ring_eligible(const ConvP& p, int span_y, int span_x) {
 #ifdef SHG_F16_NO_RING
     return false;
 #else
-    if (p.s_in != 1 || p.ntaps != 9 || (p.O & 7) || (p.I & 31) || p.in_scale || p.tail) return false;
+    if (p.s_in != 1 || p.ntaps != 9 || (p.O & 7) || (p.I & 31) || p.in_scale || p.residual) return false;
+    if (p.tail && (p.s_out != 1 || p.oy0 || p.ox0)) return false;
+    if (p.noise_mode && ((p.OWt & 3) || (reinterpret_cast<uintptr_t>(p.noise) & 15))) return false;
+    if ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.out_scale)) & 15) return false;
     return ring::TH - 1 + span_y <= 18 && ring::TW - 1 + span_x <= 34;
 #endif
 }
@@ -338,14 +387,14 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
     }
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES + 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES) != hipSuccess) {
             shg_set_error("conv2d_f16 (ring): cannot reserve %d bytes of LDS", ring::LDS_BYTES);
             return SHG_ERR_LAUNCH;
         }
         attr = true;
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES + 1024, st, p, (int)ntiles, n_ot);
+    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES, st, p, (int)ntiles, n_ot);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

@@ -308,6 +308,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     if (g == 0 && e < n) dw[e] = v;
 }
 
+static void launch_wgrad_reduce(const float* part, float* dw, long n, int nslice, hipStream_t s);
+void shg_launch_wgrad_reduce(const float* part, float* dw, long n, int nslice, hipStream_t s) { launch_wgrad_reduce(part, dw, n, nslice, s); }    // conv_wgrad_wino.hip
 static void launch_wgrad_reduce(const float* part, float* dw, long n, int nslice, hipStream_t s) {
     int G = 1;
     while (G < 16 && (n + 256 / G - 1) / (256 / G) < 2048 && nslice >= 8 * G) G *= 2;

@@ -902,9 +902,13 @@ def shu_split_adjoint(grads, gauss, n, c):
     return out
 
 
+WGRAD_WINO = True        # stride-1 3x3 'same' layers: weight gradient in the Winograd domain (csrc/conv_wgrad_wino.hip); False = the direct kernel
+
+
 def conv2d_wgrad(x, g, kh, kw, stride=1, pad=0):
     """Weight gradient of y = conv2d(x, w, stride, pad): x [NB,I,H,W], g = dL/dy [NB,O,OH,OW] -> dw [O,I,kh,kw]
-    (shg_conv2d_wgrad_f32; for conv_transpose2d call it with (dL/dy, x) and read the result as [Cin,Cout,kh,kw])."""
+    (shg_conv2d_wgrad_f32, or shg_conv2d_wgrad_wino_f32 where it applies; for conv_transpose2d call it with (dL/dy, x) and read the
+    result as [Cin,Cout,kh,kw])."""
     L = _Launch()
     x, g = L.req(x, 'x'), L.req(g, 'g')
     nb, i, h, w = x.shape
@@ -913,9 +917,17 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, pad=0):
         raise _lib.ShgError('conv2d_wgrad: batch sizes differ')
     lib = _lib.get_lib()
     dw = L.new((o, i, kh, kw))
+    flops = 2.0 * nb * o * i * kh * kw * oh * ow
+    if (WGRAD_WINO and lib.shg_conv2d_wgrad_wino_supported(h, w, oh, ow, kh, kw, int(stride), int(pad)) and x.data_ptr() % 16 == 0
+            and g.data_ptr() % 16 == 0 and max(i, o) * h * w * 4 < 2 ** 31):
+        ws_bytes = int(lib.shg_conv2d_wgrad_wino_workspace_bytes(nb, i, o, h, w))
+        ws = L.new((ws_bytes // 4,)) if ws_bytes else None
+        with _timed(L, 'conv_wgrad_wino', flops, executed=flops / 4):
+            check(lib.shg_conv2d_wgrad_wino_f32(_ptr(x), _ptr(g), _ptr(dw), nb, i, o, h, w, _ptr(ws), ws_bytes, L.stream()), 'conv2d_wgrad_wino')
+        return dw
     ws_bytes = int(lib.shg_conv2d_wgrad_workspace_bytes(nb, i, o, oh, ow, kh, kw))
     ws = L.new((ws_bytes // 4,)) if ws_bytes else None
-    with _timed(L, 'conv_wgrad', 2.0 * nb * o * i * kh * kw * oh * ow):
+    with _timed(L, 'conv_wgrad', flops):
         check(lib.shg_conv2d_wgrad_f32(_ptr(x), _ptr(g), _ptr(dw), nb, i, o, h, w, oh, ow, kh, kw, int(stride), int(pad), _ptr(ws), ws_bytes,
                                        L.stream()), 'conv2d_wgrad')
     return dw

@@ -285,19 +285,22 @@ def test_graph_pipeline_recaptures_when_the_parameters_move():
     def step(x_, z_):
         return hz.run_generator(G, x_, z_, noise_mode='const')
     pipe = hz.GraphPipeline(DEV, step, (x, z), depth=2, watch=list(G.parameters()) + list(G.buffers()))
-    before = pipe.run(x, z).clone()
-    pipe.join()
+    before = pipe.run(x, z)
+    pipe.join()                                    # (the replay runs on the slot's stream: join before the current stream reads the output)
+    before = before.clone()
     assert pipe.captures == 1 and torch.equal(before, step(x, z))
     for p in G.parameters():                       # what an EMA update / optimiser step does: in place, new version counters
         p.mul_(1.25)
     for _ in range(3):
-        after = pipe.run(x, z).clone()
+        after = pipe.run(x, z)
         pipe.join()
+        after = after.clone()
     assert pipe.captures == 2                      # one re-capture, then plain replays
     assert torch.equal(after, step(x, z)) and not torch.equal(after, before)
     _ParamCache.invalidate_all()                   # what train_stage.PhaseGraphs does around its replays
-    again = pipe.run(x, z).clone()
+    again = pipe.run(x, z)
     pipe.join()
+    again = again.clone()
     assert pipe.captures == 3 and torch.equal(again, after)
 
 

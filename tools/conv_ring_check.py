@@ -46,5 +46,34 @@ for (n, i, o, h, w, with_bias) in cases:
         bad += 0 if same else 1
     bad += 0 if err < 2e-3 else 1
     print(line, flush=True)
+# the fused layer tail (everything but in_scale / residual): against conv_f16_kernel's store pass, bit for bit
+tails = [(2, 64, 64, 64, 64, dict(act=True)), (8, 64, 64, 512, 512, dict(act=True, bias=True)), (3, 128, 96, 40, 52, dict(act=True, bias=True, d=True, noise=1)),
+         (2, 256, 256, 32, 36, dict(act=False, gain=0.5, d=True, noise=2)), (4, 512, 512, 16, 16, dict(act=True, bias=True, d=True, noise=2, clamp=0.7)),
+         (2, 64, 64, 100, 132, dict(act=True, bias=True, noise=1)), (1, 32, 72, 21, 20, dict(act=True, bias=True, d=True)), (8, 128, 128, 256, 256, dict(act=True, bias=True))]
+for (n, i, o, h, w, t) in tails:
+    torch.manual_seed(n * 77 + i + o + h)
+    x = torch.randn(n, i, h, w, device=dev).half().to(memory_format=CL)
+    wt = (torch.randn(o, i, 3, 3, device=dev) / (i * 9) ** 0.5).half()
+    kw = dict(act=t.get('act'), gain=t.get('gain', 1.0), clamp=t.get('clamp', 256.0))
+    b = torch.randn(o, device=dev) if t.get('bias') else None
+    if t.get('d'):
+        kw['out_scale'] = torch.rand(n, o, device=dev) + 0.5
+    if t.get('noise') == 1:
+        kw['noise'], kw['noise_strength'] = torch.randn(h, w, device=dev), 0.3
+    if t.get('noise') == 2:
+        kw['noise'], kw['noise_strength'] = torch.randn(n, 1, h, w, device=dev), 0.3
+    y_new = run(None, lambda: kf.conv2d(x, wt, b, 1, 1, **kw))
+    line = f'tail n{n} {i:4d}->{o:4d} {h:4d}x{w:<4d} {t}:'
+    if os.path.exists(VAR):
+        _lib.use_library(VAR)
+        y_old = kf.conv2d(x, wt, b, 1, 1, **kw)
+        torch.cuda.synchronize()
+        _lib.use_library(PROD)
+        same = torch.equal(y_old, y_new)
+        line += f' bit-exact vs conv_f16_kernel: {same} ({int((y_old != y_new).sum())} of {y_new.numel()} differ, max {float((y_old.float() - y_new.float()).abs().max()):.3e})'
+        bad += 0 if same else 1
+    else:
+        line += ' (no noring variant built)'
+    print(line, flush=True)
 print('FAILED' if bad else 'ok')
 sys.exit(1 if bad else 0)

@@ -1,4 +1,6 @@
-"""Weight-gradient kernel (shg_conv2d_wgrad_f32) on the layer shapes of the 256x256 / 512x512 models, batch 8."""
+"""Weight-gradient kernels (shg_conv2d_wgrad_f32; shg_conv2d_wgrad_wino_f32 where it applies) on the layer shapes of the 256x256 / 512x512 models,
+batch 8 (16 with --batch 16: the critic's stacked pass).  TFLOP/s are direct-form (the Winograd route executes a quarter of them).
+SHG_WGRAD_DIRECT=1: the direct kernel everywhere."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +9,9 @@ from shgan_amd import _lib
 if os.environ.get('SHG_VARIANT'):
     _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import kernels as kk
-N = 8
+N = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 8
+if os.environ.get('SHG_WGRAD_DIRECT'):
+    kk.WGRAD_WINO = False
 CASES = [('3x3 s1 64ch 512^2', 64, 64, 512, 3, 1, 1), ('3x3 s1 128ch 256^2', 128, 128, 256, 3, 1, 1), ('3x3 s1 256ch 128^2', 256, 256, 128, 3, 1, 1),
          ('3x3 s1 512ch 64^2', 512, 512, 64, 3, 1, 1), ('3x3 s1 512ch 32^2', 512, 512, 32, 3, 1, 1), ('3x3 s1 512ch 16^2', 512, 512, 16, 3, 1, 1),
          ('3x3 s1 512ch 8^2', 512, 512, 8, 3, 1, 1), ('3x3 s1 512ch 4^2', 512, 512, 4, 3, 1, 1),
