@@ -308,16 +308,18 @@ int shg_bias_act_backward_f16(const void* g, const void* y, void* dx, long total
  * saved output: gt = gy*A'(y)*d, part [N][blocks][2][C] = per-workgroup pixel sums of gz*t and gz (caller sums over blocks: deterministic),
  * gnoise [N,HW] = channel sums of gz.  d fp32 [N,C] / noise fp32 [HW] (mode 1) or [N,HW] (mode 2) / bias fp32 [C], each optional. */
 /* the same backward for float32 NCHW layers (forward = shg_bias_act_f32 with scale / noise / bias): gt = gy*A'(y)*d, part [N][blocks][2][C],
- * gnoise [cslices][N,HW] (per channel slice: the caller adds them); HW % 4 == 0, C <= 512. */
+ * gnoise [cslices][N,HW] (per channel slice: the caller adds them); HW % 4 == 0, C <= 512.
+ * Both take an optional second product u (a tensor like gy) / e fp32 [N,C]: gt = A'(y) * (gy*d + u*e) -- the tail's double backward
+ * (R1 / path length, stylegan_default_loss.py:72-88,118-124): d/dgy = A'(y) (ggt d + t ggd) in one pass. */
 int shg_modtail_backward_f32_blocks(long HW);
 int shg_modtail_backward_f32_cslices(int N, int C, long HW);
-int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, float* gt, float* part, float* gnoise, int N, int C,
-                             long HW, int act, float alpha, float gain, float clamp, void* stream);
+int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, const float* u, const float* e, float* gt, float* part,
+                             float* gnoise, int N, int C, long HW, int act, float alpha, float gain, float clamp, void* stream);
 int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C, int act,
                     float alpha, float gain, float clamp, void* stream);
 int shg_modtail_backward_f16_blocks(long HW, int C);
-int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, void* gt, float* part, float* gnoise, int N, long HW, int C,
-                             int act, float alpha, float gain, float clamp, void* stream);
+int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, const void* u, const float* e, void* gt, float* part,
+                             float* gnoise, int N, long HW, int C, int act, float alpha, float gain, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -109,10 +109,10 @@ _SIGS = {
     'shg_bias_act_backward_f16': [c_fp, c_fp, c_fp, c_l, c_i, c_f, c_f, c_f, c_fp],
     'shg_modtail_backward_f32_blocks': [c_l],
     'shg_modtail_backward_f32_cslices': [c_i, c_i, c_l],
-    'shg_modtail_backward_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_fp],
+    'shg_modtail_backward_f32': [c_fp] * 9 + [c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_fp],
     'shg_modtail_f16': [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_fp],
     'shg_modtail_backward_f16_blocks': [c_l, c_i],
-    'shg_modtail_backward_f16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_fp],
+    'shg_modtail_backward_f16': [c_fp] * 9 + [c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_fp],
 }
 
 _lib = None

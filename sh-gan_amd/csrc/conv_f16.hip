@@ -920,6 +920,7 @@ __global__ __launch_bounds__(256) void bias_act_backward_f16_kernel(const _Float
 struct TailP {
     const _Float16* t; const _Float16* y_in; const _Float16* gy;
     const float* d; const float* noise; const float* bias;
+    const _Float16* u; const float* e;  // backward: optional second product, out = A'(y) (gy d + u e)
     _Float16* out;                    // forward: y; backward: gt
     float* part; float* gnoise;
     int N, HW, C, noise_mode, act, nblk;
@@ -979,9 +980,9 @@ __global__ __launch_bounds__(256) void modtail_backward_f16_kernel(const TailP p
     for (int q = 0; q < 8; ++q) s1[q] = s0[q] = 0.f;
     // (256 and the grid stride are multiples of C/8 <= 64: a thread keeps its channel group for the whole loop)
     const int c = (int)(((long)blockIdx.x * 256 + tid) % c8n) * 8;
-    float dd[8];
+    float dd[8], ee[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dd[q] = p.d ? p.d[(long)n * p.C + c + q] : 1.f;
+    for (int q = 0; q < 8; ++q) { dd[q] = p.d ? p.d[(long)n * p.C + c + q] : 1.f; ee[q] = (p.u && p.e) ? p.e[(long)n * p.C + c + q] : 1.f; }
     const long stride = (long)gridDim.x * 256;
     const int iters = (int)((total + stride - 1) / stride);                                        // uniform trip count: whole waves stay in the shuffle
     for (int it = 0; it < iters; ++it) {
@@ -992,13 +993,15 @@ __global__ __launch_bounds__(256) void modtail_backward_f16_kernel(const TailP p
             const h8 g = *(const h8*)(p.gy + off + e * 8), yv = *(const h8*)(p.y_in + off + e * 8);
             h8 tv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (p.t) tv = *(const h8*)(p.t + off + e * 8);
+            h8 uv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.u) uv = *(const h8*)(p.u + off + e * 8);
             h8 o;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float yq = (float)yv[q];
                 const float slope = (p.act && p.clamp >= 0.f && fabsf(yq) >= p.clamp) ? 0.f : (yq > 0.f || !p.act ? gp : gn);
                 const float gz = (float)g[q] * slope;
-                o[q] = (_Float16)(gz * dd[q]);
+                o[q] = p.u ? (_Float16)__builtin_fmaf((float)uv[q] * slope, ee[q], gz * dd[q]) : (_Float16)(gz * dd[q]);
                 s1[q] += gz * (float)tv[q];
                 s0[q] += gz;
                 pix_sum += gz;
@@ -1459,18 +1462,20 @@ extern "C" int shg_modtail_backward_f16_blocks(long HW, int C) {
     return (int)(blocks > 256 ? 256 : blocks);
 }
 
-// gt = gy * A'(y) * d (halves); part [N][blocks][2][C] fp32 = per-workgroup sums over pixels of gz*t and gz (NULL: skipped; t may be NULL
-// when only sum gz is wanted); gnoise [N,HW] fp32 = sum over channels of gz (NULL: skipped).  C in {8,16,...,512} with C/8 a power of two.
-extern "C" int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, void* gt, float* part, float* gnoise, int N,
-                                        long HW, int C, int act, float alpha, float gain, float clamp, void* stream) {
+// gt = gy * A'(y) * d [+ u * A'(y) * e] (halves); part [N][blocks][2][C] fp32 = per-workgroup sums over pixels of gz*t and gz (NULL: skipped; t may be
+// NULL when only sum gz is wanted); gnoise [N,HW] fp32 = sum over channels of gz (NULL: skipped); u (halves like gy) / e [N,C] fp32: the optional second
+// product of the tail's double backward.  C in {8,16,...,512} with C/8 a power of two.
+extern "C" int shg_modtail_backward_f16(const void* gy, const void* y, const void* t, const float* d, const void* u, const float* e, void* gt, float* part,
+                                        float* gnoise, int N, long HW, int C, int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(gy && y && gt && N >= 1 && HW >= 1, "modtail_backward_f16: null pointer / empty");
     SHG_CHECK_ARG(HW < 2147483647L, "modtail_backward_f16: H*W must fit 31 bits");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gt) |
-                    reinterpret_cast<uintptr_t>(d)) & 15) == 0, "modtail_backward_f16: gy, y, t, gt and d must be 16-byte aligned (vector accesses)");
+                    reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(u)) & 15) == 0, "modtail_backward_f16: gy, y, t, u, gt and d must be 16-byte aligned (vector accesses)");
     const int c8n = C / 8;
     SHG_CHECK_ARG(C >= 8 && (C % 8) == 0 && c8n <= 64 && (c8n & (c8n - 1)) == 0, "modtail_backward_f16: C/8 must be a power of two <= 64");
     f16::TailP p{};
     p.gy = (const _Float16*)gy; p.y_in = (const _Float16*)y; p.t = (const _Float16*)t; p.d = d; p.out = (_Float16*)gt; p.part = part;
+    p.u = (const _Float16*)u; p.e = e;
     p.gnoise = gnoise; p.N = N; p.HW = (int)HW; p.C = C; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.nblk = shg_modtail_backward_f16_blocks(HW, C);
     hipLaunchKernelGGL(f16::modtail_backward_f16_kernel, dim3(p.nblk, N), dim3(256), 0, (hipStream_t)stream, p);

@@ -452,9 +452,9 @@ extern "C" int shg_planes_to_image_f32(const float* mid, const float* bias, floa
 //   registers, the pixel sums are reduced per wave (DPP) and per workgroup (LDS) into part[n][block][2][C] -- summed by the caller in
 //   a fixed order (deterministic, no atomics).  HW % 4 == 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void modtail_backward_f32_kernel(const float* gy, const float* y, const float* t, const float* d, float* gt,
-                                                                    float* part, float* gnoise, int C, int HW, int nblk, int act, float alpha,
-                                                                    float gain, float clamp) {
+__global__ __launch_bounds__(256) void modtail_backward_f32_kernel(const float* gy, const float* y, const float* t, const float* d, const float* u,
+                                                                    const float* e, float* gt, float* part, float* gnoise, int C, int HW, int nblk,
+                                                                    int act, float alpha, float gain, float clamp) {
     __shared__ float red[2][4][512];                                // per-wave sums of every channel: one barrier at the end (C <= 512)
     const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float gp = gain, gn = act ? alpha * gain : gain;
@@ -471,17 +471,21 @@ __global__ __launch_bounds__(256) void modtail_backward_f32_kernel(const float* 
             float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t) tv = *(const float4*)(t + off);
             const float dd = d ? d[(long)n * C + c] : 1.f;
-            const float gq[4] = {g.x, g.y, g.z, g.w}, yq[4] = {yv.x, yv.y, yv.z, yv.w}, tq[4] = {tv.x, tv.y, tv.z, tv.w};
-            float gz[4];
+            float4 uv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u) uv = *(const float4*)(u + off);
+            const float ee = (u && e) ? e[(long)n * C + c] : (u ? 1.f : 0.f);
+            const float gq[4] = {g.x, g.y, g.z, g.w}, yq[4] = {yv.x, yv.y, yv.z, yv.w}, tq[4] = {tv.x, tv.y, tv.z, tv.w}, uq[4] = {uv.x, uv.y, uv.z, uv.w};
+            float gz[4], o4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float slope = (act && clamp >= 0.f && fabsf(yq[q]) >= clamp) ? 0.f : ((yq[q] > 0.f || !act) ? gp : gn);
                 gz[q] = gq[q] * slope;
                 s1 += gz[q] * tq[q];
                 s0 += gz[q];
+                o4[q] = u ? __builtin_fmaf(uq[q] * slope, ee, gz[q] * dd) : gz[q] * dd;
             }
             nsum.x += gz[0]; nsum.y += gz[1]; nsum.z += gz[2]; nsum.w += gz[3];
-            *(float4*)(gt + off) = make_float4(gz[0] * dd, gz[1] * dd, gz[2] * dd, gz[3] * dd);
+            *(float4*)(gt + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
         if (part) {                                                 // (uniform branch: whole waves take part in the shuffles)
 #pragma unroll
@@ -509,16 +513,17 @@ extern "C" int shg_modtail_backward_f32_cslices(int N, int C, long HW) {
     return (int)(z < 1 ? 1 : z);
 }
 
-// gt = gy * A'(y) * d; part [N][blocks][2][C] = per-workgroup pixel sums of gz*t and gz (NULL: skipped; t may be NULL); gnoise [cslices][N,HW] = channel
-// sums of gz per channel slice (NULL: skipped; the caller adds the slices).  NCHW float32, HW % 4 == 0, 16-byte aligned tensors.
-extern "C" int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, float* gt, float* part, float* gnoise,
-                                        int N, int C, long HW, int act, float alpha, float gain, float clamp, void* stream) {
+// gt = gy * A'(y) * d [+ u * A'(y) * e]; part [N][blocks][2][C] = per-workgroup pixel sums of gz*t and gz (NULL: skipped; t may be NULL); gnoise
+// [cslices][N,HW] = channel sums of gz per channel slice (NULL: skipped; the caller adds the slices).  u [N,C,HW] / e [N,C] (both optional): the second
+// product of the tail's double backward, d/dgy = A'(y) (ggt d + t ggd).  NCHW float32, HW % 4 == 0, 16-byte aligned tensors.
+extern "C" int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, const float* u, const float* e, float* gt,
+                                        float* part, float* gnoise, int N, int C, long HW, int act, float alpha, float gain, float clamp, void* stream) {
     SHG_CHECK_ARG(gy && y && gt && N >= 1 && C >= 1 && C <= 512 && HW >= 4 && (HW % 4) == 0, "modtail_backward_f32: bad arguments (C <= 512, HW a multiple of 4)");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gt) |
-                    reinterpret_cast<uintptr_t>(gnoise)) & 15) == 0, "modtail_backward_f32: tensors must be 16-byte aligned");
+                    reinterpret_cast<uintptr_t>(gnoise) | reinterpret_cast<uintptr_t>(u)) & 15) == 0, "modtail_backward_f32: tensors must be 16-byte aligned");
     const int nblk = shg_modtail_backward_f32_blocks(HW);
     hipLaunchKernelGGL(modtail_backward_f32_kernel, dim3(nblk, N, shg_modtail_backward_f32_cslices(N, C, HW)), dim3(256), 0, (hipStream_t)stream, gy, y,
-                       t, d, gt, part, gnoise, C, (int)HW, nblk, act, alpha, gain, clamp);
+                       t, d, u, e, gt, part, gnoise, C, (int)HW, nblk, act, alpha, gain, clamp);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

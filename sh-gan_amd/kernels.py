@@ -291,13 +291,14 @@ def bias_act_backward(g, y, act=True, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp
     return dx
 
 
-def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, act=True, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0):
+def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, act=True, gain=1.0, alpha=0.2, act_gain=SQRT2, clamp=256.0, u=None, e=None):
     """First-order backward of y = A(t * d[n,c] + noise + bias[c]) (float32 NCHW) in one pass: -> (gt, s1 [N,C] = sum_hw gz*t | None,
-    s0 [N,C] = sum_hw gz | None, gnoise [N,1,H,W] | None) with gz = gy * A'(y)."""
+    s0 [N,C] = sum_hw gz | None, gnoise [N,1,H,W] | None) with gz = gy * A'(y); with ``u`` (like gy) / ``e`` [N,C]: gt = A'(y) * (gy * d + u * e)."""
     L = _Launch()
-    gy, y, t = L.req(gy, 'gy'), L.req(y, 'y'), L.req(t, 't')
+    gy, y, t, u = L.req(gy, 'gy'), L.req(y, 'y'), L.req(t, 't'), L.req(u, 'u')
     n, c, h, w = y.shape
     d = L.req(None if d is None else d.reshape(n, c), 'd')
+    e = L.req(None if e is None else e.reshape(n, c), 'e')
     lib = _lib.get_lib()
     nblk = lib.shg_modtail_backward_f32_blocks(h * w)
     part = torch.empty((n, nblk, 2, c), device=L.dev, dtype=torch.float32) if want_sums else None
@@ -305,9 +306,9 @@ def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, ac
     gnoise = torch.empty((zs, n, 1, h, w), device=L.dev, dtype=torch.float32) if want_noise else None
     a, al, g, cl = _act_args(act, gain, alpha, act_gain, clamp)
     gt = torch.empty_like(y)
-    with _timed(L, 'modtail_bwd', 4.0 * (3 + (t is not None)) * y.numel()):
-        check(lib.shg_modtail_backward_f32(_ptr(gy), _ptr(y), _ptr(t), _ptr(d), _ptr(gt), _ptr(part), _ptr(gnoise), n, c, h * w, a, al, g, cl,
-                                           L.stream()), 'modtail_backward_f32')
+    with _timed(L, 'modtail_bwd', 4.0 * (3 + (t is not None) + (u is not None)) * y.numel()):
+        check(lib.shg_modtail_backward_f32(_ptr(gy), _ptr(y), _ptr(t), _ptr(d), _ptr(u), _ptr(e), _ptr(gt), _ptr(part), _ptr(gnoise), n, c, h * w, a, al, g,
+                                           cl, L.stream()), 'modtail_backward_f32')
     s1 = s0 = None
     if want_sums:
         sums = part.sum(1)                    # fixed order over the workgroup partials: deterministic

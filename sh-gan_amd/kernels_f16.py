@@ -301,23 +301,27 @@ def modtail(t, d=None, noise=None, bias=None, act=False, gain=1.0, alpha=0.2, ac
     return y
 
 
-def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
+def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0,
+                     u=None, e=None):
     """-> (gt [N,C,H,W] halves, s1 [N,C] fp32 = sum_hw gz*t | None, s0 [N,C] fp32 = sum_hw gz | None, gnoise [N,1,H,W] fp32 | None) with
-    gz = gy * A'(y): the whole first-order backward of ``modtail`` in one pass over gy / y / t."""
+    gz = gy * A'(y): the whole first-order backward of ``modtail`` in one pass over gy / y / t.  With ``u`` (halves like gy) / ``e`` [N,C]:
+    gt = A'(y) * (gy * d + u * e) (the tail's double backward)."""
     L = kernels._Launch()
     gy, y = _h(L, gy, 'gy'), _h(L, y, 'y')
-    t = _h(L, t, 't')
+    t, u = _h(L, t, 't'), _h(L, u, 'u')
     n, c, h, w = y.shape
     d32 = None if d is None else L.req(d.detach().to(torch.float32).reshape(n, c), 'd')
+    e32 = None if e is None else L.req(e.detach().to(torch.float32).reshape(n, c), 'e')
     lib = _lib.get_lib()
     nblk = lib.shg_modtail_backward_f16_blocks(h * w, c)
     part = torch.empty((n, nblk, 2, c), device=L.dev, dtype=torch.float32) if want_sums else None
     gnoise = torch.empty((n, 1, h, w), device=L.dev, dtype=torch.float32) if want_noise else None
     a, al, g, cl = kernels._act_args(act, gain, alpha, act_gain, clamp)
     gt = _new_cl(L, n, c, h, w)
-    with kernels._timed(L, 'modtail_bwd_f16', 2.0 * (3 + (t is not None)) * y.numel()):
-        check(lib.shg_modtail_backward_f16(kernels._ptr(gy), kernels._ptr(y), kernels._ptr(t), kernels._ptr(d32), kernels._ptr(gt), kernels._ptr(part),
-                                           kernels._ptr(gnoise), n, h * w, c, a, al, g, cl, L.stream()), 'modtail_backward_f16')
+    with kernels._timed(L, 'modtail_bwd_f16', 2.0 * (3 + (t is not None) + (u is not None)) * y.numel()):
+        check(lib.shg_modtail_backward_f16(kernels._ptr(gy), kernels._ptr(y), kernels._ptr(t), kernels._ptr(d32), kernels._ptr(u), kernels._ptr(e32),
+                                           kernels._ptr(gt), kernels._ptr(part), kernels._ptr(gnoise), n, h * w, c, a, al, g, cl, L.stream()),
+              'modtail_backward_f16')
     s1 = s0 = None
     if want_sums:
         sums = part.sum(1)                    # fixed order over the workgroup partials: deterministic

@@ -204,6 +204,7 @@ class _BiasActFn(torch.autograd.Function):
                 dx, _, s0, _ = kernels.modtail_backward(g.detach().contiguous(), y, None, None, want_sums=True, want_noise=False, act=act, gain=gain,
                                                         alpha=alpha, act_gain=act_gain, clamp=clamp)
             return dx, s0.sum(0).to(ctx.bias_dtype), None, None, None, None, None
+        # (create_graph -- R1: the plain slope kernel + a channel sum; the fused sums kernel as a node measured 2 ms slower per Dreg pass)
         dx = _BiasActBwdFn.apply(g, y, (act, gain, alpha, act_gain, clamp))
         db = None
         if has_bias and ctx.needs_input_grad[1]:
@@ -265,6 +266,16 @@ class _ModTailFn(torch.autograd.Function):
         act, gain, alpha, act_gain, clamp = ctx.cfg
         need_t, need_d, need_n, need_b = ctx.needs_input_grad[:4]
         n, c = y.shape[0], y.shape[1]
+        if torch.is_grad_enabled() and CLOSED_TAIL_BACKWARD:
+            # create_graph (R1 / path length): every gradient of the tail from the fused kernel, as ONE differentiable node.  (needs_input_grad
+            # says which inputs CAN receive a gradient, not which ones this pass wants: the path-length pass asks for the latents only, and
+            # the noise / bias sums it never uses must not cost tensor passes either.)
+            gt, gd, s0, gnz = _ModTailBwdFn.apply(gy, y, t if d is not None else None, d, bool(noise is not None and need_n), ctx.cfg)
+            gb = s0.sum(0).to(bias.dtype) if (bias is not None and need_b) else None
+            gn = None
+            if noise is not None and need_n:
+                gn = (gnz.sum(0) if noise.numel() != gnz.numel() else gnz).reshape(noise.shape).to(noise.dtype)
+            return (gt if need_t else None), (gd if (d is not None and need_d) else None), gn, gb, None
         if torch.is_grad_enabled():
             # create_graph: the same quantities from differentiable pieces (gz is linear in gy, piecewise constant in y)
             gz = _BiasActBwdFn.apply(gy, y, ctx.cfg)
@@ -294,6 +305,104 @@ class _ModTailFn(torch.autograd.Function):
         if gnz is not None:
             gn = (gnz.sum(0) if noise.numel() != gnz.numel() else gnz).reshape(noise.shape).to(noise.dtype)
         return (gt if need_t else None), gd, gn, gb, None
+
+
+CLOSED_TAIL_BACKWARD = True      # (A/B switch: False = the tensor-operator composition under create_graph)
+
+
+def _tail_backward_kernel(gy, y, t, d, want_sums, cfg, u=None, e=None):
+    """(A'(y) * (gy * d [+ u * e]), sum_hw gy * A'(y) * t) on the fused first-order kernel of either layout."""
+    act, gain, alpha, act_gain, clamp = cfg
+    if y.dtype == torch.float16:
+        gt, s1, _, _ = kernels_f16.modtail_backward(gy.detach().to(torch.float16), y, None if t is None else t.detach().to(torch.float16), d,
+                                                    want_sums=want_sums, want_noise=False, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp,
+                                                    u=None if u is None else u.detach().to(torch.float16), e=e)
+    else:
+        gt, s1, _, _ = kernels.modtail_backward(gy.detach().contiguous(), y, None if t is None else t.detach().contiguous(), d, want_sums=want_sums,
+                                                want_noise=False, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp,
+                                                u=None if u is None else u.detach().contiguous(), e=e)
+    return gt, s1
+
+
+class _ModTailBwdFn(torch.autograd.Function):
+    """(gt, gd, s0, gnoise) = (gz * d[n,c], sum_hw gz * t, sum_hw gz, sum_c gz) with gz = gy * A'(y): the first-order backward of the
+    modulation tail as a node of its own, for ``create_graph`` passes (d / t may be None: the plain bias + activation tail).  Scaling by a
+    per-(n, c) factor and the per-(n, c) dot product are each other's derivatives, so the node's own backward is the same kernel again
+    (A' is piecewise constant: y carries no gradient):
+        d/dgy = A'(y) * (ggt * d + t * ggd [+ ggs0 + ggn])      d/dt = gz * ggd      d/dd = sum_hw gz * ggt
+    -- two passes of the fused kernel (its optional second product carries the sum) instead of ~10 broadcasting tensor operators per layer
+    (stylegan_default_loss.py:72-88: the path-length regulariser differentiates every modulated layer of the synthesis network twice).
+    Gradients arriving through the two sums (nothing in the shipped losses sends any) are added with tensor operators."""
+    @staticmethod
+    def forward(ctx, gy, y, t, d, want_noise, cfg):
+        act, gain, alpha, act_gain, clamp = cfg
+        kw = dict(want_sums=True, want_noise=want_noise, act=act, gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
+        d_ = None if d is None else d.detach()
+        if y.dtype == torch.float16:
+            gt, s1, s0, gnz = kernels_f16.modtail_backward(gy.detach().to(torch.float16), y, None if t is None else t.detach(), d_, **kw)
+        else:
+            gt, s1, s0, gnz = kernels.modtail_backward(gy.detach().contiguous(), y, None if t is None else t.detach(), d_, **kw)
+        ctx.save_for_backward(gy, y, t, d)
+        ctx.cfg = cfg
+        gd = s1.reshape(d.shape).to(d.dtype) if (d is not None and t is not None) else None
+        return gt, gd, s0, gnz
+
+    @staticmethod
+    def backward(ctx, ggt, ggd, ggs0, ggn):
+        gy, y, t, d = ctx.saved_tensors
+        cfg = ctx.cfg
+        n, c = y.shape[0], y.shape[1]
+        need_gy, _, need_t, need_d = ctx.needs_input_grad[:4]
+        need_t, need_d = need_t and t is not None, need_d and d is not None
+        if ggd is not None and t is None:
+            ggd = None
+        extra = None                              # gradients through the plain sums: broadcast back (tensor operators; differentiable)
+        if ggs0 is not None:
+            extra = ggs0.reshape(n, c, 1, 1).to(y.dtype).expand_as(y)
+        if ggn is not None:
+            e2 = ggn.reshape(n, 1, y.shape[2], y.shape[3]).to(y.dtype).expand_as(y)
+            extra = e2 if extra is None else extra + e2
+        if torch.is_grad_enabled():            # a third derivative: tensor operators (never taken by the shipped losses)
+            gz = _BiasActBwdFn.apply(gy, y, cfg)
+            g_gy = g_t = g_d = None
+            ggd4 = None if ggd is None else ggd.reshape(n, c, 1, 1)
+            if need_gy:
+                v = 0 if extra is None else extra
+                if ggt is not None:
+                    v = v + (ggt if d is None else ggt * d.to(ggt.dtype).reshape(n, c, 1, 1))
+                if ggd is not None:
+                    v = v + t * ggd4.to(t.dtype)
+                g_gy = _BiasActBwdFn.apply(v, y, cfg) if torch.is_tensor(v) else None
+            if need_t and ggd is not None:
+                g_t = gz * ggd4.to(gz.dtype)
+            if need_d and ggt is not None:
+                g_d = (gz.float() * ggt.float()).sum([2, 3]).reshape(d.shape).to(d.dtype)
+            return g_gy, None, g_t, g_d, None, None
+        g_gy = g_t = g_d = None
+        ggd_f = None if ggd is None else ggd.detach().reshape(n, c).float().contiguous()
+        if (need_t and ggd is not None) or (need_d and ggt is not None):
+            # one pass: gz * ggd and sum_hw gz * ggt (a missing factor: the pass still gives the other quantity)
+            want = need_d and ggt is not None
+            gz_s, s1 = _tail_backward_kernel(gy, y, ggt if want else None, ggd_f, want, cfg)
+            if need_t and ggd is not None:
+                g_t = gz_s
+            if want:
+                g_d = s1.reshape(d.shape).to(d.dtype)
+        if need_gy:
+            d_f = None if d is None else d.detach().reshape(n, c).float().contiguous()
+            a = None
+            if ggt is not None and ggd is not None:            # A'(y) (ggt d + t ggd) in one pass
+                a, _ = _tail_backward_kernel(ggt, y, None, d_f, False, cfg, u=t, e=ggd_f)
+            elif ggt is not None:
+                a, _ = _tail_backward_kernel(ggt, y, None, d_f, False, cfg)
+            elif ggd is not None:
+                a, _ = _tail_backward_kernel(t, y, None, ggd_f, False, cfg)
+            if extra is not None:
+                ex = extra.contiguous(memory_format=CL) if y.dtype == torch.float16 else extra.contiguous()
+                b = _tail_backward_kernel(ex, y, None, None, False, cfg)[0]
+                a = b if a is None else a.add_(b)
+            g_gy = a
+        return g_gy, None, g_t, g_d, None, None
 
 
 def modconv_tail(t, d=None, noise=None, bias=None, act=False, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):

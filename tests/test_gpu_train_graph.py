@@ -10,6 +10,11 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
 def small_networks(seed):
     import shgan_amd  # noqa: F401
     from shgan_amd import configs
@@ -553,3 +558,49 @@ def test_encoder_feature_gradients_joined_in_the_down_layer():
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize('half', [False, True])
+@pytest.mark.parametrize('with_d', [True, False])
+def test_closed_tail_backward_node_vs_tensor_operators(half, with_d):
+    """``grad_ops._ModTailBwdFn`` (the modulation tail's first-order backward as one differentiable node on the fused kernel; its own
+    backward = the same kernel with the optional second product) against the tensor-operator composition it replaces under
+    ``create_graph``: a path-length-shaped double backward of ``modconv_tail`` -- first derivative with respect to (t, d), then the gradient
+    of a random functional of that derivative with respect to t, d, bias and the noise.  A self-comparison of two routes of this repo; the
+    reference-pinned carriers are tests/test_gpu_config5.py (Greg / Dreg of the full-width step against the reference's autograd) and
+    tests/test_gpu_backward.py::test_stylegan2_loss_phases_match_hand_written_autograd, both of which run with the closed node on."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    rs = np.random.RandomState(5 + half + 2 * with_d)
+    n, c, h, w = 3, 32, 16, 24
+    dt = torch.float16 if half else torch.float32
+
+    def leaf(a, dtype=torch.float32):
+        t_ = torch.from_numpy(a.astype(np.float32)).to(DEV).to(dtype)
+        if dtype == torch.float16:
+            t_ = t_.contiguous(memory_format=torch.channels_last)
+        return t_.requires_grad_(True)
+    t0, d0 = rs.standard_normal((n, c, h, w)), rs.uniform(0.5, 1.5, (n, c))
+    b0, z0 = rs.standard_normal(c) * 0.1, rs.standard_normal((h, w)) * 0.1
+    r1, r2 = rs.standard_normal((n, c, h, w)), rs.standard_normal((n, c))
+    gy0 = rs.standard_normal((n, c, h, w))
+    res = {}
+    for closed in (True, False):
+        grad_ops.CLOSED_TAIL_BACKWARD = closed
+        try:
+            t, d, b, z = leaf(t0, dt), (leaf(d0) if with_d else None), leaf(b0), leaf(z0)
+            with torch.enable_grad():
+                y = grad_ops.modconv_tail(t, d=d, noise=z, bias=b, act=True, gain=1.0)
+                gy = torch.from_numpy(gy0.astype(np.float32)).to(DEV).to(dt)
+                ins = [t] + ([d] if with_d else [])
+                g1 = torch.autograd.grad([(y * gy).sum()], ins, create_graph=True)
+                f = (g1[0].float() * torch.from_numpy(r1.astype(np.float32)).to(DEV)).sum()
+                if with_d:
+                    f = f + (g1[1] * torch.from_numpy(r2.astype(np.float32)).to(DEV)).sum()
+                g2 = torch.autograd.grad([f], [t] + ([d] if with_d else []), allow_unused=True)
+            res[closed] = [g.float() for g in g1] + [torch.zeros(1, device=DEV) if g is None else g.float() for g in g2]
+        finally:
+            grad_ops.CLOSED_TAIL_BACKWARD = True
+    tol = 4e-3 if half else 2e-5
+    for a, bb in zip(res[True], res[False]):
+        assert rel_err(a.detach().cpu().numpy(), bb.detach().cpu().numpy()) < tol or float(bb.abs().max()) == 0.0

@@ -153,9 +153,9 @@ def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.shg_bias_act_f16(P, None, P, 64, 12, 1, 0.2, 1.0, 256.0, None) == -1
     assert lib.shg_bias_act_f16(P, ctypes.c_void_p(8), P, 64, 16, 1, 0.2, 1.0, 256.0, None) == -1 and b'aligned' in lib.shg_last_error()   # float4 operand loads
     assert lib.shg_modtail_f16(P, ctypes.c_void_p(24), None, 0, None, P, 1, 64, 16, 1, 0.2, 1.0, 256.0, None) == -1 and b'aligned' in lib.shg_last_error()
-    assert lib.shg_modtail_backward_f16(P, P, None, None, P, None, None, 1, 64, 24, 1, 0.2, 1.0, 256.0, None) == -1 and b'power of two' in lib.shg_last_error()
+    assert lib.shg_modtail_backward_f16(P, P, None, None, None, None, P, None, None, 1, 64, 24, 1, 0.2, 1.0, 256.0, None) == -1 and b'power of two' in lib.shg_last_error()
     assert lib.shg_modtail_backward_f16_blocks(64 * 64, 64) == 128 and lib.shg_modtail_backward_f16_blocks(512 * 512, 64) == 256
-    assert lib.shg_modtail_backward_f32(P, P, None, None, P, None, None, 1, 64, 30, 1, 0.2, 1.0, 256.0, None) == -1
+    assert lib.shg_modtail_backward_f32(P, P, None, None, None, None, P, None, None, 1, 64, 30, 1, 0.2, 1.0, 256.0, None) == -1
     assert lib.shg_modtail_backward_f32_cslices(8, 512, 16) == 64 and lib.shg_modtail_backward_f32_cslices(8, 64, 512 * 512) == 1
     # and the Python wrappers refuse CPU tensors (no fallback)
     from shgan_amd import kernels_f16
