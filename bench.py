@@ -516,8 +516,30 @@ def worker(local_rank, a, spawned_world=None, port=None):
                     'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)}
 
         conv = {k: v for k, v in ((n_, cls_conv(n_)) for n_ in sorted(tsum) if n_.startswith('conv_')) if v}
-        hbm = {k: v for k, v in ((n, cls_hbm(n)) for n in ('upfirdn2d', 'fir_up_planar', 'torgb', 'fromrgb', 'shu', 'composite_u8'))
+        hbm = {k: v for k, v in ((n, cls_hbm(n)) for n in ('upfirdn2d', 'fir_up_planar', 'torgb', 'fromrgb', 'composite_u8'))
                if v}
+
+        def shu_block():
+            # the Spectral Hint Unit's three launches, each against the roof that bounds it: the spectral stage (1x1 conv + ReLU + band
+            # filter: 64-wide GEMMs per spectral pixel) is matrix work on the fp32 MFMA; the two transform stages are short dependent
+            # chains per 64x64 plane (row DFT, column DFT as MFMA passes with a barrier between) on a few MB -- latency-bound: their time
+            # is the figure, the byte rate is listed only to show they are nowhere near HBM
+            st = {}
+            for name, kind in (('shu_rfft2', 'latency'), ('shu_spectral', 'mfma'), ('shu_irfft2', 'latency')):
+                d = tsum.get(name)
+                if not d or d['ms'] <= 0:
+                    continue
+                e = {'us_per_step': round(d['ms'] / psteps * 1e3, 1), 'launches_per_step': d['calls'] // psteps, 'bound': kind}
+                if kind == 'mfma':
+                    tf = d['work'] / (d['ms'] * 1e-3) / 1e12
+                    e.update(executed_tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / PEAK_FP32_MFMA_TFLOPS, 4))
+                else:
+                    e['algorithmic_GBps'] = round(d['work'] / (d['ms'] * 1e-3) / 1e9, 1)
+                st[name] = e
+            if not st:
+                return None
+            return {'ms_per_step': round(sum(v['us_per_step'] for v in st.values()) / 1e3, 4), 'stages': st}
+        shu = shu_block()
         conv_ms = sum(tsum[k]['ms'] for k in tsum if k.startswith('conv_'))
         conv_exec = sum(tsum[k]['executed'] for k in tsum if k.startswith('conv_'))
         conv_alg = sum(tsum[k]['work'] for k in tsum if k.startswith('conv_'))
@@ -569,6 +591,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
                       f'{psteps} steps (HIP events on the launch stream)',
             'roofline': roof,
             'hbm': {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'classes': hbm},
+            'shu': shu,
             'second_config': second,
             'fp16_blocks_eval': fp16_eval,
             'train_step': train,

@@ -874,7 +874,7 @@ def shu_rfft2_shift(x):
     L.view(x, 'x')
     n, c = x.shape[:2]
     t = L.new((n, 2 * c, 64, 33))
-    with _timed(L, 'shu', 4.0 * (x.numel() + t.numel())):
+    with _timed(L, 'shu_rfft2', 4.0 * (x.numel() + t.numel())):
         check(_lib.get_lib().shg_shu_rfft2_shift_f32(_ptr(x), x.stride(0), _ptr(t), n, c, L.stream()), 'shu_rfft2_shift')
     return t
 
@@ -898,7 +898,7 @@ def shu_split_adjoint(grads, gauss, n, c):
         g_arr[l] = g.data_ptr()
         s_arr[l] = g.stride(0)
     out = L.new((n, 2 * c, 64, 33))
-    with _timed(L, 'shu', 4.0 * out.numel()):
+    with _timed(L, 'shu_split_adjoint', 4.0 * out.numel()):
         check(_lib.get_lib().shg_shu_split_adjoint_f32(g_arr, s_arr, t_arr, _ptr(out), n, c, L.stream()), 'shu_split_adjoint')
     return out
 
@@ -952,7 +952,8 @@ def shu_spectral(t, w0p, b0, w1p, cw):
     if tuple(w0p.shape) != (32, 2, 64) or tuple(w1p.shape) != (bands * 32, 2, 64) or cw.numel() != bands * h * w:
         raise _lib.ShgError('shu_spectral: packed weight / cw shapes do not match')
     out = L.new((n, c2, h, w))
-    with _timed(L, 'shu', 4.0 * (t.numel() + out.numel())):
+    # matrix work: conv0 (c2 x c2) + the band filter (bands c2 x c2) per spectral pixel, fp32 MFMA
+    with _timed(L, 'shu_spectral', 2.0 * n * h * w * c2 * c2 * (1 + bands)):
         check(_lib.get_lib().shg_shu_spectral_f32(_ptr(t), _ptr(w0p), _ptr(b0), _ptr(w1p), _ptr(cw), _ptr(out), n, c2, h * w, bands,
                                                   L.stream()), 'shu_spectral')
     return out
@@ -986,7 +987,7 @@ def shu_split_irfft2(y, cw, gauss, outs, accumulate):
         o_arr[l] = o.data_ptr()
         s_arr[l] = o.stride(0)
         nbytes += 4.0 * o.numel() * (2 if accumulate else 1)
-    with _timed(L, 'shu', nbytes):
+    with _timed(L, 'shu_irfft2', nbytes):
         check(_lib.get_lib().shg_shu_split_irfft2_f32(_ptr(y), _ptr(cw), g_arr, o_arr, s_arr, n, c, bands, int(bool(accumulate)),
                                                       L.stream()), 'shu_split_irfft2')
     return outs
