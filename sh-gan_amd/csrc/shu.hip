@@ -126,49 +126,37 @@ struct ShuSpectralParams {
     int P, B;       // positions per plane (64*33), bands
 };
 
-// Tile = 32 positions x 64 channels; the four waves are (output-channel half mo) x (K half kh): each multiplies half of the 64-deep sums of
-// both stages (16 + 6 x 16 MFMAs) and the kh = 1 wave hands its partial tile to its partner through LDS.  (A 64-position tile with one wave per
-// 32 x 32 output block = 528 workgroups of 224 MFMAs per wave: 2 x 256 + 16 -- the 16 stragglers cost a whole extra round, 30 us for 14 us of
-// matrix work; 1 056 workgroups of 112 MFMAs per wave spread to within a fifth.)
 __global__ __launch_bounds__(256) void shu_spectral_kernel(const ShuSpectralParams p) {
-    __shared__ __attribute__((aligned(16))) float Tl[64][32];       // [channel][position]
-    __shared__ __attribute__((aligned(16))) float tl[64][32];
-    __shared__ float red[2][16][64];                                // partial tiles of the kh = 1 waves: [mo][register][lane]
+    __shared__ __attribute__((aligned(16))) float Tl[64][64];       // [channel][position]
+    __shared__ __attribute__((aligned(16))) float tl[64][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int mo = wave >> 1, kh = wave & 1;
-    const int n = blockIdx.y, p0 = blockIdx.x * 32;
+    const int mo = wave >> 1, nt = wave & 1;
+    const int n = blockIdx.y, p0 = blockIdx.x * 64;
     const float* Tn = p.T + (long)n * 64 * p.P + p0;
+    // T tile: 64 channels x 64 positions, rows of 256 bytes
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {                                   // T tile: 64 channels x 32 positions, rows of 128 bytes
-        const int e = q * 256 + tid, ch = e >> 3, c4 = e & 7;
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * 256 + tid, ch = e >> 4, c4 = e & 15;
         *reinterpret_cast<float4*>(&Tl[ch][4 * c4]) = *reinterpret_cast<const float4*>(Tn + (long)ch * p.P + 4 * c4);
     }
     float cwv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cwv[k] = k < p.B ? p.cw[(long)k * p.P + p0 + l31] : 0.f;
+    for (int k = 0; k < 8; ++k) cwv[k] = k < p.B ? p.cw[(long)k * p.P + p0 + nt * 32 + l31] : 0.f;
     __syncthreads();
     shu_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {   // t = relu(W0 T + b0): this wave's half of K
+    {   // t = relu(W0 T + b0)
         const float* ap = p.w0p + mo * 64 + lane;
 #pragma unroll 8
-        for (int ks = kh * 16; ks < kh * 16 + 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 128], Tl[2 * ks + half][l31], acc, 0, 0, 0);
-        if (kh) {
+        for (int ks = 0; ks < 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 128], Tl[2 * ks + half][nt * 32 + l31], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[mo][r][lane] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            tl[row][nt * 32 + l31] = fmaxf(acc[r] + p.b0[row], 0.f);
+            acc[r] = 0.f;
         }
-        __syncthreads();
-        if (!kh) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                tl[row][l31] = fmaxf(acc[r] + red[mo][r][lane] + p.b0[row], 0.f);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
     __syncthreads();
     {   // S = [W1_0 | W1_1 | ...] (cw (.) t)
@@ -176,23 +164,17 @@ __global__ __launch_bounds__(256) void shu_spectral_kernel(const ShuSpectralPara
         for (int k = 0; k < p.B; ++k) {
             const float cwk = cwv[0];
 #pragma unroll 8
-            for (int ks = kh * 16; ks < kh * 16 + 16; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(k * 32 + ks) * 128], cwk * tl[2 * ks + half][l31], acc, 0, 0, 0);
+            for (int ks = 0; ks < 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(k * 32 + ks) * 128], cwk * tl[2 * ks + half][nt * 32 + l31], acc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 7; ++q) cwv[q] = cwv[q + 1];     // (rotate: keeps the band index static)
         }
     }
-    if (kh) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[mo][r][lane] = acc[r];
-    }
-    __syncthreads();
-    if (kh) return;
-    float* Sn = p.S + (long)n * 64 * p.P + p0 + l31;
+    float* Sn = p.S + (long)n * 64 * p.P + p0 + nt * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        Sn[(long)row * p.P] = acc[r] + red[mo][r][lane];
+        Sn[(long)row * p.P] = acc[r];
     }
 }
 
@@ -205,7 +187,7 @@ extern "C" int shg_shu_spectral_f32(const float* T, const float* w0p, const floa
                   "shu_spectral: built for 64 spectral channels, P %% 64 == 0, at most 8 bands");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(S)) & 15) == 0, "shu_spectral: T / S must be 16-byte aligned");
     ShuSpectralParams p{T, w0p, b0, w1p, cw, S, P, bands};
-    hipLaunchKernelGGL(shu_spectral_kernel, dim3(P / 32, N), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(shu_spectral_kernel, dim3(P / 64, N), dim3(256), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
