@@ -77,20 +77,36 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 sr
 
 struct Coord { int n, ty, tx, ot; };
 
+struct RingDiv { unsigned n_ot, tiles_x, tiles_y, m_ot, m_tx, m_ty; };    // divisors of the tile decode and floor(2^32 / divisor)
+
+// n / d for wave-uniform values with a precomputed m = floor((2^32 - 1) / d): the estimate is at most one short (scalar unit: ~8 instructions
+// instead of the ~40 of a runtime division -- the decode of the next tile stood between two steps' multiplies: tools/ring_trace.py 'issue')
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned m, unsigned& rem) {
+    unsigned q = __umulhi(n, m), r = n - q * d;
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
 template <int NT>
-__global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const int ntiles, const int n_ot) {
+__global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const int ntiles, const RingDiv dv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int nchunks = p.I >> 5, c16n = p.I >> 4, npix = p.PH * p.PW;
+    const int n_ot = (int)dv.n_ot;
+    const int PW = NT == 9 ? TW + 2 : p.PW;                      // (the 3x3 patch is 18 x 34: a constant divisor for the piece -> (row, column) map)
+    const int nchunks = p.I >> 5, c16n = p.I >> 4, npix = p.PH * PW;
     const bool resident = n_ot == 1 && nchunks <= 2;            // weight stage of step s = chunk's own slab: loaded by the first two steps only
 
     auto decode = [&](int tile) __attribute__((always_inline)) -> Coord {
         Coord c;
-        c.ot = tile % n_ot; tile /= n_ot;
-        c.tx = tile % p.tiles_x; tile /= p.tiles_x;
-        c.ty = tile % p.tiles_y; c.n = tile / p.tiles_y;
+        unsigned r, t = fastdiv((unsigned)tile, dv.n_ot, dv.m_ot, r);
+        c.ot = (int)r;
+        t = fastdiv(t, dv.tiles_x, dv.m_tx, r);
+        c.tx = (int)r;
+        c.n = (int)fastdiv(t, dv.tiles_y, dv.m_ty, r);
+        c.ty = (int)r;
         return c;
     };
 
@@ -103,9 +119,11 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         const int iy0 = c.ty * TH + p.org_y, ix0 = c.tx * TW + p.org_x;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {       // (recomputed per tile: five cached (row, column, channel) triples cost 15 registers for the whole kernel)
-            const int pp = ((wave & 3) * 5 + i) * 32 + (lane >> 1), py = pp / p.PW, px = pp - py * p.PW;
+            const int pp = ((wave & 3) * 5 + i) * 32 + (lane >> 1), py = pp / PW, px = pp - py * PW;
             const int iy = iy0 + py, ix = ix0 + px, ch = ks_dma * 16 + (((lane & 1) ^ ((pp >> 3) & 1)) << 3);
-            pvoff[i] = (pp < npix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (unsigned)(((iy * p.W + ix) * p.I + ch) * 2) : OOB;
+            // (one select, no short-circuit branches: this runs between two steps' multiplies on every wave)
+            const bool ok = (pp < npix) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            pvoff[i] = ok ? (unsigned)(((iy * p.W + ix) * p.I + ch) * 2) : OOB;
         }
         srd_x = make_srd(p.x + (long)c.n * p.H * p.W * p.I, (unsigned)(p.H * p.W * p.I * 2));
     };
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
     for (int r = 0; r < BR; ++r)
 #pragma unroll
         for (int c = 0; c < BC; ++c) {
-            const int pp = NT == 9 ? (wave * 2 + r) * p.PW + j + c : (wave * 2 + (r & 1) + p.tdy[r >> 1]) * p.PW + j + p.tdx[r >> 1];
+            const int pp = NT == 9 ? (wave * 2 + r) * PW + j + c : (wave * 2 + (r & 1) + p.tdy[r >> 1]) * PW + j + p.tdx[r >> 1];
             baddr_[r][c] = (unsigned)(pp * 32 + ((kg ^ ((pp >> 3) & 1)) << 4));
         }
     auto baddr = [&](int t, int q) __attribute__((always_inline)) -> unsigned { return NT == 9 ? baddr_[q + t / 3][t % 3] : baddr_[t * 2 + q][0]; };
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         for (int q = 0; q < 2; ++q) {
             const int gy = c.ty * TH + wave * 2 + q, gx = c.tx * TW + j;
             const int oy = gy * p.s_out + p.oy0, ox = gx * p.s_out + p.ox0;
-            const bool ok = gy < p.GH && gx < p.GW && oy >= 0 && oy < p.OHt && ox >= 0 && ox < p.OWt;
+            const bool ok = (gy < p.GH) & (gx < p.GW) & ((unsigned)oy < (unsigned)p.OHt) & ((unsigned)ox < (unsigned)p.OWt);
             pyoff[q] = ok ? (unsigned)((oy * p.OWt + ox) * p.O * 2) : OOB;
         }
         p_ot = c.ot;
@@ -267,6 +285,11 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         for (int i = 0; i < 5; ++i) dma_weight(i, 0, tile_off);
         if (prm_any) { dma_params(cur, 0); if (!prm_per_tile) dma_params(cur, 1); }
     }
+#ifndef SHG_RING_NO_PRIO
+    // the second-dispatched half of the workgroup loses the issue arbitration of its SIMD to the older wave on every step (wave 7 multiplies
+    // 5.5 k cycles beside wave 0's 3.6 k, and the step ends with the slowest wave): one static priority for that half, no per-phase flips
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     while (true) {
         // step s is in LDS once every wave's requests have landed; the same barrier says every wave has finished reading stage (s+1) & 1
         RING_TRACE(0);
@@ -367,7 +390,7 @@ bool conv_ring_eligible(const ConvP& p, int span_y, int span_x) {
     if (p.tail && (p.s_out != 1 || p.oy0 || p.ox0)) return false;
     if (p.noise_mode && ((p.OWt & 3) || (reinterpret_cast<uintptr_t>(p.noise) & 15))) return false;
     if ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.out_scale)) & 15) return false;
-    return ring::TH - 1 + span_y <= 18 && ring::TW - 1 + span_x <= 34;
+    return span_y == 3 && span_x == 3;                             // (the kernel's 18 x 34 patch)
 #endif
 }
 
@@ -394,7 +417,9 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
         attr = true;
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES, st, p, (int)ntiles, n_ot);
+    const ring::RingDiv dv{(unsigned)n_ot, (unsigned)p.tiles_x, (unsigned)p.tiles_y, 0xFFFFFFFFu / (unsigned)n_ot, 0xFFFFFFFFu / (unsigned)p.tiles_x,
+                           0xFFFFFFFFu / (unsigned)p.tiles_y};
+    hipLaunchKernelGGL((ring::conv_f16_ring_kernel<9>), dim3(grid), dim3(512), ring::LDS_BYTES, st, p, (int)ntiles, dv);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }
