@@ -213,7 +213,7 @@ int shg_shu_rfft2_shift_f32(const float* x, long x_batch_stride, float* T, int N
 size_t shg_conv2d_wgrad_workspace_bytes(int NB, int I, int O, int OH, int OW, int kh, int kw);
 int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, int NB, int I, int O, int H, int W, int OH, int OW,
                          int kh, int kw, int stride, int pad, void* workspace, size_t ws_bytes, void* stream);
-/* The same weight gradient for the stride-1 3x3 'same' layers (pad 1, OH = H, OW = W, W % 4 == 0, W >= 16) in the Winograd domain -- the
+/* The same weight gradient for the stride-1 3x3 'same' layers (pad 1, OH = H, OW = W, W % 4 == 0, W >= 4) in the Winograd domain -- the
  * transpose of F(4x4,3x3): dw = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G, a quarter of the multiplications, both operands transformed
  * in the kernel, fp32 MFMA; deterministic; ~5e-6 relative against float64 (the direct form: ~2e-6).  shg_conv2d_wgrad_wino_supported
  * tells whether a geometry is served (1 / 0); x and g 16-byte aligned. */

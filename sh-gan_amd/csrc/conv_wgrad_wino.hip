@@ -12,7 +12,7 @@
 // (A[o = c][k = t], B[k = t][i = c]): no exchange of transformed data between waves, no cross-wave reduction, one barrier per chunk.
 // The price is that a gradient tile is transformed by the two waves that share its channels and an input patch by four (244 VALU
 // instructions per 36 MFMAs of 32 cycles -- the two waves of a SIMD overlap one's transforms with the other's products).
-// A chunk = 8 tiles (1 x 8 or 2 x 4) of one image: the raw 4 TY x 4 TX gradient window of 64 channels and the (4 TY + 2) x (4 TX + 8) input
+// A chunk = 8 tiles (1 x 8 or 2 x 4; images narrower than 16 columns: 4 tiles, 2 x 2 or 4 x 1) of one image: the raw 4 TY x 4 TX gradient window of 64 channels and the (4 TY + 2) x (4 TX + 8) input
 // window of 32 channels arrive by 16-byte LDS-DMA (`buffer_load ... lds`; the descriptor's range check writes the zero padding), double
 // buffered, 16 channels interleaved per piece so that the 16 channels of a ds_read_b128 group hit 16 consecutive 16-byte slots (the
 // interleave is done on the GLOBAL side of the DMA: lane = (piece, channel)).  The epilogue applies G^T . G per accumulator element (all 36 positions of an (o, i) pair live in one lane) and writes
@@ -29,7 +29,7 @@ struct WgWinoP {
     const float* g;      // [NB, O, H, W]
     float* out;          // dw [O, I, 3, 3] (nslice == 1) or partials [nslice][O][I][9]
     int NB, I, O, H, W;
-    int lx;              // log2 of the tiles per chunk row (TX = 8 or 4; TY = 8 / TX)
+    int lx;              // log2 of the tiles per chunk row: chunk = TY x TX tiles = 1 x 8, 2 x 4 (W < 32) or 2 x 2, 4 x 1 (W < 16: four tiles, one k-step)
     int cty, ctx;        // chunks per image
     int nchunk, nslice;
 };
@@ -78,7 +78,8 @@ __device__ __forceinline__ void gt3(const float (&m)[6], float (&o)[3]) {
 template <int LX>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgWinoP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int TX = 1 << LX, TY = 8 >> LX, XP = TX + 2;      // tiles per chunk row / column; 16-byte pieces per input-window row
+    constexpr int TX = 1 << LX, TPC = LX >= 2 ? 8 : 4, TY = TPC >> LX, XP = TX + 2;      // tiles per chunk row / chunk / column; 16-byte pieces per input-window row
+    static_assert((4 * TY + 2) * XP <= 64 && 4 * TY * TX <= 32, "a channel's windows are at most 64 / 32 pieces");
     const int tid = threadIdx.x, lane = tid & 63, cc = lane & 15, tq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int osub = wave & 3, isub = wave >> 2;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgWinoP p
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                           // request k = wave + 8 j: channel group j, pieces 4 wave ..
             const int q = 4 * wave + tq, o = o0 + 16 * j + cc, gy = gy0 + (q >> LX), gx = gx0 + (q & (TX - 1)) * 4;
-            const bool ok = o < p.O && gy < p.H && gx < p.W;
+            const bool ok = (q >> LX) < 4 * TY && o < p.O && gy < p.H && gx < p.W;
             dma16(base + (wave + 8 * j) * 1024, ok ? (unsigned)((o * HW + gy * p.W + gx) * 4) : OOB, srd_g);
         }
 #pragma unroll
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgWinoP p
         const int buf = (c - c_begin) & 1;
         if (c + 1 < c_end) issue(c + 1, buf ^ 1);
 #pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            // tile j = 4 s + tq of the chunk: (jy, jx) = (0, j) for 1 x 8 chunks, (s, tq) for 2 x 4
-            const int qg = LX == 3 ? 4 * s + tq : 16 * s + tq, qx = LX == 3 ? 4 * s + tq : 4 * s * XP + tq;
+        for (int s = 0; s < TPC / 4; ++s) {
+            // tile j = 4 s + tq of the chunk at (jy, jx) = (j / TX, j % TX): first gradient piece 4 jy TX + jx, first input piece 4 jy XP + jx
+            const int j = 4 * s + tq, qg = ((j >> LX) << (2 + LX)) + (j & (TX - 1)), qx = (j >> LX) * 4 * XP + (j & (TX - 1));
             const unsigned char* gs = lds + buf * STAGE + g_lane + qg * 256;
             const unsigned char* xs = lds + buf * STAGE + x_lane + qx * 256;
             // gradient tile: 4 rows of one piece; down the columns first: S[a][col] = sum_r A[a][r] e[r][col]
@@ -201,13 +202,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgWinoP p
 }  // namespace wgw
 
 static bool wgw_eligible(int H, int W, int OH, int OW, int kh, int kw, int stride, int pad) {
-    return kh == 3 && kw == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (W & 3) == 0 && W >= 16 && H >= 4;
+    return kh == 3 && kw == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (W & 3) == 0 && W >= 4 && H >= 4;
 }
 
+static int wgw_lx(int W) { return W >= 32 ? 3 : (W >= 16 ? 2 : (W >= 8 ? 1 : 0)); }
+static int wgw_ty(int lx) { return (lx >= 2 ? 8 : 4) >> lx; }
+
 static int wgw_slices(int NB, int I, int O, int H, int W) {
-    const int lx = W >= 32 ? 3 : 2;
+    const int lx = wgw_lx(W);
     const long blocks = (long)shg_cdiv(I, wgw::BI) * shg_cdiv(O, wgw::BO);
-    const long nchunk = (long)NB * shg_cdiv(H, 4 * (8 >> lx)) * shg_cdiv(W, 4 << lx);
+    const long nchunk = (long)NB * shg_cdiv(H, 4 * wgw_ty(lx)) * shg_cdiv(W, 4 << lx);
     long s = (256 + blocks - 1) / blocks;                        // one workgroup per CU (2 x 64 KiB of LDS), one round
     if (s > nchunk) s = nchunk;
     if (s > 1024) s = 1024;
@@ -230,13 +234,13 @@ extern "C" int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* 
                                          size_t ws_bytes, void* stream) {
     SHG_CHECK_ARG(x && g && dw, "conv2d_wgrad_wino: null pointer");
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1, "conv2d_wgrad_wino: bad shape");
-    SHG_CHECK_ARG(wgw_eligible(H, W, H, W, 3, 3, 1, 1), "conv2d_wgrad_wino: 3x3 stride-1 pad-1 layers with W %% 4 == 0, W >= 16, H >= 4");
+    SHG_CHECK_ARG(wgw_eligible(H, W, H, W, 3, 3, 1, 1), "conv2d_wgrad_wino: 3x3 stride-1 pad-1 layers with W %% 4 == 0, W >= 4, H >= 4");
     SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0, "conv2d_wgrad_wino: x and g must be 16-byte aligned");
     SHG_CHECK_ARG((long)I * H * W * 4 < (1L << 31) && (long)O * H * W * 4 < (1L << 31), "conv2d_wgrad_wino: an image of x / g must stay below 2 GiB");
     WgWinoP p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W;
-    p.lx = W >= 32 ? 3 : 2;
-    p.cty = shg_cdiv(H, 4 * (8 >> p.lx)); p.ctx = shg_cdiv(W, 4 << p.lx);
+    p.lx = wgw_lx(W);
+    p.cty = shg_cdiv(H, 4 * wgw_ty(p.lx)); p.ctx = shg_cdiv(W, 4 << p.lx);
     p.nchunk = NB * p.cty * p.ctx;
     p.nslice = wgw_slices(NB, I, O, H, W);
     const size_t need = p.nslice > 1 ? (size_t)p.nslice * O * I * 9 * sizeof(float) : 0;
@@ -245,7 +249,9 @@ extern "C" int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* 
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess) {
+            hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess) {
             shg_set_error("conv2d_wgrad_wino: cannot reserve %d bytes of LDS", 2 * wgw::STAGE);
             return SHG_ERR_LAUNCH;
         }
@@ -254,7 +260,9 @@ extern "C" int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(shg_cdiv(I, wgw::BI), shg_cdiv(O, wgw::BO), p.nslice);
     if (p.lx == 3) hipLaunchKernelGGL(wgw::conv_wgrad_wino_kernel<3>, grid, dim3(512), 2 * wgw::STAGE, s, p);
-    else hipLaunchKernelGGL(wgw::conv_wgrad_wino_kernel<2>, grid, dim3(512), 2 * wgw::STAGE, s, p);
+    else if (p.lx == 2) hipLaunchKernelGGL(wgw::conv_wgrad_wino_kernel<2>, grid, dim3(512), 2 * wgw::STAGE, s, p);
+    else if (p.lx == 1) hipLaunchKernelGGL(wgw::conv_wgrad_wino_kernel<1>, grid, dim3(512), 2 * wgw::STAGE, s, p);
+    else hipLaunchKernelGGL(wgw::conv_wgrad_wino_kernel<0>, grid, dim3(512), 2 * wgw::STAGE, s, p);
     SHG_CHECK_LAUNCH();
     if (p.nslice > 1) {
         shg_launch_wgrad_reduce((const float*)workspace, dw, (long)O * I * 9, p.nslice, s);
