@@ -1185,6 +1185,7 @@ static int conv2d_f16_impl(const void* x, const void* w, const float* bias, void
     }
     SHG_CHECK_ARG(mode == 1 && k == 3 && stride == 2 && crop >= 0 && OH >= 1 && OW >= 1, "conv2d_f16: the transposed form is 3x3 stride 2");
     // full[oy][ox] = sum_{ky,kx} x[(oy-ky)/2][(ox-kx)/2] w[ky][kx] over even (oy-ky), (ox-kx); phase (py,px) = parity of (oy,ox)
+    if (f16::convt_upring_eligible(p)) return f16::convt_upring_launch(p, crop, st);      // all four phases from one pass over the input
     p.s_in = 1; p.s_out = 2;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {

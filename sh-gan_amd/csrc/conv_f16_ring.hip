@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
         v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
         const int o = p_ot * 64 + m * 32 + (2 * gp + kg) * 8;
         const unsigned voff = o < p.O ? pyoff[q] + (unsigned)(o * 2) : OOB;
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(srd_y));
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd_y));     // (the wait state hipcc pads behind a > 8-byte store whose data registers are rewritten next: not modelled inside asm)
     };
 
     // ---- one step: 18 k-iterations (tap, k-step) of four MFMAs; the operands of iteration it + 1 are read while iteration it multiplies (one
