@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -101,6 +101,7 @@ _SIGS = {
     'shg_conv2d_f16_packed_weight_elems': [c_i] * 3,
     'shg_conv2d_f16_pack_weight': [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_conv2d_f16_pack_weight_oihw': [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'shg_conv2d_f16_set_routes': [c_i],
     'shg_conv2d_wgrad_f16_workspace_bytes': [c_i] * 6,
     'shg_conv2d_wgrad_f16': [c_fp, c_fp, c_fp] + [c_i] * 10 + [c_fp, ctypes.c_size_t, c_fp],
     'shg_upfirdn2d_f16': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],

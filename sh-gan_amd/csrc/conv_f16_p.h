@@ -34,6 +34,7 @@ bool conv_ring_eligible(const ConvP& p, int span_y, int span_x);
 int conv_ring_launch(const ConvP& p, int span_y, int span_x, hipStream_t st);
 
 // conv_f16_upring.hip: the stride-2 transposed 3x3 form (mode 1 of conv2d_f16_impl) with all four phases in one persistent launch
+int conv_f16_routes();          // conv_f16_ring.hip: the mask of shg_conv2d_f16_set_routes
 bool convt_upring_eligible(const ConvP& p);
 int convt_upring_launch(const ConvP& p, int crop, hipStream_t st);
 

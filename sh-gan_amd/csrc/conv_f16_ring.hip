@@ -382,10 +382,14 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
 // The ring kernel serves: patches read with stride 1 (stride-1 convolutions; span = extent of the tap offsets) of at most 18 x 34 pixels,
 // 9 taps (for now), whole 8-channel output pieces; of the fused tail everything but the input scale and the residual (those stay on
 // conv_f16_kernel), noise with whole 16-byte pieces per row.
+static int g_f16_routes = 3;         // bit 0: stride-1 3x3 launches on the ring kernel, bit 1: transposed launches on the merged-phase kernel
+int conv_f16_routes() { return g_f16_routes; }
+
 bool conv_ring_eligible(const ConvP& p, int span_y, int span_x) {
 #ifdef SHG_F16_NO_RING
     return false;
 #else
+    if (!(g_f16_routes & 1)) return false;
     if (p.s_in != 1 || p.ntaps != 9 || (p.O & 7) || (p.I & 31) || p.in_scale || p.residual) return false;
     if (p.tail && (p.s_out != 1 || p.oy0 || p.ox0)) return false;
     if (p.noise_mode && ((p.OWt & 3) || (reinterpret_cast<uintptr_t>(p.noise) & 15))) return false;
@@ -425,3 +429,13 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
 }
 
 }  // namespace f16
+
+// Which kernels serve the fp16 convolutions: bit 0 = persistent ring kernel for the stride-1 3x3 launches, bit 1 = merged-phase kernel for the
+// stride-2 transposed launches (default 3); 0 sends everything to the gather kernel conv_f16_kernel.  Every route gives the same bits
+// (tests/test_gpu_fp16_routes.py holds them against each other); the switch exists for that comparison and for A/B timing.  Returns the old mask.
+extern "C" int shg_conv2d_f16_set_routes(int mask) {
+    const int old = f16::g_f16_routes;
+    f16::g_f16_routes = mask & 3;
+    return old;
+}
+

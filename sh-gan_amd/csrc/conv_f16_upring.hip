@@ -251,6 +251,7 @@ bool convt_upring_eligible(const ConvP& p) {
 #ifdef SHG_F16_NO_UPRING
     return false;
 #else
+    if (!(conv_f16_routes() & 2)) return false;
     return (p.I & 31) == 0 && (p.O & 7) == 0 && !p.bias && !p.tail && p.I <= 512 && ((reinterpret_cast<uintptr_t>(p.in_scale)) & 15) == 0 &&
            (long)p.H * p.W * p.I * 2 < (1L << 31) && (long)p.OHt * p.OWt * p.O * 2 < (1L << 31);
 #endif
