@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MB == 2 &&
 // ---------------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int WR = 4;                // output rows per staged block
+constexpr int WR = 4;                // output rows per staged block (the 3x3 stride-1 kernel stages 8: wgrad_rows)
+constexpr int wgrad_rows(int k, int s) { return (k == 3 && s == 1) ? 8 : WR; }
 constexpr int WC = 16;               // output columns per staged block = one MFMA k-step
 
 struct WgradP {
@@ -365,7 +366,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // Channel pitches (144 / 304 / 880 / 208 bytes) put the 16 lanes of a b128 group on 16 different 16-byte slots: conflict-free.
 template <int K, int S>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_f16_kernel(const WgradP p) {
-    constexpr int NT = K * K;
+    constexpr int NT = K * K, WR = wgrad_rows(K, S);         // (8 rows at 3x3 stride 1: 72 MFMAs per wave between two barriers instead of 36)
     constexpr int XR = (WR - 1) * S + K, XC = (WC - 1) * S + K, RP = S == 1 ? 24 : 48, GP = WR * WC + 8, XP = XR * RP + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
     _Float16* gT = sm;                               // [64][GP]
@@ -378,50 +379,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // staging is software-pipelined: the NHWC loads of block b+1 are issued before the multiply loop of block b and are scattered
-    // (transposed) into LDS after it
-    constexpr int GIT = WR * WC * 8 / 256, XIT = (XR * XC * 8 + 255) / 256;
-    h8 gv[GIT], xv[XIT];
+    // staging is software-pipelined: the NHWC loads of block b+1 are issued before the multiply loop of block b and are written
+    // (transposed) into LDS after it.  A thread stages FOUR ADJACENT PIXELS of one 8-channel group: per channel they are 8 contiguous bytes
+    // of the [channel][pixel] image -- one ds_write_b64 (stride 2: the even and the odd pair, two ds_write_b32) instead of four 2-byte
+    // scatter writes (48 ds_write_b16 per thread and block kept the LDS pipe busier than the matrix pipe: bank-conflict rate 0.54,
+    // profiles/r05_f16_pmc_base_summary.txt).  Gradient tile: 16 quads x 8 groups (threads 0-127; K = 1: the input tile has the same shape
+    // and takes threads 128-255); input tile: XR rows x QPR quads (the last one partial).
+    constexpr int GITEMS = WR * 4 * 8;               // 128 (4 rows) or 256 (8 rows)
+    constexpr int QPR = (XC + 3) / 4, XITEMS = XR * QPR * 8, XROUNDS = K == 1 ? 1 : (XITEMS + 255) / 256;
+    h8 gv[4], xv[XROUNDS][4];
+    const int sq = tid & 7;                          // 8-channel group of this thread's items
     auto fetch = [&](long blk) __attribute__((always_inline)) {
         const int bxi = (int)(blk % p.bx);
         const long rest = blk / p.bx;
         const int byi = (int)(rest % p.by), n = (int)(rest / p.by);
         const int oy0 = byi * WR, ox0 = bxi * WC;
+        if (K != 1 || tid < 128) {
+            const int quad = (tid >> 3) & (WR * 4 - 1), r = quad >> 2, c = (quad & 3) * 4;
+            const int oy = oy0 + r, ch = ot * 64 + sq * 8;
+            const _Float16* gp = p.g + (((long)n * p.OH + oy) * p.OW + ox0 + c) * p.O + ch;
 #pragma unroll
-        for (int u = 0; u < GIT; ++u) {
-            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / WC, c = pp - r * WC;
-            const int oy = oy0 + r, ox = ox0 + c, ch = ot * 64 + q * 8;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (oy < p.OH && ox < p.OW && ch < p.O) v = *(const h8*)(p.g + (((long)n * p.OH + oy) * p.OW + ox) * p.O + ch);
-            gv[u] = v;
+            for (int m = 0; m < 4; ++m) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (tid < GITEMS && oy < p.OH && ox0 + c + m < p.OW && ch < p.O) v = *(const h8*)(gp + (long)m * p.O);
+                gv[m] = v;
+            }
         }
         const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
 #pragma unroll
-        for (int u = 0; u < XIT; ++u) {
-            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / XC, c = pp - r * XC;
-            const int iy = iy0 + r, ix = ix0 + c, ch = it * 64 + q * 8;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (pp < XR * XC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.I) v = *(const h8*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.I + ch);
-            xv[u] = v;
+        for (int u = 0; u < XROUNDS; ++u) {
+            const int e = K == 1 ? tid - 128 : tid + u * 256, quad = e >> 3, r = quad / QPR, c = (quad - r * QPR) * 4;
+            const int iy = iy0 + r, ch = it * 64 + sq * 8;
+            const bool rok = e >= 0 && e < XITEMS && iy >= 0 && iy < p.H && ch < p.I;
+            const _Float16* xp = p.x + (((long)n * p.H + iy) * p.W + ix0 + c) * p.I + ch;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int ix = ix0 + c + m;
+                if (rok && c + m < XC && ix >= 0 && ix < p.W) v = *(const h8*)(xp + (long)m * p.I);
+                xv[u][m] = v;
+            }
         }
     };
     if ((long)blockIdx.y < p.nblocks) fetch(blockIdx.y);
     for (long blk = blockIdx.y; blk < p.nblocks; blk += p.slices) {
         __syncthreads();
-        // LDS row = (ch % 8) * 8 + ch / 8: the 8 lanes of a pixel hit 8 different banks
+        // LDS row = (ch % 8) * 8 + ch / 8: the 8 lanes of a pixel quad hit 8 different 16-byte slots
+        if (tid < GITEMS) {
+            const int quad = tid >> 3, pp = (quad >> 2) * WC + (quad & 3) * 4;
 #pragma unroll
-        for (int u = 0; u < GIT; ++u) {
-            const int e = tid + u * 256, q = e & 7, pp = e >> 3;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gT[(k * 8 + q) * GP + pp] = gv[u][k];
+            for (int k = 0; k < 8; ++k) {
+                h4 w4 = {gv[0][k], gv[1][k], gv[2][k], gv[3][k]};
+                *(h4*)(gT + (k * 8 + sq) * GP + pp) = w4;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < XIT; ++u) {
-            const int e = tid + u * 256, q = e & 7, pp = e >> 3, r = pp / XC, c = pp - r * XC;
-            if (pp < XR * XC) {
-                const int pos = r * RP + (S == 1 ? c : (c & 1) * 24 + (c >> 1));
+        for (int u = 0; u < XROUNDS; ++u) {
+            const int e = K == 1 ? tid - 128 : tid + u * 256, quad = e >> 3, r = quad / QPR, c = (quad - r * QPR) * 4;
+            if (e >= 0 && e < XITEMS) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) xT[(k * 8 + q) * XP + pos] = xv[u][k];
+                for (int k = 0; k < 8; ++k) {
+                    _Float16* row = xT + (k * 8 + sq) * XP + r * RP;
+                    if constexpr (S == 1) {
+                        h4 w4 = {xv[u][0][k], xv[u][1][k], xv[u][2][k], xv[u][3][k]};
+                        *(h4*)(row + c) = w4;
+                    } else {                                         // columns c, c + 2 -> even half, c + 1, c + 3 -> odd half (at + 24)
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        h2 ev = {xv[u][0][k], xv[u][2][k]}, od = {xv[u][1][k], xv[u][3][k]};
+                        *(h2*)(row + (c >> 1)) = ev;
+                        *(h2*)(row + 24 + (c >> 1)) = od;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1318,14 +1346,15 @@ extern "C" int shg_conv2d_wgrad_f16(const void* x, const void* g, float* dw, int
     p.x = (const _Float16*)x; p.g = (const _Float16*)g; p.part = (float*)workspace;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.s = stride; p.pad = pad; p.k = k;
     p.OP = (O + 63) / 64 * 64; p.IP = (I + 63) / 64 * 64;
-    p.by = shg_cdiv(OH, f16::WR); p.bx = shg_cdiv(OW, f16::WC);
+    const int wr = f16::wgrad_rows(k, stride);
+    p.by = shg_cdiv(OH, wr); p.bx = shg_cdiv(OW, f16::WC);
     p.nblocks = (long)N * p.by * p.bx;
     const long tiles = (long)(p.OP / 64) * (p.IP / 64);
     const long slices = wgrad_f16_slices(tiles, p.nblocks, k == 1 ? 1024 : 512);
     p.slices = (int)slices;
     SHG_CHECK_ARG(!(k == 1 && stride == 2), "conv2d_wgrad_f16: 1x1 stride-2 (the forward decimates with upfirdn2d first)");
-    p.XR = (f16::WR - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
-    const size_t lds = ((size_t)64 * (f16::WR * f16::WC + 8) + (size_t)64 * (p.XR * (stride == 1 ? 24 : 48) + 8)) * sizeof(_Float16);
+    p.XR = (wr - 1) * stride + k; p.XC = (f16::WC - 1) * stride + k;
+    const size_t lds = ((size_t)64 * (wr * f16::WC + 8) + (size_t)64 * (p.XR * (stride == 1 ? 24 : 48) + 8)) * sizeof(_Float16);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)slices);
     if (k == 3 && stride == 1) hipLaunchKernelGGL((f16::conv_wgrad_f16_kernel<3, 1>), grid, dim3(256), lds, st, p);
