@@ -316,8 +316,9 @@ int shg_modtail_backward_f32_cslices(int N, int C, long HW);
 int shg_modtail_backward_f32(const float* gy, const float* y, const float* t, const float* d, const float* u, const float* e, float* gt, float* part,
                              float* gnoise, int N, int C, long HW, int act, float alpha, float gain, float clamp, void* stream);
 /* Kernel routes of the fp16 convolutions: bit 0 = the persistent LDS-DMA ring kernel for 3x3 stride-1 launches (csrc/conv_f16_ring.hip), bit 1 = the
- * merged-phase kernel for the stride-2 transposed form (csrc/conv_f16_upring.hip); default 3; 0 = the gather kernel for everything.  All routes
- * give identical bits; returns the previous mask. */
+ * merged-phase kernel for the stride-2 transposed form (csrc/conv_f16_upring.hip), bit 2 = the persistent kernel for 3x3 stride-2 launches
+ * (csrc/conv_f16_down.hip); default 7; 0 = the gather kernel for everything.  Bits 0 / 1 give the gather kernel's bits, bit 2 the same
+ * products summed k-step-major; returns the previous mask. */
 int shg_conv2d_f16_set_routes(int mask);
 int shg_modtail_f16(const void* t, const float* d, const float* noise, int noise_mode, const float* bias, void* y, int N, long HW, int C, int act,
                     float alpha, float gain, float clamp, void* stream);

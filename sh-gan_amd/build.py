@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libshgan_hip.so'
 VARDIR = os.path.join(os.path.dirname(HERE), 'tools', '_variants')      # study builds (-DSHG_ABLATE, A/B knobs) live with the tools, never beside the product library
-SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_wgrad_wino.hip', 'conv_f16.hip', 'conv_f16_ring.hip', 'conv_f16_upring.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
+SOURCES = ['capi.hip', 'upfirdn2d.hip', 'pointwise.hip', 'dense.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_poly.hip', 'conv_wgrad.hip', 'conv_wgrad_wino.hip', 'conv_f16.hip', 'conv_f16_ring.hip', 'conv_f16_upring.hip', 'conv_f16_down.hip', 'shu.hip', 'mask_raster.hip', 'fid_stats.hip']
 # per-source extras: the Winograd weight-gradient transforms are scalar fp32 chains beside MFMAs -- SLP-packed (v_pk_*) forms cost register
 # moves and issue slots there
 SRC_FLAGS = {'conv_wgrad_wino.hip': ['-fno-slp-vectorize']}

@@ -1096,6 +1096,7 @@ static int conv_taps(ConvP p, int ntaps, const int* dy, const int* dx, const int
     p.org_y = mny; p.org_x = mnx;
     p.GH = GH; p.GW = GW;
     if (conv_ring_eligible(p, mxy - mny + 1, mxx - mnx + 1)) return conv_ring_launch(p, mxy - mny + 1, mxx - mnx + 1, st);
+    if (mny == mnx && mxy - mny == 2 && mxx - mnx == 2 && conv_down_eligible(p)) return conv_down_launch(p, -mny, st);
     // wide grids of stride-1 reads: 8 x 32 pixel tiles, two pixel blocks per wave (each weight operand feeds two MFMAs); stride-2 reads
     // (a 4x larger patch) and narrow grids keep 8 x 16
     const int nb = (p.s_in == 1 && GW > TW) ? 2 : 1;

@@ -38,4 +38,8 @@ int conv_f16_routes();          // conv_f16_ring.hip: the mask of shg_conv2d_f16
 bool convt_upring_eligible(const ConvP& p);
 int convt_upring_launch(const ConvP& p, int crop, hipStream_t st);
 
+// conv_f16_down.hip: the stride-2 3x3 launches (p.s_in == 2, nine taps) on a persistent kernel; pad = the convolution's padding
+bool conv_down_eligible(const ConvP& p);
+int conv_down_launch(const ConvP& p, int pad, hipStream_t st);
+
 }  // namespace f16

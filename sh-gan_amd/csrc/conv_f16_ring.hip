@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_f16_ring_kernel(const ConvP p, const
 // The ring kernel serves: patches read with stride 1 (stride-1 convolutions; span = extent of the tap offsets) of at most 18 x 34 pixels,
 // 9 taps (for now), whole 8-channel output pieces; of the fused tail everything but the input scale and the residual (those stay on
 // conv_f16_kernel), noise with whole 16-byte pieces per row.
-static int g_f16_routes = 3;         // bit 0: stride-1 3x3 launches on the ring kernel, bit 1: transposed launches on the merged-phase kernel
+static int g_f16_routes = 7;         // bit 0: stride-1 3x3 launches on the ring kernel, bit 1: transposed launches on the merged-phase kernel, bit 2: stride-2 3x3 launches on conv_f16_down.hip
 int conv_f16_routes() { return g_f16_routes; }
 
 bool conv_ring_eligible(const ConvP& p, int span_y, int span_x) {
@@ -431,11 +431,12 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
 }  // namespace f16
 
 // Which kernels serve the fp16 convolutions: bit 0 = persistent ring kernel for the stride-1 3x3 launches, bit 1 = merged-phase kernel for the
-// stride-2 transposed launches (default 3); 0 sends everything to the gather kernel conv_f16_kernel.  Every route gives the same bits
-// (tests/test_gpu_fp16_routes.py holds them against each other); the switch exists for that comparison and for A/B timing.  Returns the old mask.
+// stride-2 transposed launches, bit 2 = persistent kernel for the stride-2 3x3 launches (default 7); 0 sends everything to the gather kernel
+// conv_f16_kernel.  Routes 0 / 1 give the gather kernel's bits, route 2 its products in another summation order
+// (tests/test_gpu_fp16_routes.py); the switch exists for that comparison and for A/B timing.  Returns the old mask.
 extern "C" int shg_conv2d_f16_set_routes(int mask) {
     const int old = f16::g_f16_routes;
-    f16::g_f16_routes = mask & 3;
+    f16::g_f16_routes = mask & 7;
     return old;
 }
 

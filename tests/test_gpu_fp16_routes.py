@@ -22,7 +22,7 @@ def kf():
 
 def both_routes(kf, fn):
     lib = kf._lib.get_lib()
-    old = lib.shg_conv2d_f16_set_routes(3)
+    old = lib.shg_conv2d_f16_set_routes(7)
     try:
         y_new = fn()
         lib.shg_conv2d_f16_set_routes(0)
@@ -81,3 +81,31 @@ def test_merged_phase_transposed_kernel_equals_per_phase_launches_and_float64(kf
     full[:, :, :ref.shape[2], :ref.shape[3]] = ref
     ref = full[:, :, pad:pad + oh, pad:pad + ow]
     assert float((y_new.double() - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+DOWN = [(1, 32, 128, 17, 17, {}), (2, 64, 128, 33, 65, dict(bias=True)), (1, 64, 72, 40, 73, dict(act=True, bias=True)), (3, 128, 256, 21, 33, dict(act=True, bias=True, d=True)),
+        (2, 32, 8, 9, 9, dict(act=False, gain=0.5)), (2, 128, 512, 17, 17, dict(act=True, bias=True, clamp=0.7)), (2, 64, 128, 129, 129, dict(act=True, bias=True)),
+        (1, 48, 40, 12, 20, dict(bias=True, pad=1)), (2, 96, 136, 31, 18, dict(act=True, pad=1))]
+
+
+@pytest.mark.parametrize('n,i,o,h,w,t', DOWN)
+def test_stride2_persistent_kernel_vs_gather_kernel_and_float64(kf, n, i, o, h, w, t):
+    """csrc/conv_f16_down.hip sums the same products k-step-major (the gather kernel: 32-channel chunk -> tap -> k-step): not bit-identical;
+    both are held against float64 torch, and against each other at half-precision rounding."""
+    torch.manual_seed(n * 31 + i + o + h + w)
+    pad = t.get('pad', 0)
+    x = torch.randn(n, i, h, w, device=DEV).half().to(memory_format=CL)
+    wt = (torch.randn(o, i, 3, 3, device=DEV) / (i * 9) ** 0.5).half()
+    b = torch.randn(o, device=DEV) if t.get('bias') else None
+    kw = {}
+    if 'act' in t:
+        kw.update(act=t['act'], gain=t.get('gain', 1.0), clamp=t.get('clamp', 256.0))
+    if t.get('d'):
+        kw['out_scale'] = torch.rand(n, o, device=DEV) + 0.5
+    y_new, y_old = both_routes(kf, lambda: kf.conv2d(x, wt, b, 2, pad, **kw))
+    d = (y_new.float() - y_old.float()).abs()
+    assert float(d.max()) <= 2e-3 * float(y_old.float().abs().max()) and float((d > 0).float().mean()) < 0.05
+    if not kw:
+        ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), 2, pad)
+        for y in (y_new, y_old):
+            assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-3

@@ -16,7 +16,7 @@ bad = 0
 
 
 def routes(fn):
-    old = lib.shg_conv2d_f16_set_routes(3)
+    old = lib.shg_conv2d_f16_set_routes(7)
     try:
         a = fn(); lib.shg_conv2d_f16_set_routes(0); b = fn()
     finally:
