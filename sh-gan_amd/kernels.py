@@ -311,11 +311,22 @@ def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, ac
                                            cl, L.stream()), 'modtail_backward_f32')
     s1 = s0 = None
     if want_sums:
-        sums = part.sum(1)                    # fixed order over the workgroup partials: deterministic
+        sums = sum_partials(part)             # fixed order over the workgroup partials: deterministic
         s1, s0 = sums[:, 0], sums[:, 1]
     if gnoise is not None:
         gnoise = gnoise[0] if zs == 1 else gnoise.sum(0)
     return gt, s1, s0, gnoise
+
+
+def sum_partials(part):
+    """part [N, B, ...] float32 -> [N, ...] = sum over B in block order (shg_sum_partials_f32)."""
+    L = _Launch()
+    part = L.req(part, 'part')
+    n, b = part.shape[:2]
+    out = L.new((n,) + tuple(part.shape[2:]))
+    with L:
+        check(_lib.get_lib().shg_sum_partials_f32(_ptr(part), _ptr(out), n, b, out.numel() // n, L.stream()), 'sum_partials')
+    return out
 
 
 def fma(a, b, c):

@@ -324,6 +324,6 @@ def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, ac
               'modtail_backward_f16')
     s1 = s0 = None
     if want_sums:
-        sums = part.sum(1)                    # fixed order over the workgroup partials: deterministic
+        sums = kernels.sum_partials(part)     # fixed order over the workgroup partials: deterministic
         s1, s0 = sums[:, 0], sums[:, 1]
     return gt, s1, s0, gnoise
