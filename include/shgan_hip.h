@@ -59,6 +59,9 @@ int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long t
 int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int HW, void* stream);
 /* out [N,K] = sum over b of part [N,B,K] in block order (the per-workgroup partial sums of shg_modtail_backward_*: deterministic). */
 int shg_sum_partials_f32(const float* part, float* out, int N, int B, int K, void* stream);
+/* `(weight * gain).to(float16)` of the fp16 layers and its gradient in one launch each: to_half != 0: dst (halves) = half(src (floats) * gain);
+ * else dst (floats) = float(src (halves)) * gain. */
+int shg_scale_cast_f32_f16(const void* src, void* dst, long n, float gain, int to_half, void* stream);
 /* Phase planes of a stride-2 transposed convolution (shg_conv2d_f32 mode 2 / out_mode 1, shg_conv2d_up_poly_f32) -> image with the
  * crop / zero-extension conv2d_gradfix.py:96-128 applies: y[n,c,Y,X] = full[Y+lo][X+lo] (+ bias[c]), zero outside the
  * (2H+1) x (2W+1) result.  N*C <= 65535. */

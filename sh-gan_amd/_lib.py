@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -42,6 +42,7 @@ _SIGS = {
     'shg_fma_f32': [c_fp, c_fp, c_fp, c_fp, c_l, c_fp],
     'shg_scale_channels_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_fp],
     'shg_sum_partials_f32': [c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'shg_scale_cast_f32_f16': [c_fp, c_fp, c_l, c_f, c_i, c_fp],
     'shg_planes_to_image_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv_weight_prep_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_fp],
     'shg_conv2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_i,

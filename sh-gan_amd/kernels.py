@@ -318,6 +318,19 @@ def modtail_backward(gy, y, t=None, d=None, want_sums=True, want_noise=False, ac
     return gt, s1, s0, gnoise
 
 
+def scale_cast(x, gain, to_half):
+    """half(x * gain) of a float32 tensor (``to_half``) or float(x) * gain of a float16 one, contiguous, one launch (shg_scale_cast_f32_f16)."""
+    L = _Launch()
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == (torch.float32 if to_half else torch.float16)):
+        raise _lib.ShgError('scale_cast: a HIP tensor of the source dtype is expected')
+    x = x.contiguous()
+    L._own(x, 'x')
+    y = torch.empty(x.shape, dtype=torch.float16 if to_half else torch.float32, device=x.device)
+    with L:
+        check(_lib.get_lib().shg_scale_cast_f32_f16(_ptr(x), _ptr(y), x.numel(), float(gain), int(bool(to_half)), L.stream()), 'scale_cast')
+    return y
+
+
 def sum_partials(part):
     """part [N, B, ...] float32 -> [N, ...] = sum over B in block order (shg_sum_partials_f32)."""
     L = _Launch()

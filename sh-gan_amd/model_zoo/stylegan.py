@@ -469,17 +469,17 @@ class conv2d_layer(nn.Module):
         ak = _act_kwargs(self.activation, gain)
         if self.up == 1 and self.down == 1 and conv2d_gradfix.conv_bias_act_supported(x, self.weight, ak):
             # 3x3 stride-1 layers: convolution + bias + activation as one node on one forward kernel
-            return conv2d_gradfix.conv2d_bias_act(x, (self.weight * self.weight_gain).to(x.dtype), self.bias, self.padding, **ak)
+            return conv2d_gradfix.conv2d_bias_act(x, grad_ops.scaled_weight(self.weight, self.weight_gain, x.dtype), self.bias, self.padding, **ak)
         if (self.up == 1 and self.down == 2 and self.padding == 0 and self.weight.shape[2] == 1 and self.resample_filter is not None
                 and tuple(self.resample_filter.shape) == (4, 4) and conv2d_gradfix.conv_bias_act_supported(x, self.weight, ak)):
             # the residual blocks' skip: decimate with the low-pass (conv2d_resample.py:104-108), then the 1x1 with its gain in the store pass
             xd = upfirdn2d.upfirdn2d(x=x, f=self.resample_filter, down=2, padding=[1, 1, 1, 1])
-            return conv2d_gradfix.conv2d_bias_act(xd, (self.weight * self.weight_gain).to(x.dtype), self.bias, 0, **ak)
+            return conv2d_gradfix.conv2d_bias_act(xd, grad_ops.scaled_weight(self.weight, self.weight_gain, x.dtype), self.bias, 0, **ak)
         if self.up == 1 and self.down == 2 and self.padding == 1:
-            y = conv2d_resample.conv2d_down_bias_act(x, (self.weight * self.weight_gain).to(x.dtype), self.resample_filter, self.bias, ak)
+            y = conv2d_resample.conv2d_down_bias_act(x, grad_ops.scaled_weight(self.weight, self.weight_gain, x.dtype), self.resample_filter, self.bias, ak)
             if y is not None:
                 return y
-        y = conv2d_resample.conv2d_resample(x=x, w=(self.weight * self.weight_gain).to(x.dtype), f=self.resample_filter, up=self.up,
+        y = conv2d_resample.conv2d_resample(x=x, w=grad_ops.scaled_weight(self.weight, self.weight_gain, x.dtype), f=self.resample_filter, up=self.up,
                                             down=self.down, padding=self.padding, flip_weight=(self.up == 1))
         if ak is None or (y.dtype == torch.float16 and y.shape[1] % 8):
             if self.bias is not None:

@@ -7,6 +7,7 @@ never comes here: the modules switch to these only when gradients are requested 
   upfirdn2d.py:174-192); convolutions in ``conv2d_gradfix.py``.
 Every backward is written with differentiable operators again, so second derivatives (the R1 / path-length regularisers,
 stylegan_default_loss.py:76-91, 118-124) work."""
+import os
 import threading
 
 import torch
@@ -147,6 +148,30 @@ class _StashGradFn(torch.autograd.Function):
 def stash_input_grad(x, join):
     """Identity whose gradient goes to ``join`` (see InputGradJoin) instead of autograd's accumulation, when a consumer is waiting."""
     return _StashGradFn.apply(x, join) if wants_grad(x) else x
+
+
+class _ScaleCastFn(torch.autograd.Function):
+    """``(w * gain).to(float16)`` (forward) / ``g.float() * gain`` (its gradient) as one kernel each; linear, so the backward is the same
+    Function with the dtypes exchanged (differentiable to any order)."""
+    @staticmethod
+    def forward(ctx, x, gain, to_half):
+        ctx.gain, ctx.to_half = gain, to_half
+        return kernels.scale_cast(x.detach(), gain, to_half)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScaleCastFn.apply(g, ctx.gain, not ctx.to_half), None, None
+
+
+SCALE_CAST_KERNEL = os.environ.get('SHG_SCALE_CAST', '1') == '1'     # (A/B switch; SHG_SCALE_CAST=0: the tensor operators)
+
+
+def scaled_weight(weight, gain, dtype):
+    """``(weight * gain).to(dtype)`` of a layer's float32 master weight (stylegan.py:228,236-238); for float16 layers on the HIP device one
+    launch forward and one backward instead of a product and a cast each way."""
+    if SCALE_CAST_KERNEL and dtype == torch.float16 and weight.dtype == torch.float32 and weight.is_cuda:
+        return _ScaleCastFn.apply(weight, float(gain), True)
+    return (weight * gain).to(dtype)
 
 
 def channel_sum(t):
