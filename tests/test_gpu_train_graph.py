@@ -39,7 +39,9 @@ def real_batch(n, seed):
 def test_phase_graphs_follow_the_eager_loop():
     """Six iterations (Gmain + Dmain every time, Greg at 0 / 4, Dreg at 0) from the same state: eager ``run_phases`` vs ``PhaseGraphs``
     (two eager runs of a phase, then capture + replays).  Deterministic setting (noise_mode 'const', no style mixing, host latents from
-    a seeded generator): the replays run the same kernels on the same data, so the parameters agree to round-off."""
+    a seeded generator): the replays run the same kernels on the same data, so the parameters agree to round-off.
+    A comparison of this repository with itself: the eager loop it follows is pinned on the reference by tests/test_gpu_config5.py (the four
+    phases of the full-width step against the reference's autograd, float64 yardstick)."""
     from shgan_amd import losses, train_stage as ts
     G, D = small_networks(5)
     g0, d0 = copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict())
@@ -346,7 +348,9 @@ def test_fused_demodulation_weight_kernel_vs_tensor_ops(o, i, k, half):
 def test_dmain_one_critic_pass_over_the_stacked_batch_equals_the_two_passes_of_the_reference(fp16):
     """stylegan_default_loss.py:84-106 judges the generated and the real batch in two critic passes with a backward each.  The product
     stacks them (``Discriminator.forward(segments=2)``: minibatch statistic per half) and runs one backward of the summed losses.  No
-    other layer mixes samples: the logits must be IDENTICAL, the parameter gradients equal up to the order of the weight-gradient sums."""
+    other layer mixes samples: the logits must be IDENTICAL, the parameter gradients equal up to the order of the weight-gradient sums.
+    Self-comparison (stacked pass vs the two passes of THIS repository); the two-pass form is what tests/test_gpu_config5.py holds against
+    the reference's autograd (Dmain gradients of the full-width critic), and that test runs with the stacked pass switched on."""
     import shgan_amd  # noqa: F401
     from shgan_amd import losses
     from shgan_amd.model_zoo import stylegan
@@ -419,7 +423,9 @@ def test_fused_style_factors_vs_float64_autograd(half, n, i, o):
 def test_residual_block_input_gradients_joined_in_the_convolution_kernel(fp16):
     """``grad_ops.InputGradJoin``: in the critic's residual blocks the skip branch's input gradient is added by conv0's input-gradient
     kernel (its ``residual`` operand) instead of by autograd's accumulation pass.  Same gradients as the ordinary path (switch off) for
-    the parameters and for the image; the kernel path is really taken (every block joins once); the R1 pass (create_graph) is unchanged."""
+    the parameters and for the image; the kernel path is really taken (every block joins once); the R1 pass (create_graph) is unchanged.
+    Self-comparison (switch on vs off); the reference pin is tests/test_gpu_config5.py (critic gradients, first and second order, against
+    the reference's autograd at full width -- run with the join on) and the discriminator goldens of tests/test_gpu_backward.py."""
     import shgan_amd  # noqa: F401
     from shgan_amd.model_zoo import stylegan
     from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
@@ -469,7 +475,9 @@ def test_residual_block_input_gradients_joined_in_the_convolution_kernel(fp16):
 @pytest.mark.parametrize('fp16', [False, True])
 def test_conv_bias_act_as_one_training_node_equals_the_two_nodes(fp16):
     """3x3 stride-1 layers under autograd: ``_ConvBiasActFn`` (bias + lrelu_agc in the convolution's store pass, one node) against
-    convolution node + bias/activation node -- critic logits, parameter gradients, image gradient, and the R1 second-order gradients."""
+    convolution node + bias/activation node -- critic logits, parameter gradients, image gradient, and the R1 second-order gradients.
+    Self-comparison (one node vs two nodes of this repository); the two-node form is pinned on the reference's discriminator golden
+    (tests/test_gpu_backward.py) and both run under tests/test_gpu_config5.py (Dmain / Dreg vs the reference's autograd, fused switch on)."""
     import shgan_amd  # noqa: F401
     from shgan_amd.model_zoo import stylegan
     from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
@@ -520,7 +528,9 @@ def test_conv_bias_act_as_one_training_node_equals_the_two_nodes(fp16):
 def test_encoder_feature_gradients_joined_in_the_down_layer():
     """The co-modulation encoder's feature maps feed the block's stride-2 layer and the synthesis network: the gradient arriving from the
     synthesis side is added by the down layer's input-gradient kernel (``upfir_planar`` residual operand) -- same generator gradients as
-    with the switch off, and the kernel path is taken once per float32 encoder block."""
+    with the switch off, and the kernel path is taken once per float32 encoder block.
+    Self-comparison (switch on vs off); the generator gradients themselves are pinned on the reference by tests/test_gpu_config5.py
+    (Gmain / Greg against the reference's autograd, run with the join on)."""
     import shgan_amd  # noqa: F401
     from shgan_amd import kernels
     from shgan_amd.model_zoo import stylegan
