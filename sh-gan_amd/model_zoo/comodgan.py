@@ -173,19 +173,20 @@ class synthesis_block(stylegan_synthesis_block):
 
     def forward(self, x, x0, img, ws, w0, fused_modconv=None, noise_mode='random', style_cache=None):
         x, x0 = grad_ops.to_block_dtype(x, self.use_fp16), grad_ops.to_block_dtype(x0, self.use_fp16)      # comodgan.py:305-312
+        fm = stylegan_mod.fused_modconv_rule(self, x, fused_modconv)                                         # comodgan.py:307-309
         w_iter = iter(ws.unbind(dim=1))
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
-        x = self.conv0(x, _style_in(style_cache, self.conv0, w_iter, w0), noise_mode=noise_mode, residual=x0,
+        x = self.conv0(x, _style_in(style_cache, self.conv0, w_iter, w0), fused_modconv=fm, noise_mode=noise_mode, residual=x0,
                        styles_sd=_style_of(style_cache, self.conv0))
         if self.res_link:
-            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y,
-                           styles_sd=_style_of(style_cache, self.conv1))
+            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), fused_modconv=fm, gain=np.sqrt(0.5), noise_mode=noise_mode,
+                           residual=y, styles_sd=_style_of(style_cache, self.conv1))
         else:
-            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), noise_mode=noise_mode,
+            x = self.conv1(x, _style_in(style_cache, self.conv1, w_iter, w0), fused_modconv=fm, noise_mode=noise_mode,
                            styles_sd=_style_of(style_cache, self.conv1))
         if self.torgb is not None:
-            img = self.torgb(x, _style_in(style_cache, self.torgb, w_iter, w0), base_img=img, base_filter=self.resample_filter,
+            img = self.torgb(x, _style_in(style_cache, self.torgb, w_iter, w0), fused_modconv=fm, base_img=img, base_filter=self.resample_filter,
                              styles_sd=_style_of(style_cache, self.torgb))
         elif img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)

@@ -181,9 +181,11 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     """Modulated (and demodulated) convolution, signature of stylegan.py:103-113.
 
     x [N,I,H,W], weight [O,I,k,k], styles [N,I], noise broadcastable to the output ([H',W'] or
-    [N,1,H',W']).  Both values of ``fused_modconv`` run the same kernels: the activations are scaled by
+    [N,1,H',W']).  float32: both values of ``fused_modconv`` run the same kernels: the activations are scaled by
     the normalised styles while the input tile is staged, the shared weight is pre-normalised
     (stylegan.py:146), and the demodulation coefficient (stylegan.py:155) is applied in the epilogue.
+    float16 without autograd: ``fused_modconv`` selects, as in the reference, whether the per-sample WEIGHT (w * s * d, fused) or the
+    ACTIVATION (x * s, then * d: non-fused) is what gets rounded to half.
     ``_prepped`` / ``_epilogue`` are used by the layer classes to pass cached weights and to fuse
     bias / activation / residual."""
     batch_size = x.shape[0]
@@ -191,6 +193,13 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
     misc.assert_shape(x, [batch_size, in_channels, None, None])
     misc.assert_shape(styles, [batch_size, in_channels])
+    if (fused_modconv and x.dtype == torch.float16 and x.is_cuda and down == 1 and not _epilogue and _tail is None
+            and not grad_ops.wants_grad(x, weight, styles, noise)):
+        # the reference's fused form on halves (stylegan.py:149-170,183-193): per-sample weights rounded to half, see _modulated_conv2d_half_infer
+        y = _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, None, _act_kwargs(None),
+                                         None, fused=True)
+        if y is not None:
+            return y
     if grad_ops.generic_route(x, weight, styles, noise):
         if _epilogue:
             raise NotImplementedError('modulated_conv2d: the fused epilogue is an inference-path extension')
@@ -349,6 +358,16 @@ F16_INFER_FUSED = True       # half layers without autograd: modulation / tail f
 ROUTE_TRACE = None
 
 
+def fused_modconv_rule(module, x, fused_modconv):
+    """The blocks' choice of the modulated-convolution form (stylegan.py:488-490, comodgan.py:240-242,307-309): unless the caller fixes it,
+    fused in eval for float32 blocks and for a batch of ONE image, else the non-fused algebra.  On this path float32 layers run the same
+    kernels either way (``modulated_conv2d``); for float16 blocks the flag selects where the half rounding falls (weights or
+    activations), as in the reference."""
+    if fused_modconv is None:
+        return (not module.training) and (x.dtype == torch.float32 or int(x.shape[0]) == 1)
+    return bool(fused_modconv)
+
+
 def layer_route(module, x, *tensors):
     half = isinstance(x, torch.Tensor) and x.dtype == torch.float16
     if grad_ops.wants_grad(x, *tensors):
@@ -362,11 +381,15 @@ def layer_route(module, x, *tensors):
     return route
 
 
-def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual, cache=None):
+def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, bias, ak, residual, cache=None,
+                                 fused=False):
     """Inference route of a float16 modulated layer (no autograd): the same algebra as ``_modulated_conv2d_train`` with the passes fused
     into the NHWC fp16 convolution -- ``x * styles`` while the patch is staged, demodulation / noise / bias / lrelu_agc / skip-add in its
     store pass (up = 1); the transposed form (up = 2) takes the style scale at staging, its tail follows the FIR in one modtail pass.
-    Returns None when the geometry is not one of the layer forms (caller falls back to the composed route)."""
+    Returns None when the geometry is not one of the layer forms (caller falls back to the composed route).
+    ``fused`` = the reference's ``fused_modconv`` form on halves (stylegan.py:149-170,183-193; what its blocks take in eval for a batch of
+    ONE image, :490): the weight is modulated and demodulated per sample in float32 and rounded to half once, the activations stay as
+    they are -- there a grouped convolution with groups = N, here one launch per image with that image's weight (same arithmetic)."""
     from .. import kernels_f16
     k = weight.shape[2]
     if ak is None or weight.shape[2] != weight.shape[3] or k not in (1, 3) or padding != k // 2 or up not in (1, 2):
@@ -384,6 +407,26 @@ def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample
         return wn_, wsq_, pk
     wn, wsq, pk = cache.get(f'w16_{up}_{int(bool(flip_weight))}_{int(bool(demodulate))}', [weight], build) if cache is not None else build()
     _, sn, d = _modulation_factors(True, weight, styles, demodulate, wfac=(wn, wsq))
+    if fused:
+        outs = []
+        per_sample_noise = noise is not None and noise.ndim == 4 and noise.shape[0] == x.shape[0] and x.shape[0] > 1
+        tail = ak if (ak.get('act') or float(ak.get('gain', 1.0)) != 1.0) else {}         # (the bare operator: no activation pass)
+        for j in range(x.shape[0]):
+            wj = wn * sn[j].reshape(1, -1, 1, 1)                                    # :150-151
+            if d is not None:
+                wj = wj * d[j].reshape(-1, 1, 1, 1)                                 # :169
+            nz = noise[j:j + 1] if per_sample_noise else noise
+            rj = None if residual is None else residual[j:j + 1]
+            if up == 1:
+                pkj = kernels_f16.pack_weight((wj if flip_weight else wj.flip([2, 3])).to(torch.float16))
+                outs.append(kernels_f16.conv2d(x[j:j + 1], pkj, bias, 1, padding, noise=nz, residual=rj, **tail))
+                continue
+            pkj = kernels_f16.pack_weight((wj.flip([2, 3]) if flip_weight else wj).transpose(0, 1).to(torch.float16), transposed=True)
+            mid = kernels_f16.conv_transpose2d(x[j:j + 1], pkj, None, 0, None)
+            mid = kernels_f16.upfirdn2d(mid, resample_filter, padx0=1, padx1=1, pady0=1, pady1=1, gain=4.0)
+            yj = kernels_f16.modtail(mid, noise=nz, bias=bias, **ak)
+            outs.append(yj if rj is None else yj + rj)
+        return outs[0] if len(outs) == 1 else torch.cat(outs).contiguous(memory_format=torch.channels_last)
     if up == 1:
         return kernels_f16.conv2d(x, pk, bias, 1, padding, in_scale=sn, out_scale=d, noise=noise, residual=residual, **ak)
     # conv2d_resample.py:122-142 with up = 2, padding = 1, a 4x4 filter: conv_transpose2d(stride 2, padding 0) -> FIR pad [1,1,1,1], gain 4
@@ -592,7 +635,7 @@ class synthesis_layer(conv2d_layer):
         if route == 'f16_fused':
             y = _modulated_conv2d_half_infer(x, self.weight.detach(), self.affine(w), None if noise is None else noise * self.noise_strength.detach(),
                                              self.up, self.padding, self.resample_filter, True, self.up == 1, self.bias.detach(), ak, residual,
-                                             cache=_cache_of(self))
+                                             cache=_cache_of(self), fused=bool(fused_modconv))
             if y is not None:
                 return y
         if route != 'f32_fused':
@@ -639,7 +682,13 @@ class torgb_layer(conv2d_layer):
         route = layer_route(self, x, w, self.weight, self.bias, self.affine.weight, base_img)
         if route == 'f16_fused':
             from .. import kernels_f16
-            y = kernels_f16.conv2d(x, self.weight.detach().to(torch.float16), self.bias.detach(), 1, 0, in_scale=self.affine(w) * self.weight_gain)
+            if fused_modconv:         # stylegan.py:149-151,183-193 without demodulation: per-sample weights w * s rounded to half, one image per launch
+                st = self.affine(w) * self.weight_gain
+                ys = [kernels_f16.conv2d(x[j:j + 1], (self.weight.detach() * st[j].reshape(1, -1, 1, 1)).to(torch.float16), self.bias.detach(), 1, 0)
+                      for j in range(x.shape[0])]
+                y = ys[0] if len(ys) == 1 else torch.cat(ys)
+            else:
+                y = kernels_f16.conv2d(x, self.weight.detach().to(torch.float16), self.bias.detach(), 1, 0, in_scale=self.affine(w) * self.weight_gain)
             y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             return y if base_img is None else upfirdn2d.upsample2d(base_img, base_filter) + y
         if route != 'f32_fused':
@@ -749,17 +798,18 @@ class synthesis_block(nn.Module):
         if self.const is not None:
             x = (self.const if grad_ops.wants_grad(self.const) else self.const.detach()).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         x = grad_ops.to_block_dtype(x, self.use_fp16)                            # stylegan.py:486-495
+        fm = fused_modconv_rule(self, x, fused_modconv)                          # :488-490
         if self.res_link:
             y = self.skip(x, gain=np.sqrt(0.5))
         w_iter = iter(ws.unbind(dim=1))
         if self.conv0 is not None:
-            x = self.conv0(x, next(w_iter).contiguous(), noise_mode=noise_mode)
+            x = self.conv0(x, next(w_iter).contiguous(), fused_modconv=fm, noise_mode=noise_mode)
         if self.res_link:
-            x = self.conv1(x, next(w_iter).contiguous(), gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y)
+            x = self.conv1(x, next(w_iter).contiguous(), fused_modconv=fm, gain=np.sqrt(0.5), noise_mode=noise_mode, residual=y)
         else:
-            x = self.conv1(x, next(w_iter).contiguous(), noise_mode=noise_mode)
+            x = self.conv1(x, next(w_iter).contiguous(), fused_modconv=fm, noise_mode=noise_mode)
         if self.torgb is not None:
-            img = self.torgb(x, next(w_iter).contiguous(), base_img=img, base_filter=self.resample_filter)
+            img = self.torgb(x, next(w_iter).contiguous(), fused_modconv=fm, base_img=img, base_filter=self.resample_filter)
         elif img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         return x, img

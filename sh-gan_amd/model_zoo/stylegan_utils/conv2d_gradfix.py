@@ -72,7 +72,11 @@ def _ones(n, i, device):
 def _conv_fwd(x, weight, bias, stride, padding, groups):
     if x.dtype == torch.float16:             # the reference's fp16 blocks (stylegan.py:486,660-667): NHWC fp16-MFMA kernels, fp32 accumulation
         if groups != 1:
-            raise NotImplementedError('conv2d: grouped fp16 convolutions (the fused N=1 form, stylegan.py:187-190) are not built; fp16 layers run the non-fused algebra')
+            # grouped halves (the reference's fused modulated form reshapes the batch into groups, stylegan.py:187-190): one launch per group
+            cg, og = x.shape[1] // groups, weight.shape[0] // groups
+            ys = [kernels_f16.conv2d(x[:, j * cg:(j + 1) * cg].contiguous(memory_format=torch.channels_last), weight[j * og:(j + 1) * og].to(torch.float16),
+                                     None if bias is None else bias[j * og:(j + 1) * og], stride, padding) for j in range(groups)]
+            return torch.cat(ys, 1)
         return kernels_f16.conv2d(x, weight.to(torch.float16), bias, stride, padding)
     n, c, h, w = x.shape
     if THIN_1X1 and groups == 1 and stride == 1 and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and n <= 65535:
@@ -97,7 +101,11 @@ def _convt_fwd(x, weight, bias, padding, groups, out_hw=None):
     rows / columns [padding, padding + h) x [padding, padding + w) instead, zero where the result ends earlier (``_fit``)."""
     if x.dtype == torch.float16:
         if groups != 1:
-            raise NotImplementedError('conv_transpose2d: grouped fp16 transposed convolutions are not built')
+            cg, og = x.shape[1] // groups, weight.shape[1]          # weight [Cin, Cout/g, 3, 3]: group j owns input rows j*cg ...
+            ys = [kernels_f16.conv_transpose2d(x[:, j * cg:(j + 1) * cg].contiguous(memory_format=torch.channels_last),
+                                               weight[j * cg:(j + 1) * cg].to(torch.float16), None if bias is None else bias[j * og:(j + 1) * og],
+                                               padding, out_hw) for j in range(groups)]
+            return torch.cat(ys, 1)
         return kernels_f16.conv_transpose2d(x, weight.to(torch.float16), bias, padding, out_hw)
     n, c, h, w = x.shape
     ci_g, co_g = weight.shape[0] // groups, weight.shape[1]

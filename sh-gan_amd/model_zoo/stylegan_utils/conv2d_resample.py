@@ -24,12 +24,14 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     if x.dtype == torch.float16 or (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
         # training path and every float16 tensor (conv2d_resample.py:26-51 verbatim in structure): flip for a true convolution, the transposed form takes
         # the weight as [Cin, Cout, kh, kw]
-        if groups != 1:
+        if groups != 1 and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
             raise NotImplementedError('grouped convolutions are forward only')
         wg = w if flip_weight else w.flip([2, 3])
         if transpose:
-            return conv2d_gradfix.conv_transpose2d(x, wg.transpose(0, 1), stride=stride, padding=padding)
-        return conv2d_gradfix.conv2d(x, wg, stride=stride, padding=padding)
+            # torch layout [Cin, Cout/groups, kh, kw] (conv2d_resample.py:40-47)
+            wt = wg.transpose(0, 1) if groups == 1 else wg.reshape(groups, oc // groups, icg, kh, kw).transpose(1, 2).reshape(groups * icg, oc // groups, kh, kw)
+            return conv2d_gradfix.conv_transpose2d(x, wt, stride=stride, padding=padding, groups=groups)
+        return conv2d_gradfix.conv2d(x, wg, stride=stride, padding=padding, groups=groups)
     xs = x.reshape(n * groups, c // groups, h, wd)
     if transpose:
         if stride != 2:

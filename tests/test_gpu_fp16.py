@@ -459,3 +459,106 @@ def test_direct_weight_pack_equals_the_staged_pack(o, i, k):
     from shgan_amd.model_zoo.stylegan_utils import conv2d_gradfix
     got = conv2d_gradfix._conv_input_grad(gy.to(dtype=torch.float16, memory_format=torch.channels_last), w, x.shape, 1, k // 2)
     assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+# ---- the reference's FUSED modulated form on halves (fused_modconv with float16: what its blocks take in eval for ONE image) ---------------
+
+@pytest.fixture(scope='module')
+def gf():
+    import shgan_amd  # noqa: F401
+    return load_golden('fp16_fused')
+
+
+def test_fused_modulated_conv2d_halves_vs_reference(gf):
+    """``modulated_conv2d(..., fused_modconv=True)`` on halves (stylegan.py:149-170,183-193: per-sample weights w * s * d rounded to half
+    once, grouped convolution with groups = N) against the reference's own half run of that branch, N = 1, 2, 3, plain / up / toRGB
+    (tests/golden/fp16_fused.npz, tools/gen_golden.py: gen_fp16_fused).  Same bars as the non-fused operator test above: 4e-3 of the output
+    range to the fp32 evaluation on the same half inputs, 6e-3 to the reference's half result."""
+    from shgan_amd.model_zoo import stylegan
+    f4 = torch.from_numpy(gf['f']).to(DEV)
+    for name in gf['mc_names']:
+        k = 'mc__' + str(name) + '__'
+        up, demod = (int(v) for v in gf[k + 'cfg'])
+        w = torch.from_numpy(gf[k + 'w']).to(DEV)
+        noise = torch.from_numpy(gf[k + 'noise']).to(DEV) if (k + 'noise') in gf.files else None
+        kw = dict(weight=w, styles=torch.from_numpy(gf[k + 'styles']).to(DEV), noise=noise, up=up, padding=w.shape[2] // 2,
+                  resample_filter=f4 if up > 1 else None, demodulate=bool(demod), flip_weight=(up == 1))
+        with torch.no_grad():
+            y = stylegan.modulated_conv2d(x=dev_h(gf[k + 'x']), fused_modconv=True, **kw)
+            y_nf = stylegan.modulated_conv2d(x=dev_h(gf[k + 'x']), fused_modconv=False, **kw)
+        assert y.dtype == torch.float16 and tuple(y.shape) == tuple(gf[k + 'y16'].shape)
+        e32, e16 = rel_err(c(y), gf[k + 'y32']), rel_err(c(y), gf[k + 'y16'].astype(np.float32))
+        print(f'fused modconv {name}: vs fp32 {e32:.2e}, vs reference half {e16:.2e}; non-fused form vs fp32 {rel_err(c(y_nf), gf[k + "y32"]):.2e}')
+        assert e32 < 4e-3 and e16 < 6e-3, (name, e32, e16)
+        assert not torch.equal(y, y_nf), name                      # the flag really selects another rounding point
+
+
+@pytest.mark.parametrize('up', [1, 2])
+def test_grouped_half_convolutions_are_one_launch_per_group(up):
+    """conv2d_resample(groups = N) on halves (the reshape the reference's fused form performs, stylegan.py:187-190) == the per-group
+    float32 convolutions of torch on the same half operands, within one half rounding of the result (+ one for the FIR)."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo.stylegan_utils import conv2d_resample, upfirdn2d
+    rs = np.random.RandomState(7 + up)
+    n, i, o, h, w = 3, 16, 24, 10, 12
+    x = torch.from_numpy(rs.standard_normal((1, n * i, h, w)).astype(np.float32)).half().to(DEV).to(memory_format=CL)
+    wt = torch.from_numpy((rs.standard_normal((n * o, i, 3, 3)) / np.sqrt(9 * i)).astype(np.float32)).half().to(DEV)
+    f4 = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    with torch.no_grad():
+        y = conv2d_resample.conv2d_resample(x=x, w=wt, f=f4 if up > 1 else None, up=up, padding=1, groups=n, flip_weight=(up == 1))
+    assert y.dtype == torch.float16 and y.shape[1] == n * o
+    refs = []
+    for j in range(n):
+        xj, wj = x[:, j * i:(j + 1) * i].double(), wt[j * o:(j + 1) * o].double()
+        if up == 1:
+            refs.append(F.conv2d(xj, wj, padding=1))
+        else:
+            mid = F.conv_transpose2d(xj, wj.transpose(0, 1), stride=2)          # flip_weight False: true convolution with the un-flipped weight
+            f2 = (f4.double() * 4.0)[None, None].repeat(o, 1, 1, 1)
+            refs.append(F.conv2d(F.pad(mid, [1, 1, 1, 1]), f2.flip([2, 3]), groups=o))
+    ref = torch.cat(refs, 1)
+    assert tuple(ref.shape) == tuple(y.shape)
+    assert rel_err(c(y), c(ref)) < (1e-3 if up == 1 else 2e-3)
+
+
+def test_generator_fp16_blocks_batch_of_one_takes_the_fused_form_vs_reference(gf):
+    """In eval a batch of ONE image makes every half block of the reference take the fused form (stylegan.py:490, comodgan.py:309): the
+    product follows the same rule (``stylegan.fused_modconv_rule``) -- checked on the SH-GAN generator with fp16 blocks against the
+    reference's own run (reduced width, noise_mode='const'), image at 2e-2 of its range like the batch-of-two fixture."""
+    from shgan_amd import configs, eval_harness
+    from shgan_amd.model_zoo import stylegan
+    from oracle import shgan_oracle as orc
+    kw = dict(ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G = configs.build_generator(256, use_fp16_before_res=64, use_fp16_after_res=32, **kw)
+    G.load_state_dict(orc.init_state_dict(256, seed=int(gf['G__seed']), noise_strength=0.1, bias_std=0.1, **kw), strict=True)
+    G = G.to(DEV).eval().requires_grad_(False)
+    real_u8 = np.random.RandomState(84).randint(0, 256, size=(1, 3, 256, 256)).astype(np.uint8)
+    real = torch.from_numpy(real_u8.astype(np.float32)) / 127.5 - 1.0
+    mask = torch.from_numpy(np.unpackbits(gf['G__mask_bits'])[: 256 * 256].reshape(1, 1, 256, 256).astype(np.float32))
+    x = eval_harness.assemble_input(real, mask).to(DEV)
+    z = torch.from_numpy(gf['G__z']).to(DEV)
+    seen = []
+    orig = stylegan._modulated_conv2d_half_infer
+
+    def spy(*a, **k):
+        seen.append(bool(k.get('fused')))
+        return orig(*a, **k)
+    stylegan._modulated_conv2d_half_infer = spy
+    try:
+        with torch.no_grad():
+            img = G(x=x, z=z, c=torch.zeros(1, 0, device=DEV), noise_mode='const')
+            seen_one, seen[:] = list(seen), []
+            x2 = torch.cat([x, x])
+            img2 = G(x=x2, z=torch.cat([z, z]), c=torch.zeros(2, 0, device=DEV), noise_mode='const')
+            seen_two = list(seen)
+    finally:
+        stylegan._modulated_conv2d_half_infer = orig
+    # six half 3x3 layers (synthesis 64 / 128 / 256: conv0 + conv1) -- with the three toRGB layers the reference's nine half calls
+    assert len(seen_one) == 6 and all(seen_one) and int(gf['G__calls_half']) == 9
+    assert len(seen_two) == 6 and not any(seen_two)                       # a batch of two: the non-fused algebra, as in the reference
+    e_f, e_nf = rel_err(c(img)[:, :, ::2, ::2], gf['G__img_eval']), rel_err(c(img)[:, :, ::2, ::2], gf['G__img_eval_nonfused'])
+    ref_gap, ref_forms = rel_err(gf['G__img_eval'], gf['G__img_fp32']), rel_err(gf['G__img_eval'], gf['G__img_eval_nonfused'])
+    print(f'G eval, one image: ours vs reference fused {e_f:.2e} (vs its non-fused run {e_nf:.2e}); reference fused vs its fp32 {ref_gap:.2e}, '
+          f'its two forms apart {ref_forms:.2e}')
+    assert img.dtype == torch.float32 and e_f < 2e-2
+    assert rel_err(c(img2[:1])[:, :, ::2, ::2], gf['G__img_fp32']) < 2e-2

@@ -165,6 +165,48 @@ def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
         kernels_f16.upfirdn2d(torch.zeros(1, 8, 8, 8, dtype=torch.float16), torch.ones(4, 4))
 
 
+def test_round5_entry_points_validate_their_arguments_without_a_gpu():
+    """The entry points added with ABI 29-33 (Winograd-domain weight gradient, the fp16 route switch, the two glue kernels): geometry
+    gates, workspace planning and argument checks are host code -- exercised here without a device."""
+    lib = _lib.get_lib()
+    P = ctypes.c_void_p(16)
+    sup = lib.shg_conv2d_wgrad_wino_supported
+    assert sup(64, 64, 64, 64, 3, 3, 1, 1) == 1 and sup(4, 4, 4, 4, 3, 3, 1, 1) == 1
+    assert sup(64, 64, 32, 32, 3, 3, 2, 1) == 0                     # stride 2: the direct kernel
+    assert sup(64, 64, 64, 64, 1, 1, 1, 0) == 0                     # 1x1
+    assert sup(64, 62, 64, 62, 3, 3, 1, 1) == 0                     # rows of whole 16-byte pieces only
+    assert sup(64, 64, 62, 62, 3, 3, 1, 0) == 0                     # pad 0
+    # workspace = K-slices x [O, I, 3, 3] floats when the (o, i) grid alone cannot fill 256 CUs; none when it does or when there is one chunk
+    wsb = lib.shg_conv2d_wgrad_wino_workspace_bytes
+    assert wsb(8, 64, 64, 512, 512) % (64 * 64 * 9 * 4) == 0 and wsb(8, 64, 64, 512, 512) // (64 * 64 * 9 * 4) == 128      # 2 blocks -> 128 slices
+    assert wsb(8, 512, 512, 64, 64) // (512 * 512 * 9 * 4) == 2                                                              # 128 blocks -> 2 slices
+    assert wsb(1, 512, 512, 4, 4) == 0                                                                                        # one chunk of tiles
+    f = lib.shg_conv2d_wgrad_wino_f32
+    assert f(None, P, P, 1, 32, 32, 16, 16, None, 0, None) == -1 and b'null' in lib.shg_last_error()
+    assert f(P, P, P, 1, 32, 32, 16, 18, None, 0, None) == -1 and b'W %' in lib.shg_last_error()
+    assert f(ctypes.c_void_p(8), P, P, 1, 32, 32, 16, 16, None, 0, None) == -1 and b'aligned' in lib.shg_last_error()
+    assert f(P, P, P, 8, 64, 64, 512, 512, P, 16, None) == -1 and b'workspace' in lib.shg_last_error()
+    assert f(P, P, P, 1, 4096, 32, 512, 512, P, 1 << 40, None) == -1 and b'2 GiB' in lib.shg_last_error()
+    # fp16 route switch: returns the previous mask, keeps three bits
+    old = lib.shg_conv2d_f16_set_routes(0)
+    try:
+        assert old == 7 and lib.shg_conv2d_f16_set_routes(0xFF) == 0 and lib.shg_conv2d_f16_set_routes(5) == 7
+    finally:
+        lib.shg_conv2d_f16_set_routes(old)
+    assert lib.shg_conv2d_f16_set_routes(old) == old
+    # glue kernels
+    assert lib.shg_sum_partials_f32(None, P, 1, 4, 64, None) == -1 and lib.shg_sum_partials_f32(P, P, 70000, 4, 64, None) == -1
+    assert lib.shg_sum_partials_f32(P, P, 1, 0, 64, None) == -1
+    assert lib.shg_scale_cast_f32_f16(None, P, 16, 1.0, 1, None) == -1 and lib.shg_scale_cast_f32_f16(P, P, -1, 1.0, 1, None) == -1
+    assert lib.shg_scale_cast_f32_f16(P, P, 0, 1.0, 1, None) == 0                      # empty: nothing launched
+    with pytest.raises(_lib.ShgError):
+        kernels.sum_partials(torch.zeros(2, 4, 64))
+    with pytest.raises(_lib.ShgError):
+        kernels.scale_cast(torch.zeros(8), 1.0, True)
+    with pytest.raises(_lib.ShgError):
+        kernels.conv2d_wgrad(torch.zeros(1, 32, 16, 16), torch.zeros(1, 32, 16, 16), 3, 3, 1, 1)
+
+
 def test_configs_build_and_seeded_init_are_deterministic():
     """The product constructs the shipped generators by itself (registry configs = the flattened YAML of SURVEY A.1) and
     initialises them identically in every process: same seed -> bit-identical state dict, reference initialiser statistics."""

@@ -1001,13 +1001,98 @@ def gen_fid():
     save('fid', names=np.asarray(list(spec.keys())), **cases)
 
 
+def gen_fp16_fused():
+    """The reference's FUSED modulated convolution on half tensors (stylegan.py:149-170,183-193: per-sample weights w * s * d rounded to
+    half once, grouped convolution with groups = N), the form its blocks take in eval when the batch is ONE image
+    (``fused_modconv = (not training) and (fp32 or N == 1)``, stylegan.py:490, comodgan.py:242,309) -- operator level for N = 1 and N = 2,
+    and the SH-GAN generator with fp16 blocks on a batch of one (eval).  Run by the reference itself on CPU."""
+    g = rs(900)
+    f4 = ref_ufd.setup_filter([1, 3, 3, 1])
+    out = {'f': f4.numpy()}
+
+    def h(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.float32)).half()
+
+    mc = [('same_n1', (1, 32, 16, 16), (48, 32, 3, 3), 1, True, True), ('up_n1', (1, 32, 8, 8), (24, 32, 3, 3), 2, True, True),
+          ('torgb_n1', (1, 32, 16, 16), (3, 32, 1, 1), 1, False, False), ('same_n2', (2, 32, 12, 16), (40, 32, 3, 3), 1, True, True),
+          ('up_n3', (3, 16, 8, 8), (24, 16, 3, 3), 2, True, True), ('torgb_n2', (2, 32, 16, 16), (3, 32, 1, 1), 1, False, False),
+          ('same_n1_wide', (1, 64, 20, 20), (64, 64, 3, 3), 1, True, False)]
+    for name, xs, ws, up, demod, with_noise in mc:
+        x = h(g.standard_normal(xs) * 3.0)
+        w = tn(g.standard_normal(ws))
+        st = tn(g.standard_normal((xs[0], xs[1])) + 1.0)
+        noise = tn(g.standard_normal((xs[2] * up, xs[3] * up)) * 0.1) if with_noise else None
+        k = ws[2]
+        kw = dict(weight=w, styles=st, noise=noise, up=up, padding=k // 2, resample_filter=f4 if up > 1 else None, demodulate=demod,
+                  flip_weight=(up == 1), fused_modconv=True)
+        y16 = stylegan.modulated_conv2d(x=x, **kw)
+        y32 = stylegan.modulated_conv2d(x=x.float(), **kw)
+        assert y16.dtype == torch.float16
+        for key, val in (('x', x), ('w', w), ('styles', st), ('y16', y16), ('y32', y32)):
+            out['mc__' + name + '__' + key] = val.numpy()
+        if noise is not None:
+            out['mc__' + name + '__noise'] = noise.numpy()
+        out['mc__' + name + '__cfg'] = np.array([up, int(demod)], dtype=np.int64)
+    out['mc_names'] = np.array([m[0] for m in mc])
+
+    # ---- SH-GAN generator with fp16 blocks, ONE image, eval: every half block takes the fused form
+    cfg = dict(resolution=256, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128)
+    G32 = build_reference_generator(**cfg)
+    mp = comodgan.Mapping(z_dim=64, c_dim=0, w_dim=64, num_ws=14, num_layers=8, embed_features=None, layer_features=None, activation=ACT,
+                          lr_multiplier=0.01, w_avg_beta=0.995)
+    enc = shgan.Encoder(resolution=256, ic_n=4, oc_n=128, ch_base=2048, ch_max=32, use_fp16_before_res=64, resample_filter=[1, 3, 3, 1],
+                        activation=ACT, mbstd_group_size=0, mbstd_c_n=0, c_dim=None, cmap_dim=None, use_dropout=True, has_extra_final_layer=False,
+                        shu_channels=32, shu_df_freedom=[2, 3], shu_df_type='piecewise_linear', shu_input_res=64, shu_lowest_res=4,
+                        shu_tail_sigma_mult=3, shu_gaussian_at_input_res=False)
+    syn = comodgan.Synthesis(w_dim=64, w0_dim=128, resolution=256, rgb_n=3, ch_base=2048, ch_max=32, use_fp16_after_res=32,
+                             resample_filter=[1, 3, 3, 1], activation=ACT)
+    G = comodgan.Generator(mp, enc, syn).eval()
+    sd = orc.init_state_dict(256, seed=83, ch_base=2048, ch_max=32, w_dim=64, z_dim=64, w0_dim=128, noise_strength=0.1, bias_std=0.1)
+    G.load_state_dict(sd, strict=True)
+    G32.load_state_dict(sd, strict=True)
+    real_u8, mask, z = synth_inputs(1, 256, 64, seed=84)
+    x = assemble_x(real_u8, mask)
+    out['G__mask_bits'], out['G__z'], out['G__seed'] = np.packbits(mask), z, np.int64(83)
+    # which form every modulated layer call took (the claim this fixture exists for): record the flag the reference passed down
+    seen = []
+    orig = stylegan.modulated_conv2d
+
+    def spy(*a, **k):
+        seen.append((str(k['x'].dtype).replace('torch.', ''), bool(k.get('fused_modconv', True)), int(k['x'].shape[0])))
+        return orig(*a, **k)
+    stylegan.modulated_conv2d = spy
+    try:
+        img = G(x=x, z=torch.from_numpy(z), c=torch.zeros(1, 0), noise_mode='const')
+    finally:
+        stylegan.modulated_conv2d = orig
+    assert any(d == 'float16' and fz for d, fz, _ in seen), seen
+    assert all(fz for _, fz, _ in seen), seen
+    out['G__calls_half'] = np.int64(sum(1 for d, _, _ in seen if d == 'float16'))
+    out['G__img_eval'] = img.numpy()[:, :, ::2, ::2]
+    out['G__img_eval_stats'] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
+    out['G__img_fp32'] = G32.eval()(x=x, z=torch.from_numpy(z), c=torch.zeros(1, 0), noise_mode='const').numpy()[:, :, ::2, ::2]
+    # the same batch of one through the NON-fused form (what a batch of 2+ takes): how far apart the reference's own two forms are
+    img_nf = None
+    def spy_nf(*a, **k):
+        if k['x'].dtype == torch.float16:
+            k['fused_modconv'] = False
+        return orig(*a, **k)
+    stylegan.modulated_conv2d = spy_nf
+    try:
+        img_nf = G(x=x, z=torch.from_numpy(z), c=torch.zeros(1, 0), noise_mode='const')
+    finally:
+        stylegan.modulated_conv2d = orig
+    out['G__img_eval_nonfused'] = img_nf.numpy()[:, :, ::2, ::2]
+    save('fp16_fused', **out)
+
+
 GENS = dict(upfirdn2d=gen_upfirdn2d, conv2d_resample=gen_conv2d_resample, modconv=gen_modconv,
             small_ops=gen_small_ops, shu=gen_shu, generator_small=gen_generator_small,
             generator_full_stats=gen_generator_full_stats, masks=gen_masks,
             generator_full512_stats=gen_generator_full512_stats, stylegan2_plain=gen_stylegan2_plain,
             discriminator=gen_discriminator, discriminator_grads=gen_discriminator_grads, generator_grads=gen_generator_grads,
             discriminator_conditional=gen_discriminator_conditional, fid=gen_fid, config5_step=gen_config5_step, fp16=gen_fp16, generator_small1024=gen_generator_small1024,
-            generator_grads64=gen_generator_grads64)
+            generator_grads64=gen_generator_grads64, fp16_fused=gen_fp16_fused)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
