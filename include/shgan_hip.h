@@ -36,6 +36,13 @@ int shg_upfirdn2d_out_size(int H, int W, int fh, int fw, int upx, int upy, int d
                            int pady0, int pady1, int* OH, int* OW);
 int shg_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx, int upy,
                       int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
+/* the same operator over the plugin's whole operand range (upfirdn2d.cpp:38-59: any strides, AT_DISPATCH_FLOATING_TYPES_AND_HALF):
+ * dtype 0 float32 / 1 float16 / 2 float64 (accumulation float, float64: double); x_strides / y_strides = element strides (n, c, h, w);
+ * f float32 [fh,fw] with element strides f_stride_y / f_stride_x.  Serves float64, float32 channels_last, float16 NCHW and views
+ * without a conversion pass; the two dense network layouts keep their streaming kernels (shg_upfirdn2d_f32 / _f16). */
+int shg_upfirdn2d_strided(const void* x, const float* f, void* y, int dtype, int N, int C, int H, int W, const long* x_strides,
+                          const long* y_strides, int fh, int fw, long f_stride_y, long f_stride_x, int upx, int upy, int downx, int downy,
+                          int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
 /* upfirdn2d fused with the tail of an up-sampling synthesis layer (stylegan.py:295-304, comodgan.py:326-327):
  * y = lrelu_agc(FIR(x)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.
  * noise_mode 0 none, 1 noise [OH,OW], 2 noise [N,OH,OW]; act 0 none / 1 lrelu_agc; clamp < 0 = no clamp. */

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -37,6 +37,8 @@ _SIGS = {
     'shg_device_info': [c_i, ctypes.c_char_p, c_i],
     'shg_upfirdn2d_out_size': [c_i] * 12 + [ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
     'shg_upfirdn2d_f32': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp],
+    'shg_upfirdn2d_strided': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(c_l), ctypes.POINTER(c_l), c_i, c_i, c_l, c_l] + [c_i] * 9
+                             + [c_f, c_fp],
     'shg_upfirdn2d_epilogue_f32': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_bias_act_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp],
     'shg_fma_f32': [c_fp, c_fp, c_fp, c_fp, c_l, c_fp],

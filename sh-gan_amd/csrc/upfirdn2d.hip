@@ -451,6 +451,89 @@ extern "C" int shg_upfirdn2d_f32(const float* x, const float* f, float* y, int N
     return ufd_launch(p, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The plugin's full operand range (upfirdn2d.cpp:38-59: any strides, AT_DISPATCH_FLOATING_TYPES_AND_HALF): x and y described by their
+// element strides, dtype float32 / float16 / float64; accumulation in float (float64: in double), `v *= gain` last, as
+// upfirdn2d.cu:38,104-121.  The streaming kernels above serve the two dense layouts the networks use (float32 NCHW, float16 NHWC); this
+// one serves everything else the reference's op accepts -- float64 tensors, float32 channels_last, float16 NCHW, arbitrary views --
+// without a conversion pass.  One lane per output element, lanes ordered along the unit-stride axis of y.
+// ---------------------------------------------------------------------------------------------
+struct UfdStridedP {
+    const void* x; const float* f; void* y;
+    int N, C, H, W, OH, OW;
+    long sx[4], sy[4];           // element strides of x / y: n, c, h, w
+    int fh, fw; long fsy, fsx;   // filter extent and element strides
+    int upx, upy, dnx, dny, px0, py0, flip;
+    float gain;
+    int c_minor;                 // y has unit channel stride: lanes run over c first
+    long total;
+};
+
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void upfirdn_strided_kernel(const UfdStridedP p) {
+    const T* x = (const T*)p.x;
+    T* y = (T*)p.y;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < p.total; e += (long)gridDim.x * 256) {
+        int n, c, oy, ox;
+        long r = e;
+        if (p.c_minor) { c = (int)(r % p.C); r /= p.C; ox = (int)(r % p.OW); r /= p.OW; oy = (int)(r % p.OH); n = (int)(r / p.OH); }
+        else { ox = (int)(r % p.OW); r /= p.OW; oy = (int)(r % p.OH); r /= p.OH; c = (int)(r % p.C); n = (int)(r / p.C); }
+        const T* xp = x + n * p.sx[0] + c * p.sx[1];
+        A v = (A)0;
+        for (int ky = 0; ky < p.fh; ++ky) {
+            const int uy = oy * p.dny + ky - p.py0;
+            if (uy < 0 || (uy % p.upy) != 0) continue;
+            const int iy = uy / p.upy;
+            if (iy >= p.H) continue;
+            const int sy_ = p.flip ? ky : p.fh - 1 - ky;
+            for (int kx = 0; kx < p.fw; ++kx) {
+                const int ux = ox * p.dnx + kx - p.px0;
+                if (ux < 0 || (ux % p.upx) != 0) continue;
+                const int ix = ux / p.upx;
+                if (ix >= p.W) continue;
+                const int sx_ = p.flip ? kx : p.fw - 1 - kx;
+                v += (A)xp[iy * p.sx[2] + ix * p.sx[3]] * (A)p.f[sy_ * p.fsy + sx_ * p.fsx];
+            }
+        }
+        v *= (A)p.gain;
+        y[n * p.sy[0] + c * p.sy[1] + oy * p.sy[2] + ox * p.sy[3]] = (T)v;
+    }
+}
+
+// dtype: 0 float32, 1 float16, 2 float64.  x_strides / y_strides: four element strides (n, c, h, w) each; f [fh, fw] float32 with element
+// strides f_stride_y / f_stride_x.  y must not alias x.  Same size rule and argument meaning as shg_upfirdn2d_f32.
+extern "C" int shg_upfirdn2d_strided(const void* x, const float* f, void* y, int dtype, int N, int C, int H, int W, const long* x_strides,
+                                     const long* y_strides, int fh, int fw, long f_stride_y, long f_stride_x, int upx, int upy, int downx,
+                                     int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream) {
+    SHG_CHECK_ARG(x && f && y && x_strides && y_strides, "upfirdn2d_strided: null pointer");
+    SHG_CHECK_ARG(dtype >= 0 && dtype <= 2, "upfirdn2d_strided: dtype must be 0 (float32), 1 (float16) or 2 (float64)");
+    SHG_CHECK_ARG(N >= 1 && C >= 1 && H >= 1 && W >= 1, "upfirdn2d: x must be rank 4 and non-empty");
+    SHG_CHECK_ARG(fh >= 1 && fw >= 1, "upfirdn2d: f must be at least 1x1");                       // upfirdn2d.cpp:26
+    SHG_CHECK_ARG(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");       // :27
+    SHG_CHECK_ARG(downx >= 1 && downy >= 1, "upfirdn2d: downsampling factor must be at least 1"); // :28
+    SHG_CHECK_ARG((long)N * C * H * W <= 2147483647L, "upfirdn2d: x is too large");               // :22
+    const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx;                                // :32
+    const int OH = (H * upy + pady0 + pady1 - fh + downy) / downy;                                // :33
+    SHG_CHECK_ARG(OW >= 1 && OH >= 1, "upfirdn2d: output must be at least 1x1");                  // :34
+    SHG_CHECK_ARG((long)N * C * OH * OW <= 2147483647L, "upfirdn2d: output is too large");        // :36
+    for (int k = 0; k < 4; ++k) SHG_CHECK_ARG(x_strides[k] >= 0 && y_strides[k] >= 0, "upfirdn2d_strided: negative stride");
+    UfdStridedP p{};
+    p.x = x; p.f = f; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+    for (int k = 0; k < 4; ++k) { p.sx[k] = x_strides[k]; p.sy[k] = y_strides[k]; }
+    p.fh = fh; p.fw = fw; p.fsy = f_stride_y; p.fsx = f_stride_x;
+    p.upx = upx; p.upy = upy; p.dnx = downx; p.dny = downy; p.px0 = padx0; p.py0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
+    p.c_minor = (C > 1 && y_strides[1] == 1) ? 1 : 0;
+    p.total = (long)N * C * OH * OW;
+    long blocks = (p.total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0) hipLaunchKernelGGL((upfirdn_strided_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (dtype == 1) hipLaunchKernelGGL((upfirdn_strided_kernel<_Float16, float>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((upfirdn_strided_kernel<double, double>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 extern "C" int shg_upfirdn2d_out_size(int H, int W, int fh, int fw, int upx, int upy, int downx, int downy, int padx0,
                                       int padx1, int pady0, int pady1, int* OH, int* OW) {
     SHG_CHECK_ARG(OH && OW, "upfirdn2d_out_size: null pointer");

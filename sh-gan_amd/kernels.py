@@ -194,6 +194,40 @@ def sep_taps(f):
     return taps
 
 
+_STRIDED_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+
+
+def upfirdn2d_strided(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0):
+    """``upfirdn2d_plugin.upfirdn2d`` over the plugin's whole operand range (upfirdn2d.cpp:38-59): x of dtype float32 / float16 / float64
+    with ANY strides, read in place; y in ``x``'s suggested memory format (channels_last for a channels_last x, else NCHW), as :37."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or not isinstance(f, torch.Tensor) or not f.is_cuda:
+        raise _lib.ShgError('upfirdn2d: x and f must reside on a HIP (cuda) device: libshgan_hip has no CPU path')
+    if x.dtype not in _STRIDED_DTYPES:
+        raise _lib.ShgError(f'upfirdn2d: x must be float32, float16 or float64 (got {x.dtype})')
+    if f.dtype != torch.float32:
+        raise _lib.ShgError('upfirdn2d: f must be float32')
+    if x.ndim != 4:
+        raise _lib.ShgError('x must be rank 4')
+    if f.ndim != 2:
+        raise _lib.ShgError('f must be rank 2')
+    L = _Launch()
+    L._own(x, 'x')
+    L._own(f, 'f')
+    n, c, h, w = x.shape
+    fh, fw = f.shape
+    oh, ow = upfirdn2d_out_size(h, w, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1)
+    if oh < 1 or ow < 1:
+        raise _lib.ShgError('upfirdn2d: output must be at least 1x1')
+    cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    sx, sy = (ctypes.c_long * 4)(*x.stride()), (ctypes.c_long * 4)(*y.stride())
+    with _timed(L, 'upfirdn2d', float(x.element_size()) * (x.numel() + y.numel())):
+        check(_lib.get_lib().shg_upfirdn2d_strided(_ptr(x), _ptr(f), _ptr(y), _STRIDED_DTYPES[x.dtype], n, c, h, w, sx, sy, fh, fw, f.stride(0),
+                                                   f.stride(1), upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain),
+                                                   L.stream()), 'upfirdn2d_strided')
+    return y
+
+
 def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0,
               epilogue=None):
     """Mirror of ``upfirdn2d_plugin.upfirdn2d`` (upfirdn2d.cpp:16).  ``epilogue`` (dict) fuses

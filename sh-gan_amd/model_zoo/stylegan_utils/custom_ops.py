@@ -15,7 +15,15 @@ class _Upfirdn2dPlugin:
 
     @staticmethod
     def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
-        if x.dtype == torch.float16:         # upfirdn2d.cpp:59 AT_DISPATCH_FLOATING_TYPES_AND_HALF: halves, NHWC (torch.channels_last)
+        # upfirdn2d.cpp:38-59: any strides, AT_DISPATCH_FLOATING_TYPES_AND_HALF.  The two dense layouts of the networks (float32 NCHW, float16
+        # channels_last) take the streaming kernels; float64, and a dense tensor in the OTHER layout of its dtype (float32 channels_last,
+        # float16 NCHW), are served in place by the strided kernel with y in x's memory format (:37), not converted.
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.ndim == 4 and isinstance(f, torch.Tensor) and f.ndim == 2:
+            cl = x.is_contiguous(memory_format=torch.channels_last)
+            if (x.dtype == torch.float64 or (x.dtype == torch.float32 and cl and not x.is_contiguous())
+                    or (x.dtype == torch.float16 and x.is_contiguous() and not cl)):
+                return kernels.upfirdn2d_strided(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+        if x.dtype == torch.float16:         # halves, NHWC (torch.channels_last)
             return kernels_f16.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
         return kernels.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
 

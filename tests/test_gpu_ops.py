@@ -636,3 +636,87 @@ def test_fir_march_at_baseline_sizes_vs_tiled_kernels(mods):
     yd = ufd.upfirdn2d(ones, f, down=2, padding=[1, 1, 1, 1])
     yu = ufd.upfirdn2d(ones[:, :, :128, :128], f, up=2, padding=[2, 1, 2, 1], gain=4)
     assert float((yd[:, :, 1:-1, 1:-1] - 1.0).abs().max()) < 1e-6 and float((yu[:, :, 2:-2, 2:-2] - 1.0).abs().max()) < 1e-6
+
+
+# ---- the native op over the plugin's whole operand range (upfirdn2d.cpp:38-59: any strides, float / double / half) -------------------------
+
+_UFD_CASES = [
+    # up, down, padding, flip, gain, filter shape
+    (1, 1, [2, 2, 2, 2], False, 1.0, (4, 4)),
+    (2, 1, [2, 1, 2, 1], False, 4.0, (4, 4)),
+    (1, 2, [1, 1, 1, 1], True, 1.0, (4, 4)),
+    ([2, 1], [1, 3], [3, 0, -1, 2], True, 0.75, (3, 5)),
+    (3, 2, [0, 4, 2, 1], False, 2.5, (6, 2)),
+]
+
+
+@pytest.mark.parametrize('layout', ['f64_nchw', 'f64_cl', 'f32_cl', 'f16_nchw', 'f32_view', 'f64_view'])
+def test_native_op_serves_every_dtype_and_layout_of_the_plugin(mods, layout):
+    """``upfirdn2d_plugin.upfirdn2d`` accepts float32 / float16 / float64 tensors with any strides and returns y in x's suggested memory
+    format (upfirdn2d.cpp:37-59).  The streaming kernels cover the two dense network layouts; ``shg_upfirdn2d_strided`` serves the rest in
+    place: checked against the oracle's float64 evaluation of upfirdn2d.py:98-138 on the same (rounded) operands, incl. a non-contiguous
+    FILTER view (the op passes the filter's strides, :48), asymmetric / negative padding and per-axis factors."""
+    from shgan_amd.model_zoo.stylegan_utils import custom_ops
+    plugin = custom_ops.get_plugin('upfirdn2d_plugin')
+    orc = mods['orc']
+    rs = np.random.RandomState(11)
+    dt = {'f64': torch.float64, 'f32': torch.float32, 'f16': torch.float16}[layout[:3]]
+    tol = {'f64': 1e-13, 'f32': 2e-6, 'f16': 1.5e-3}[layout[:3]]
+    for up, down, pad, flip, gain, fs in _UFD_CASES:
+        x = torch.from_numpy(rs.standard_normal((2, 6, 9, 11))).to(dt)
+        if layout.endswith('_cl'):
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        elif layout.endswith('_view'):
+            big = torch.from_numpy(rs.standard_normal((2, 9, 12, 16))).to(dt).to(DEV)
+            xd = big[:, 1:7, 2:11, 3:14:1]                       # a strided window of a larger tensor: neither layout is dense
+            x = xd.cpu()
+        else:
+            xd = x.to(DEV)
+        # a filter that is a transposed view: stride(0) = 1 (the op reads it through its strides)
+        fT = torch.from_numpy(rs.standard_normal((fs[1], fs[0])).astype(np.float32)).to(DEV)
+        f = fT.t()
+        assert not f.is_contiguous() or 1 in fs
+        upx, upy = (up, up) if isinstance(up, int) else up
+        dnx, dny = (down, down) if isinstance(down, int) else down
+        y = plugin.upfirdn2d(xd, f, upx, upy, dnx, dny, pad[0], pad[1], pad[2], pad[3], flip, gain)
+        ref = orc.upfirdn2d(x.double(), f.cpu().contiguous().double(), up=[upx, upy], down=[dnx, dny], padding=pad, flip_filter=flip, gain=gain)
+        assert y.dtype == dt and tuple(y.shape) == tuple(ref.shape), (layout, up, down)
+        if layout.endswith('_cl'):
+            assert y.is_contiguous(memory_format=torch.channels_last)                      # upfirdn2d.cpp:37 suggest_memory_format
+        else:
+            assert y.is_contiguous()
+        e = rel_err(c(y.double()), ref.numpy())
+        assert e < tol, (layout, up, down, pad, e)
+
+
+def test_public_upfirdn2d_in_float64_passes_gradcheck_first_and_second_order(mods):
+    """The public operator (upfirdn2d.py:141-192 semantics: its gradient is the same op with up / down exchanged and the filter flipped)
+    on float64 tensors, now that the native op takes them: torch.autograd.gradcheck / gradgradcheck against finite differences."""
+    ufd = mods['ufd']
+    rs = np.random.RandomState(12)
+    f = ufd.setup_filter([1, 3, 3, 1]).to(DEV)
+    f1 = ufd.setup_filter([1, 2, 1], separable=True).to(DEV)
+    with torch.enable_grad():
+        for kw in (dict(up=2, padding=[2, 1, 2, 1], gain=4.0), dict(down=2, padding=[1, 1, 1, 1]), dict(padding=[2, 2, 2, 2], flip_filter=True)):
+            x = torch.from_numpy(rs.standard_normal((1, 2, 5, 6))).to(DEV).requires_grad_(True)
+            fn = lambda t: ufd.upfirdn2d(t, f, **kw)          # noqa: E731
+            assert fn(x).dtype == torch.float64
+            assert torch.autograd.gradcheck(fn, (x,), eps=1e-6, atol=1e-7, rtol=1e-6, nondet_tol=0.0)
+            assert torch.autograd.gradgradcheck(fn, (x,), eps=1e-6, atol=1e-7, rtol=1e-6, nondet_tol=0.0)
+        assert f1.ndim == 1                                   # separable: one pass per axis (upfirdn2d.py:164-168)
+        x = torch.from_numpy(rs.standard_normal((1, 2, 5, 6))).to(DEV).requires_grad_(True)
+        assert torch.autograd.gradcheck(lambda t: ufd.upfirdn2d(t, f1, up=2, padding=[1, 1, 1, 1]), (x,), eps=1e-6, atol=1e-7, rtol=1e-6)
+
+
+def test_strided_native_op_rejects_bad_arguments(mods):
+    k = mods['kernels']
+    from shgan_amd import _lib
+    f = torch.ones(2, 2, device=DEV)
+    with pytest.raises(_lib.ShgError):
+        k.upfirdn2d_strided(torch.zeros(1, 2, 4, 4, device=DEV, dtype=torch.int32), f)
+    with pytest.raises(_lib.ShgError):
+        k.upfirdn2d_strided(torch.zeros(1, 2, 4, 4, device=DEV, dtype=torch.float64), f.double())
+    with pytest.raises(_lib.ShgError):
+        k.upfirdn2d_strided(torch.zeros(1, 2, 1, 1, device=DEV, dtype=torch.float64), torch.ones(4, 4, device=DEV))         # empty output
+    with pytest.raises(_lib.ShgError):
+        k.upfirdn2d_strided(torch.zeros(1, 2, 4, 4, dtype=torch.float64), torch.ones(2, 2))                                  # CPU tensors

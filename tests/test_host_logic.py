@@ -166,7 +166,7 @@ def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
 
 
 def test_round5_entry_points_validate_their_arguments_without_a_gpu():
-    """The entry points added with ABI 29-33 (Winograd-domain weight gradient, the fp16 route switch, the two glue kernels): geometry
+    """The entry points added with ABI 29-34 (Winograd-domain weight gradient, the fp16 route switch, the two glue kernels): geometry
     gates, workspace planning and argument checks are host code -- exercised here without a device."""
     lib = _lib.get_lib()
     P = ctypes.c_void_p(16)
@@ -199,6 +199,17 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.shg_sum_partials_f32(P, P, 1, 0, 64, None) == -1
     assert lib.shg_scale_cast_f32_f16(None, P, 16, 1.0, 1, None) == -1 and lib.shg_scale_cast_f32_f16(P, P, -1, 1.0, 1, None) == -1
     assert lib.shg_scale_cast_f32_f16(P, P, 0, 1.0, 1, None) == 0                      # empty: nothing launched
+    # the native op over the plugin's whole operand range (ABI 34): dtype code, strides, the size rule of upfirdn2d.cpp:26-36
+    st = (ctypes.c_long * 4)(96, 16, 4, 1)
+    ufs = lib.shg_upfirdn2d_strided
+    assert ufs(P, P, P, 3, 1, 6, 4, 4, st, st, 4, 4, 4, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None) == -1 and b'dtype' in lib.shg_last_error()
+    assert ufs(P, P, P, 2, 1, 6, 4, 4, None, st, 4, 4, 4, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None) == -1 and b'null' in lib.shg_last_error()
+    assert ufs(P, P, P, 2, 1, 6, 4, 4, st, st, 4, 4, 4, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None) == -1 and b'upsampling' in lib.shg_last_error()
+    assert ufs(P, P, P, 0, 1, 6, 2, 2, st, st, 4, 4, 4, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None) == -1 and b'at least 1x1' in lib.shg_last_error()
+    neg = (ctypes.c_long * 4)(96, 16, -4, 1)
+    assert ufs(P, P, P, 0, 1, 6, 4, 4, neg, st, 2, 2, 2, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, None) == -1 and b'stride' in lib.shg_last_error()
+    with pytest.raises(_lib.ShgError):
+        kernels.upfirdn2d_strided(torch.zeros(1, 2, 4, 4, dtype=torch.float64), torch.ones(2, 2))
     with pytest.raises(_lib.ShgError):
         kernels.sum_partials(torch.zeros(2, 4, 64))
     with pytest.raises(_lib.ShgError):
