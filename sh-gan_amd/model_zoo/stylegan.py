@@ -310,6 +310,9 @@ class _StyleFactorsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gsn, gd):
         styles, wsq, sn, d, aux = ctx.saved_tensors
+        if torch.is_grad_enabled() and CLOSED_STYLE_FACTORS_BACKWARD:
+            gs, gw = _StyleFactorsBwdFn.apply(styles, wsq, gsn, gd, sn, d, aux, ctx.half)
+            return (gs if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), None
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 s_in = styles if styles.requires_grad else styles.detach().requires_grad_(True)
@@ -321,6 +324,79 @@ class _StyleFactorsFn(torch.autograd.Function):
         return (gs if ctx.needs_input_grad[0] else None), gw, None
 
 
+class _StyleFactorsBwdFn(torch.autograd.Function):
+    """The first-order backward of ``_StyleFactorsFn`` as ONE differentiable node (path-length regulariser: the gradient with respect to
+    the styles is differentiated again).  Forward = the two backward kernels.  Backward = the closed form of the second derivative,
+    about forty small launches on this package's kernels, instead of re-deriving (sn, d) from tensor operators under ``create_graph``
+    and letting autograd differentiate ~36 recorded operators per layer twice (~1 300 launches of a Greg pass).
+
+    With m = mean(s^2), r = m^-1/2, c = r^3 / M, sn = r s, u = sn^2, e = u W^T + eps, d = e^-1/2 and incoming (gsn, gd):
+        q = -1/2 gd d^3,  t = gsn + 2 sn (q W),  gs = r t - c <t,s> s,  gW = q^T u                     (the first-order backward)
+    and for cotangents (a, b) of (gs, gW), with alpha = <a,s>, tau = <t,s>, kappa = <t,a>, abar = r a - c alpha s:
+        h = (2 sn abar) W^T + u b^T,  ggsn = abar,  ggd = -1/2 d^3 h,  p = 3/4 gd d^5 h,
+        g_sn = 2 abar (q W) + 2 sn (q b) + 2 sn (p W),
+        gs2 = r g_sn - c <g_sn,s> s - c kappa s + 3 r^5 / M^2 alpha tau s - c tau a - c alpha t,  gW2 = q^T (2 sn abar) + p^T u.
+    float16 rows divide each sample's styles by their max-norm first (stylegan.py:138): the chain rule through s / max|s| (one-hot at the
+    arg-max) is applied on both sides.  Checked against torch's float64 double backward (tests/test_gpu_train_graph.py)."""
+    @staticmethod
+    def forward(ctx, styles, wsq, gsn, gd, sn, d, aux, half):
+        gs, gw = kernels.style_factors_backward(sn, d, wsq.detach(), aux, gsn.detach().contiguous(), gd.detach().contiguous(), half, want_wsq=True)
+        ctx.save_for_backward(styles, wsq, gsn, gd)
+        ctx.half = half
+        return gs, gw
+
+    @staticmethod
+    def backward(ctx, a, b):
+        styles, wsq, gsn, gd = ctx.saved_tensors
+        if torch.is_grad_enabled():          # third order: differentiate the composed operators
+            with torch.enable_grad():
+                ins = [t if t.requires_grad else t.detach().requires_grad_(True) for t in (styles, wsq, gsn, gd)]
+                sn2, d2 = _style_factors_composed(ctx.half, ins[0], ins[1])
+                gs, gw = torch.autograd.grad([sn2, d2], ins[:2], [ins[2], ins[3]], create_graph=True)
+                out = torch.autograd.grad([gs, gw], ins, [a, b], create_graph=True, allow_unused=True)
+            return (*[o if need else None for o, need in zip(out, ctx.needs_input_grad[:4])], None, None, None, None)
+        nt, nn = kernels.dense, kernels.matmul_nn
+        s, W = styles.detach(), wsq.detach()
+        gsn, gd = gsn.detach(), gd.detach()
+        if ctx.half:
+            mu, k = s.abs().max(dim=1, keepdim=True)
+            sig = torch.gather(s, 1, k).sign()
+            s0, a0, ak = s, a, torch.gather(a, 1, k)
+            a = a / mu - s * (sig * ak / mu ** 2)
+            s = s / mu
+        m_count = s.numel()
+        r = s.square().mean().rsqrt()
+        c = r ** 3 / m_count
+        sn = s * r
+        u = sn * sn
+        d = (nt(u, W) + 1e-8).rsqrt()
+        d3 = d ** 3
+        q = -0.5 * gd * d3
+        qp_w = None
+        alpha = (a * s).sum()
+        abar = r * a - (c * alpha) * s
+        sa2 = 2 * sn * abar
+        h = nt(torch.cat([sa2, u], 1), torch.cat([W, b], 1))                    # (2 sn abar) W^T + u b^T in one launch
+        ggd = -0.5 * d3 * h
+        pq = 0.75 * gd * d3 * d * d * h
+        qp_w = nn(torch.cat([q, pq]), W)                                      # [q; p] W
+        n = s.shape[0]
+        q_w, p_w = qp_w[:n], qp_w[n:]
+        t = gsn + 2 * sn * q_w
+        tau, kappa = (t * s).sum(), (t * a).sum()
+        g_sn = 2 * (abar * q_w + sn * (nn(q, b) + p_w))
+        gs2 = r * g_sn - (c * ((g_sn * s).sum() + kappa) - (3 * r ** 5 / m_count ** 2) * alpha * tau) * s - (c * tau) * a - (c * alpha) * t
+        gw2, _ = kernels.matmul_tn(torch.cat([q, pq]), torch.cat([sa2, u]))   # q^T (2 sn abar) + p^T u
+        if ctx.half:
+            g1 = r * t - (c * tau) * s                                        # first-order gradient in the pre-normalised space
+            corr = (-sig * ((gs2 * s0).sum(1, keepdim=True) + (a0 * g1).sum(1, keepdim=True)) / mu ** 2
+                    + 2 * ak * (s0 * g1).sum(1, keepdim=True) / mu ** 3)
+            gs2 = (gs2 / mu - (sig * ak / mu ** 2) * g1).scatter_add(1, k, corr)
+        need = ctx.needs_input_grad
+        return (gs2 if need[0] else None), (gw2 if need[1] else None), (abar if need[2] else None), (ggd if need[3] else None), None, None, None, None
+
+
+CLOSED_STYLE_FACTORS_BACKWARD = os.environ.get('SHG_CLOSED_STYLE_BWD', '1') == '1'    # (A/B switch; 0: the composed double backward)
 FUSED_STYLE_FACTORS = os.environ.get('SHG_FUSED_STYLE', '1') == '1'       # (A/B switch; SHG_FUSED_STYLE=0: the tensor-op composition)
 
 

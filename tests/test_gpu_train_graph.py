@@ -419,6 +419,48 @@ def test_fused_style_factors_vs_float64_autograd(half, n, i, o):
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize('half,n,i,o', [(False, 4, 512, 512), (True, 4, 128, 64), (False, 8, 64, 128), (True, 3, 40, 24), (False, 1, 32, 3)])
+def test_closed_double_backward_of_the_style_factors_vs_float64_autograd(half, n, i, o):
+    """``_StyleFactorsBwdFn`` (the first-order backward of the style factors as one node whose own backward is the closed form of the
+    second derivative): gradients of <A, g_styles> + <B, g_wsq> with respect to the styles, the weight squares AND the incoming
+    gradients, against torch's float64 double backward of the tensor-op formulation (stylegan.py:138,147,155) -- and against the composed
+    route of this package (switch off).  Reference pin of the users: the path-length phase of tests/test_gpu_config5.py."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd.model_zoo import stylegan as sg
+    g = torch.Generator(device='cpu').manual_seed(n * 977 + i + 3 * o)
+    mk = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64).to(DEV)           # noqa: E731
+    s64, w64 = mk(n, i) + 1.0, torch.rand(o, i, generator=g, dtype=torch.float64).to(DEV) * 0.01
+    a64, b64, A64, B64 = mk(n, i), mk(n, o), mk(n, i), mk(o, i)
+
+    def ref(s, w):
+        if half:
+            s = s / s.norm(float('inf'), dim=1, keepdim=True)
+        s = s * s.square().mean().rsqrt()
+        return s, (s.square().matmul(w.t()) + 1e-8).rsqrt()
+
+    def run(fn, dt):
+        s, w, a, b = (t.to(dt).clone().requires_grad_(True) for t in (s64, w64, a64, b64))
+        with torch.enable_grad():
+            sn, d = fn(s, w)
+            gs, gw = torch.autograd.grad([sn, d], [s, w], [a, b], create_graph=True)
+            phi = (gs * A64.to(dt)).sum() + (gw * B64.to(dt)).sum()
+            return [gs.detach(), gw.detach()] + list(torch.autograd.grad(phi, [s, w, a, b]))
+    want = run(ref, torch.float64)
+    fused = lambda s, w: sg._StyleFactorsFn.apply(s, w, half)                               # noqa: E731
+    assert sg.CLOSED_STYLE_FACTORS_BACKWARD
+    got = run(fused, torch.float32)
+    sg.CLOSED_STYLE_FACTORS_BACKWARD = False
+    try:
+        composed = run(fused, torch.float32)
+    finally:
+        sg.CLOSED_STYLE_FACTORS_BACKWARD = True
+    names = ('g_styles', 'g_wsq', 'second-order: styles', 'wsq', 'incoming g_sn', 'incoming g_d')
+    for name, x, y, z in zip(names, got, want, composed):
+        err, err_c = rel_err(x.double().cpu(), y.cpu()), rel_err(z.double().cpu(), y.cpu())
+        assert err < 5e-5, (name, err, err_c)
+        assert err < 4 * err_c + 1e-5, (name, err, err_c)          # (no worse than the composed float32 route it replaces)
+
+
 @pytest.mark.parametrize('fp16', [False, True])
 def test_residual_block_input_gradients_joined_in_the_convolution_kernel(fp16):
     """``grad_ops.InputGradJoin``: in the critic's residual blocks the skip branch's input gradient is added by conv0's input-gradient

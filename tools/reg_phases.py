@@ -1,6 +1,6 @@
 """The lazy-regulariser phases (Greg: path length on batch / 2, Dreg: R1) of BASELINE config 5 at full width, one pass each: HIP-event time,
 library (aten::) operators with their device time and launch count, and this package's kernel classes (kernels.KernelTimer).
-usage: python tools/reg_phases.py [--fp16] [--phases Greg,Dreg,Gmain,Dmain]"""
+usage: python tools/reg_phases.py [--fp16] [--phases Greg,Dreg,Gmain,Dmain] [--ab-tail | --ab-style]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -19,8 +19,9 @@ real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
 L = losses.InpaintingLoss(DEV, G, D, noise_mode='random', style_mixing_prob=0.9)
 z, c = torch.randn(8, 512, device=DEV), torch.zeros(8, 0, device=DEV)
 names = sys.argv[sys.argv.index('--phases') + 1].split(',') if '--phases' in sys.argv else ['Greg', 'Dreg']
-if '--ab-tail' in sys.argv:          # same process, alternating: the closed tail-backward node against the tensor-operator composition
+if '--ab-tail' in sys.argv or '--ab-style' in sys.argv:          # same process, alternating: a closed backward node against the tensor-operator composition
     from shgan_amd.model_zoo.stylegan_utils import grad_ops
+    from shgan_amd.model_zoo import stylegan as _sg
     for phase in names:
         mod = G if phase.startswith('G') else D
 
@@ -33,7 +34,10 @@ if '--ab-tail' in sys.argv:          # same process, alternating: the closed tai
         ts = {True: [], False: []}
         for rep in range(5):
             for closed in (True, False):
-                grad_ops.CLOSED_TAIL_BACKWARD = closed
+                if '--ab-style' in sys.argv:
+                    _sg.CLOSED_STYLE_FACTORS_BACKWARD = closed
+                else:
+                    grad_ops.CLOSED_TAIL_BACKWARD = closed
                 run(); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
