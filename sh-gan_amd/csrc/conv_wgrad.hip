@@ -348,10 +348,71 @@ static int wgrad_slices(int NB, int I, int O, int OH, int OW, int taps) {
     return s < 1 ? 1 : (int)s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thin 1x1 layers (fromRGB: 4 -> 64, toRGB: C -> 3): dw[o, i] = sum_{n, p} g[n, o, p] x[n, i, p] with one side of at most 8 channels is a
+// STREAMING problem -- read the fat tensor once (1.07 GB for the critic's fromRGB at 512^2 x 16: 215 us at the rate the pointwise kernels
+// reach) -- that the MFMA tiles above served at 2.5x that (553 us: one (o, i) tile, channels padded to the tile, parallel only over pixel
+// slices).  Here a wave owns IT x 256 pixels of one image (its thin-side values stay in registers), walks 64 fat channels with
+// coalesced 16-byte loads, and reduces each channel's T dot products across its lanes; a workgroup = 4 waves = 4 adjacent pixel segments,
+// blockIdx.y = the 64-channel block.  Partial sums [pixel chunk][O x I] -> the fixed-order reduction above (deterministic).
+// ---------------------------------------------------------------------------------------------
+template <int TT, int IT>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* fat, const float* thin, float* part, int C, int T, int HW, int chunks_per_n,
+                                                         int out_sc, int out_st, int OI) {
+    __shared__ float tab[4][64][TT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x / chunks_per_n, ch = blockIdx.x - n * chunks_per_n;
+    const long p0 = ((long)ch * 4 + wave) * (IT * 256) + lane * 4;
+    float4 tv[TT][IT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+            tv[t][it] = t < T ? *reinterpret_cast<const float4*>(thin + ((long)n * T + t) * HW + p0 + it * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c0 = blockIdx.y * 64, cn = min(64, C - c0);
+    const float* fp = fat + ((long)n * C + c0) * HW + p0;
+#pragma unroll 2
+    for (int cc = 0; cc < cn; ++cc) {
+        float4 f[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) f[it] = *reinterpret_cast<const float4*>(fp + (long)cc * HW + it * 256);
+        float acc[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) a += f[it].x * tv[t][it].x + f[it].y * tv[t][it].y + f[it].z * tv[t][it].z + f[it].w * tv[t][it].w;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+            acc[t] = a;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) tab[wave][cc][t] = acc[t];
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < cn * TT; k += 256) {
+        const int cc = k / TT, t = k - cc * TT;
+        if (t < T) part[(long)blockIdx.x * OI + (long)(c0 + cc) * out_sc + (long)t * out_st] = (tab[0][cc][t] + tab[1][cc][t]) + (tab[2][cc][t] + tab[3][cc][t]);
+    }
+}
+
+// pixel chunks of the thin form (0: the layer is not one -- 1x1, stride 1, one side of at most 8 channels, whole 1024-pixel workgroup chunks)
+static int wgrad_thin_chunks(int NB, int I, int O, int H, int W, int OH, int OW, int kh, int kw, int stride, int pad) {
+    if (kh != 1 || kw != 1 || stride != 1 || pad != 0 || H != OH || W != OW) return 0;
+    if ((I > 8 && O > 8) || ((long)H * W) % 1024 != 0) return 0;
+    const long hw = (long)H * W;
+    const long chunks = (long)NB * (hw % 4096 == 0 ? hw / 4096 : hw / 1024);
+    return chunks <= 8192 ? (int)chunks : 0;
+}
+
 // bytes of scratch shg_conv2d_wgrad_f32 needs for this problem (0: none)
 extern "C" size_t shg_conv2d_wgrad_workspace_bytes(int NB, int I, int O, int OH, int OW, int kh, int kw) {
     const int s = wgrad_slices(NB, I, O, OH, OW, kh * kw);
-    return s > 1 ? (size_t)s * O * I * kh * kw * sizeof(float) : 0;
+    size_t need = s > 1 ? (size_t)s * O * I * kh * kw * sizeof(float) : 0;
+    const size_t thin = (size_t)wgrad_thin_chunks(NB, I, O, OH, OW, OH, OW, kh, kw, 1, 0) * O * I * sizeof(float);      // (taken when stride 1, pad 0)
+    return thin > need ? thin : need;
 }
 
 // dw [O, I, kh, kw] = weight gradient of y = conv2d(x [NB,I,H,W], w, stride, pad) given g = dL/dy [NB,O,OH,OW];
@@ -364,6 +425,26 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     SHG_CHECK_ARG(stride == 1 || stride == 2, "conv2d_wgrad: stride 1 or 2");
     SHG_CHECK_ARG(pad >= 0 && (OH - 1) * stride - pad + kh - 1 < H + pad && (OW - 1) * stride - pad + kw - 1 < W + pad,
                   "conv2d_wgrad: output extent does not match x, stride and padding");
+    const int thin_chunks = wgrad_thin_chunks(NB, I, O, H, W, OH, OW, kh, kw, stride, pad);
+    if (thin_chunks > 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && workspace &&
+        ws_bytes >= (size_t)thin_chunks * O * I * sizeof(float)) {
+        const bool thin_in = I <= O;                               // fat side: the gradient (fromRGB) or the activations (toRGB)
+        const float* fat = thin_in ? g : x;
+        const float* thin = thin_in ? x : g;
+        const int C = thin_in ? O : I, T = thin_in ? I : O, HW = H * W, it4 = HW % 4096 == 0;
+        const int cpn = thin_chunks / NB, sc = thin_in ? I : 1, st = thin_in ? 1 : I;
+        const dim3 grid(thin_chunks, shg_cdiv(C, 64));
+        hipStream_t s = (hipStream_t)stream;
+        float* part = (float*)workspace;
+        if (T <= 4 && it4) hipLaunchKernelGGL((wgrad_thin_kernel<4, 4>), grid, dim3(256), 0, s, fat, thin, part, C, T, HW, cpn, sc, st, O * I);
+        else if (T <= 4) hipLaunchKernelGGL((wgrad_thin_kernel<4, 1>), grid, dim3(256), 0, s, fat, thin, part, C, T, HW, cpn, sc, st, O * I);
+        else if (it4) hipLaunchKernelGGL((wgrad_thin_kernel<8, 4>), grid, dim3(256), 0, s, fat, thin, part, C, T, HW, cpn, sc, st, O * I);
+        else hipLaunchKernelGGL((wgrad_thin_kernel<8, 1>), grid, dim3(256), 0, s, fat, thin, part, C, T, HW, cpn, sc, st, O * I);
+        SHG_CHECK_LAUNCH();
+        launch_wgrad_reduce(part, dw, (long)O * I, thin_chunks, s);
+        SHG_CHECK_LAUNCH();
+        return SHG_OK;
+    }
     WgradParams p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
     const bool packed = wgrad_packed(OW, OH, W, kh, stride, pad);

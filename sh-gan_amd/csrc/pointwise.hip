@@ -160,16 +160,20 @@ extern "C" int shg_fma_f32(const float* a, const float* b, const float* c, float
 template <int MAXI>
 __global__ __launch_bounds__(256) void conv1x1_small_i_kernel(const float* x, const float* w, const float* bias, float* y, int I,
                                                               int O, int HW, float wgain, int act, float alpha, float gain,
-                                                              float clamp) {
-    // fromrgb: each thread owns 4 consecutive pixels of one sample, loops over all output channels
-    const int n = blockIdx.y;
-    const long p4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+                                                              float clamp, int PB, int OC) {
+    // fromrgb / the toRGB input gradient: a thread owns 4 consecutive pixels of one sample and walks output channels.  A workgroup =
+    // PB pixel groups (a power of two <= 256) x 256 / PB channel slices of the OC channels blockIdx.z selects: low resolutions (3 -> 512
+    // at 64^2 and below: 8-32 workgroups of 512 serial stores per thread, 230-250 us whatever the size) spread their channels over
+    // the grid instead; the arithmetic per output is unchanged.
+    const int n = blockIdx.y, pl = threadIdx.x & (PB - 1), osl = threadIdx.x / PB, S = 256 / PB;
+    const long p4 = ((long)blockIdx.x * PB + pl) * 4;
     if (p4 >= HW) return;
     float4 xv[MAXI];
 #pragma unroll
     for (int i = 0; i < MAXI; ++i)
         xv[i] = i < I ? *reinterpret_cast<const float4*>(x + ((long)n * I + i) * HW + p4) : make_float4(0, 0, 0, 0);
-    for (int o = 0; o < O; ++o) {
+    const int o_end = min(O, ((int)blockIdx.z + 1) * OC);
+    for (int o = blockIdx.z * OC + osl; o < o_end; o += S) {
         float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
@@ -192,9 +196,18 @@ extern "C" int shg_conv1x1_thin_in_f32(const float* x, const float* w, const flo
     SHG_CHECK_ARG(I >= 1 && I <= 8, "conv1x1_thin_in: I must be in 1..8 (got %d)", I);
     SHG_CHECK_ARG(HW % 4 == 0, "conv1x1_thin_in: H*W must be a multiple of 4");
     SHG_CHECK_ARG(N >= 1 && N <= 65535, "conv1x1_thin_in: bad N");
-    dim3 grid(shg_cdiv(HW / 4, 256), N);
+    const int P4 = HW / 4;
+    int PB = 256;
+    if (P4 < 256) { PB = 1; while (PB < P4) PB <<= 1; }
+    const int gx = shg_cdiv(P4, PB), S = 256 / PB;
+    long oz = shg_cdiv(2048, gx * N);                              // aim at >= 2048 workgroups; a workgroup takes at least one channel per slice
+    if (oz < 1) oz = 1;
+    int OC = shg_cdiv(O, (int)(oz > O ? O : oz));
+    if (OC < S) OC = S;
+    if (OC > O) OC = O;
+    dim3 grid(gx, N, shg_cdiv(O, OC));
     hipLaunchKernelGGL((conv1x1_small_i_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, I, O, HW, wgain, act,
-                       alpha, gain, clamp);
+                       alpha, gain, clamp, PB, OC);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

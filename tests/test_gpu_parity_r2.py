@@ -73,6 +73,22 @@ def test_thin_conv1x1_and_dense_activation_arguments(mods, act, alpha, act_gain,
     assert rel_err(c(yd), refd.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('n,i,o,h,w', [(8, 3, 512, 4, 4), (2, 3, 512, 8, 8), (3, 3, 70, 2, 6), (8, 3, 512, 64, 64), (1, 4, 64, 34, 50), (2, 8, 33, 16, 16),
+                                       (5, 1, 7, 2, 2), (2, 3, 256, 128, 128), (70, 3, 16, 4, 4)])
+def test_thin_conv1x1_every_grid_shape(mods, n, i, o, h, w):
+    """``conv1x1_thin_in`` (fromRGB and the toRGB input gradient: 3 -> C at EVERY resolution of the synthesis network) spreads its output
+    channels over the grid when the image is small (workgroup = pixel groups x channel slices): every (pixels, channels, batch) regime
+    against a float64 einsum, bias and activation on."""
+    orc, k = mods['orc'], mods['kernels']
+    rs = np.random.RandomState(n * 31 + o)
+    x, wt, b = rnd(rs, n, i, h, w), rnd(rs, o, i), rnd(rs, o)
+    ref = torch.einsum('oi,nihw->nohw', wt.double() * 0.7, x.double()) + b.double().view(1, -1, 1, 1)
+    y = k.conv1x1_thin_in(x.to(DEV), wt.to(DEV), b.to(DEV), wgain=0.7, act=False, gain=1.0)
+    assert tuple(y.shape) == (n, o, h, w) and rel_err(c(y), ref.numpy()) < 2e-6
+    ya = k.conv1x1_thin_in(x.to(DEV), wt.to(DEV), b.to(DEV), wgain=0.7, act=True, gain=0.5)
+    assert rel_err(c(ya), orc.lrelu_agc(ref, gain=0.5).numpy()) < 2e-6
+
+
 def test_bias_act_all_operand_combinations(mods):
     """y = act((x*scale) + noise*strength + bias) + residual with every subset of the optional operands
     (stylegan.py:175-180,232-238; common/utils.py:135-143)."""

@@ -63,3 +63,22 @@ def test_wgrad_wino_geometry_gate(kk):
     x, g = torch.randn(2, 16, 8, 6, device=DEV), torch.randn(2, 24, 8, 6, device=DEV)
     ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (24, 16, 3, 3), g.double().cpu(), stride=1, padding=1)
     assert rel_err(kk.conv2d_wgrad(x, g, 3, 3, 1, 1).cpu().numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('n,i,o,h,w', [(2, 4, 64, 32, 32), (3, 64, 3, 64, 64), (2, 128, 3, 32, 64), (1, 8, 8, 32, 32), (2, 5, 70, 64, 64), (8, 4, 64, 128, 128),
+                                       (2, 3, 512, 32, 32), (2, 200, 1, 64, 32), (2, 4, 64, 30, 34), (1, 9, 9, 32, 32)])
+def test_thin_1x1_weight_gradient_streaming_kernel_vs_float64(n, i, o, h, w):
+    """fromRGB / toRGB weight gradients (1x1, one side of at most 8 channels: ``wgrad_thin_kernel``, csrc/conv_wgrad.hip -- the fat tensor
+    is streamed once, per-wave dot products reduced across lanes, fixed-order sum of the pixel chunks) against torch's float64 weight
+    gradient; the last two shapes stay on the MFMA-tile kernel (pixels not in whole 1024-chunks / both sides wider than 8)."""
+    import shgan_amd  # noqa: F401
+    from shgan_amd import kernels
+    g = torch.Generator(device='cpu').manual_seed(n * 131 + i * 7 + o)
+    x = torch.randn(n, i, h, w, generator=g).to(DEV)
+    gy = torch.randn(n, o, h, w, generator=g).to(DEV)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (o, i, 1, 1), gy.double())
+    got = kernels.conv2d_wgrad(x, gy, 1, 1, 1, 0)
+    assert tuple(got.shape) == (o, i, 1, 1)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    again = kernels.conv2d_wgrad(x, gy, 1, 1, 1, 0)
+    assert torch.equal(got, again)                      # deterministic: fixed reduction order
