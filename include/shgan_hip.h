@@ -105,6 +105,15 @@ int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale, float* wu
 int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
                         const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
                         float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* stream);
+/* the same with scratch for a split along the input channels: a workgroup owns one (tile, 64 output channels) pair, so 512-channel layers
+ * at 16^2 (32^2 for the F(4x4) form below) are 32-128 workgroups for batches 4-16 and take the same time at every batch; with
+ * `workspace` of shg_conv2d_wino_workspace_bytes (0: the problem fills the chip, nothing is split) the channel chunks are cut into
+ * slices, partial outputs summed and the layer tail applied by a second small launch.  Same result up to the order of the fp32 sums. */
+size_t shg_conv2d_wino_workspace_bytes(int NB, int I, int O, int OP, int H, int W);
+int shg_conv2d_wino_ws_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                           const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
+                           float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* workspace,
+                           size_t ws_bytes, void* stream);
 /* Winograd F(4x4,3x3) form of the same convolution (conv_wino4.hip; 4x fewer MFMA flops than the direct form, about 1e-5
  * relative round-off per layer): wu has shg_conv_wino4_weight_elems(OP, I) floats, [OP/64][ceil(I/8)][4][72][64] in the
  * register layout of the kernel.  shg_conv2d_wino4_supported tells whether the geometry is served (H >= 16, W >= 32,
@@ -115,6 +124,12 @@ int shg_conv2d_wino4_supported(int NB, int I, int O, int H, int W);
 int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
                          const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
                          float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* stream);
+/* ... and with scratch for the split along the input channels (see shg_conv2d_wino_ws_f32): the 512-channel layers at 32^2 */
+size_t shg_conv2d_wino4_workspace_bytes(int NB, int I, int O, int OP, int H, int W);
+int shg_conv2d_wino4_ws_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                            const float* in_scale, const float* out_scale, const float* bias, const float* noise, int noise_mode,
+                            float noise_strength, int act, float alpha, float gain, float clamp, const float* residual, void* workspace,
+                            size_t ws_bytes, void* stream);
 /* mode 2 with out_mode 1 writes the four sub-pixel phases as planes [4][NB,O,H+1,W+1] (coalesced); this kernel applies the
  * 4x4 FIR of conv2d_resample.py:138 (pad 1) straight from the planes and fuses the synthesis-layer tail:
  * y [N,C,2H,2W] = lrelu_agc(FIR(mid)*gain*scale[n,c] + noise*noise_strength + bias[c]) + residual.  H, W = low-res extents. */

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -53,10 +53,14 @@ _SIGS = {
     'shg_conv_wino_chunk': [],
     'shg_conv_weight_prep_wino_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_wino_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_conv2d_wino_ws_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp, ctypes.c_size_t, c_fp],
+    'shg_conv2d_wino_workspace_bytes': [c_i] * 6,
     'shg_conv_wino4_weight_elems': [c_i, c_i],
     'shg_conv_weight_prep_wino4_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_wino4_supported': [c_i] * 5,
     'shg_conv2d_wino4_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
+    'shg_conv2d_wino4_ws_f32': [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp, ctypes.c_size_t, c_fp],
+    'shg_conv2d_wino4_workspace_bytes': [c_i] * 6,
     'shg_upfir_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_upfir_planar_sep_supported': [c_i, c_i],
     'shg_upfir_planar_sep_f32': [c_fp, ctypes.POINTER(c_f), c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],

@@ -666,7 +666,8 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
     conv_tiles(p, BO, BP, UP, XQ * NT);
     const int chunks = shg_cdiv(p.I, KC);
     int ks = conv_ksplit(p.n_ptiles * p.n_otiles, chunks, workspace != nullptr);
-    if (ks > 1 && (size_t)ks * out_elems * sizeof(float) > ws_bytes) ks = 1;      // workspace too small: no split
+    if (DB && p.n_ptiles * p.n_otiles >= conv_cu_count()) ks = 1;              // one workgroup per CU and a full round already: the tail split below handles the rest
+    while (ks > 1 && (size_t)ks * out_elems * sizeof(float) > ws_bytes) ks /= 2;  // workspace too small: the widest split that fits
     p.i_per_slice = shg_cdiv(chunks, ks) * KC;
     p.ksplit = shg_cdiv(p.I, p.i_per_slice);
     p.raw_reduce = UP ? 1 : 0;
@@ -853,7 +854,16 @@ extern "C" size_t shg_conv2d_workspace_bytes(int NB, int I, int O, int H, int W,
     const int xq = kh * kw == 1 ? 1 : (S == 1 ? 2 : (narrow ? 5 : 3));
     p.OHp = OH; p.OWp = OW; p.S = S; p.span_y = kh; p.span_x = kw;
     conv_tiles(p, narrow ? 64 : 128, narrow ? 256 : 128, false, xq * 256);
-    const int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, KC), true);
+    int ks = conv_ksplit(p.n_ptiles * p.n_otiles, shg_cdiv(I, KC), true);
+    if (kh * kw == 9 && !narrow && OW >= 32 && OH >= 8) {
+        // the double-buffered kernels of conv_dispatch own 128 x 256 tiles: half as many workgroups, so they may split twice as wide.  (Planned
+        // with the 128 x 128 tile alone, the 512-channel stride-2 layer at 65^2 -> 32^2 got scratch for 2 slices, the launch wanted 4,
+        // found too little and ran UNSPLIT: 128 workgroups on 256 CUs, 604 us at batch 8 and at batch 2 alike.)
+        ConvParams q = p;
+        conv_tiles(q, 128, 256, false, xq * 256);
+        const int ks2 = conv_ksplit(q.n_ptiles * q.n_otiles, shg_cdiv(I, KC), true);
+        if (ks2 > ks) ks = ks2;
+    }
     if (ks > 1) return (size_t)ks * NB * O * OH * OW * sizeof(float);
     return (kh * kw == 9 && !narrow && OW >= 32 && OH >= 8) ? conv_tail_ws_bound(false) : 0;
 }

@@ -45,6 +45,8 @@ struct WinoParams {
     int NB, I, O, OP, H, W;
     int tiles_x, tiles_y;    // tiles per image (8 x 32 or 16 x 16 pixels)
     int n_ttiles, n_otiles, nchunk;
+    int cps;                 // chunks per K slice (= nchunk when the launch is not split); slice = blockIdx.y
+    long part_stride;        // floats between the slices' partial outputs (0: y itself)
     int noise_mode;          // 0 none, 1 [H,W], 2 [NB,H,W]
     float noise_strength;
     int act;
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     const int oy0 = tyb * (2 * TY), ox0 = txb * (2 * TX);
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
+    // K slice of this workgroup (split launches: small grids, see shg_conv2d_wino_ws_f32): chunks c0 .. c0 + nch
+    const int c0 = blockIdx.y * p.cps, nch = min(p.cps, p.nchunk - c0);
 
     // ---- staging roles: waves 0..KC-1 transform channel `wave` of the chunk; waves KC..15 fetch the raw windows
     const bool xformer = wave < NXF;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         for (int q = 0; q < CPL; ++q) {
             const int k = (wave - NXF) * CPL + q;
             if (k >= KC) continue;
-            const int ch = c * KC + k;
+            const int ch = (c0 + c) * KC + k;
             const bool chok = ch < p.I;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     // ---- weights: wave w multiplies Winograd position w only, so its slice of U never needs to be shared -- each lane
     // loads its own MFMA A-operands of a chunk (KC floats: [k-step][channel block]) straight into registers, one chunk ahead
     constexpr int NU = KC / 4;
-    const f32x4* ubase = reinterpret_cast<const f32x4*>(p.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
     const size_t ustride = (size_t)16 * 64 * KC / 4;            // float4 per chunk
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(p.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC) + (size_t)c0 * ustride;
     f32x4 ua[NU], ub[NU];                                       // even / odd chunks
     auto load_u = [&](f32x4 (&dst)[NU], int c) __attribute__((always_inline)) {
         if (p.dbg & 1) return;
@@ -175,7 +179,8 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
         if (p.dbg & 4) return;
         // style of this wave's channel in chunk c: lane c%64 of the preloaded vector c/64
-        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
+        const int ca = c0 + c;
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca < 64 ? scv[0] : scv[1]), ca & 63));
         const float* rb = rbase + buf * R_SZ;
         // d B per window row first (two rows of LDS reads in flight at a time: keeps the live set small), then B^T (.)
         float f[4][4];
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
     load_u(ua, 0);
     if (!xformer) {
         dma_raw(0, 0);
-        if (p.nchunk > 1) dma_raw(1, 1);
+        if (nch > 1) dma_raw(1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         constexpr int PAR = decltype(par)::value;
         f32x4 (&ucur)[NU] = PAR ? ub : ua;
         f32x4 (&unxt)[NU] = PAR ? ua : ub;
-        const bool more = c + 1 < p.nchunk;
+        const bool more = c + 1 < nch;
         const float* bb = bbase + PAR * V_SZ;
         auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (more) load_u(unxt, c + 1);                          // (the previous chunk no longer reads this buffer)
         if (!xformer) {
-            if (c + 2 < p.nchunk) dma_raw(c + 2, PAR);          // raw(c) was consumed during chunk c-1
+            if (c + 2 < nch) dma_raw(c + 2, PAR);          // raw(c) was consumed during chunk c-1
         } else if (more) {
             transform(c + 1, PAR ^ 1);                          // raw(c+1) landed before the previous barrier
         }
@@ -263,9 +268,9 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();     // (unconditional: a path without it would leave the weight loads pending for the compiler's wait-count tracking)
     };
-    for (int c = 0; c < p.nchunk; c += 2) {
+    for (int c = 0; c < nch; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);
-        if (c + 1 < p.nchunk) chunk(std::integral_constant<int, 1>{}, c + 1);
+        if (c + 1 < nch) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     mma(apend[0], apend[1], 1);
     if (p.dbg & 16) return;
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(const WinoParams p) {
                     v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;
                     out[jj] = v + rs[jj];
                 }
-                *reinterpret_cast<f32x2*>(p.y + base + pix) = out;      // W % 4 == 0, ox even: aligned, both pixels inside
+                *reinterpret_cast<f32x2*>(p.y + blockIdx.y * p.part_stride + base + pix) = out;      // W % 4 == 0, ox even: aligned, both pixels inside
             }
         }
         if (pass < 3) __syncthreads();
@@ -399,10 +404,75 @@ extern "C" int shg_conv_weight_prep_wino_f32(const float* w, const float* wscale
 }
 
 // y = act(out_scale[n,o] * conv3x3_same(x * in_scale[n,i], w) + noise*noise_strength + bias[o]) + residual, stride 1, pad 1.
-extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
-                                   const float* in_scale, const float* out_scale, const float* bias, const float* noise,
-                                   int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
-                                   const float* residual, void* stream) {
+// ---- K-split of the Winograd kernels (this file and conv_wino4.hip).  A workgroup owns one (tile, 64 output channels) pair and walks ALL
+// input channels; 512-channel layers at 16^2 / 32^2 are 64-128 such pairs at batch 8 (32-64 at the path-length pass's batch 4): half
+// of the chip or less, and a launch takes the same 150 / 200 us at batch 2 and at batch 16.  With a workspace the channel chunks are cut
+// into `ks` slices (blockIdx.y), every slice writes its raw partial output, and this kernel sums them and applies the layer tail the
+// unsplit kernel applies in its store pass (same expression).
+__global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float* part, float* y, int ks, long total, long plane, int O, const float* out_scale,
+                                                                const float* bias, const float* noise, int noise_mode, float noise_strength, int act,
+                                                                float alpha, float gain, float clamp, const float* residual) {
+    for (long e4 = (long)blockIdx.x * 256 + threadIdx.x; e4 * 4 < total; e4 += (long)gridDim.x * 256) {
+        const long e = e4 * 4;                                    // W % 4 == 0: four pixels of one row
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + e);
+        for (int s = 1; s < ks; ++s) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(part + (long)s * total + e);
+            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        }
+        const long no = e / plane;
+        const long pix = e - no * plane;
+        const int n = (int)(no / O), o = (int)(no - (long)n * O);
+        const float osc = out_scale ? out_scale[(long)n * O + o] : 1.f, bs = bias ? bias[o] : 0.f;
+        f32x4 nz = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+        if (noise_mode) nz = *reinterpret_cast<const f32x4*>(noise + (noise_mode == 2 ? (long)n * plane : 0) + pix);
+        if (residual) rs = *reinterpret_cast<const f32x4*>(residual + e);
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = v[j] * osc + nz[j] * noise_strength + bs;
+            t = act ? shg_lrelu_agc(t, alpha, gain, clamp) : t * gain;
+            out[j] = t + rs[j];
+        }
+        *reinterpret_cast<f32x4*>(y + e) = out;
+    }
+}
+
+void shg_launch_wino_split_reduce(const float* part, float* y, int ks, int NB, int O, int H, int W, const float* out_scale, const float* bias,
+                                  const float* noise, int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                  const float* residual, hipStream_t s) {
+    const long total = (long)NB * O * H * W;
+    long grid = (total / 4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, part, y, ks, total, (long)H * W, O, out_scale, bias, noise,
+                       noise_mode, noise_strength, act, alpha, gain, clamp, residual);
+}
+
+// K slices for a grid of `tiles` workgroups over `nchunk` channel chunks: fill 256 CUs once, at least 8 chunks per slice
+int shg_wino_ksplit(long tiles, int nchunk) {
+    int ks = 1;
+    while (tiles * ks < 256 && nchunk / (ks * 2) >= 8) ks *= 2;
+    return ks;
+}
+
+static void wino_plan(WinoParams& p, int NB, int I, int OP, int H, int W) {
+    const bool wide = W >= 32;               // 8 x 32 pixel tiles, else 16 x 16
+    p.tiles_x = shg_cdiv(W, wide ? 32 : 16); p.tiles_y = shg_cdiv(H, wide ? 8 : 16);
+    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino::KC);
+}
+
+// bytes of scratch with which shg_conv2d_wino_ws_f32 splits this problem along its input channels (0: it will not)
+extern "C" size_t shg_conv2d_wino_workspace_bytes(int NB, int I, int O, int OP, int H, int W) {
+    if (NB < 1 || I < 1 || O < 1 || OP < 64 || H < 1 || W < 1) return 0;
+    WinoParams p{};
+    wino_plan(p, NB, I, OP, H, W);
+    const int ks = shg_wino_ksplit((long)p.n_ttiles * p.n_otiles, p.nchunk);
+    return ks > 1 ? (size_t)ks * NB * O * H * W * sizeof(float) : 0;
+}
+
+extern "C" int shg_conv2d_wino_ws_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                      const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                      int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                      const float* residual, void* workspace, size_t ws_bytes, void* stream) {
     SHG_CHECK_ARG(x && wu && y, "conv2d_wino: null pointer");
     SHG_CHECK_ARG(NB >= 1 && I >= 1 && O >= 1 && H >= 1 && W >= 1, "conv2d_wino: empty tensor");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino: OP must be a multiple of 64 and >= O");
@@ -415,16 +485,41 @@ extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, in
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
-    const bool wide = W >= 32;               // 8 x 32 pixel tiles, else 16 x 16
-    p.tiles_x = shg_cdiv(W, wide ? 32 : 16); p.tiles_y = shg_cdiv(H, wide ? 8 : 16);
-    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino::KC);
+    wino_plan(p, NB, I, OP, H, W);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
 #ifdef SHG_ABLATE
     { const char* d = getenv("SHG_WINO_DBG"); p.dbg = d ? atoi(d) : 0; }
 #endif
-    if (wide) hipLaunchKernelGGL((conv_wino_kernel<4, 16>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_wino_kernel<8, 8>), dim3(p.n_ttiles * p.n_otiles), dim3(wino::NT), 0, (hipStream_t)stream, p);
+    // K split: only with scratch for it, 16-byte aligned operands of the reduction (its loads are float4)
+    int ks = workspace ? shg_wino_ksplit((long)p.n_ttiles * p.n_otiles, p.nchunk) : 1;
+    const size_t out_bytes = (size_t)NB * O * H * W * sizeof(float);
+    while (ks > 1 && (size_t)ks * out_bytes > ws_bytes) ks /= 2;
+    if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0) ks = 1;
+    p.cps = shg_cdiv(p.nchunk, ks);
+    ks = shg_cdiv(p.nchunk, p.cps);
+    p.part_stride = 0;
+    if (ks > 1) {                             // slices write raw sums; the tail moves to the reduction
+        p.y = (float*)workspace; p.part_stride = (long)NB * O * H * W;
+        p.out_scale = nullptr; p.bias = nullptr; p.noise = nullptr; p.noise_mode = 0; p.residual = nullptr; p.act = 0; p.gain = 1.f;
+    }
+    const bool wide = W >= 32;
+    const dim3 grid(p.n_ttiles * p.n_otiles, ks);
+    if (wide) hipLaunchKernelGGL((conv_wino_kernel<4, 16>), grid, dim3(wino::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<8, 8>), grid, dim3(wino::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
+    if (ks > 1) {
+        shg_launch_wino_split_reduce((const float*)workspace, y, ks, NB, O, H, W, out_scale, bias, noise_mode ? noise : nullptr, noise ? noise_mode : 0,
+                                     noise_strength, act, alpha, gain, clamp, residual, (hipStream_t)stream);
+        SHG_CHECK_LAUNCH();
+    }
     return SHG_OK;
+}
+
+extern "C" int shg_conv2d_wino_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                   const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                   int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                   const float* residual, void* stream) {
+    return shg_conv2d_wino_ws_f32(x, wu, y, NB, I, O, OP, H, W, in_scale, out_scale, bias, noise, noise_mode, noise_strength, act, alpha, gain, clamp,
+                                  residual, nullptr, 0, stream);
 }

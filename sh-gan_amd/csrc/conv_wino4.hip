@@ -61,6 +61,8 @@ struct Wino4Params {
     int NB, I, O, OP, H, W;
     int tiles_x, tiles_y;    // tiles per image
     int n_ttiles, n_otiles, nchunk;
+    int cps;                 // chunks per K slice (= nchunk when the launch is not split: conv_wino.hip, K-split); slice = blockIdx.y
+    long part_stride;        // floats between the slices' partial outputs (0: y itself)
     int noise_mode;          // 0 none, 1 [H,W], 2 [NB,H,W]
     float noise_strength;
     int act;
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
     const int oy0 = tyb * (4 * TY), ox0 = txb * (4 * TX);
     const int o0 = otile * BO;
     const int HW = p.H * p.W;
+    const int c0 = blockIdx.y * p.cps, nch = min(p.cps, p.nchunk - c0), iend = min(p.I, (c0 + nch) * KC);      // this workgroup's K slice
 
     // ---- staging roles: waves 0..3 transform two channels each; waves 4..7 fetch the raw windows of two channels each
     const bool xformer = wave < 4;
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
     auto dma_piece = [&](int c, int buf, int q, int j) __attribute__((always_inline)) {
         if (p.dbg & 2) return;
         const int k = (wave - 4) * 2 + q;
-        const int ch = c * KC + k;
-        const bool chok = ch < p.I;                              // (also false for chunks past the end)
+        const int ch = (c0 + c) * KC + k;
+        const bool chok = ch < iend;                             // (also false for chunks past the end)
         const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_wino4_zeros;
         // Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: the compiler orders every later LDS read (and,
         // with 40+ loads in flight, every use of a loaded register) behind an LDS-DMA it knows about with `s_waitcnt vmcnt(0)`,
@@ -190,8 +193,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
     //   row(r)   : u[r][.] = d[r][.] B, style applied;
     //   col(j)   : V[.][j] = B^T u[.][j], six positions written to V.
     auto style_of = [&](int c) __attribute__((always_inline)) {
-        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? sca[0] : sca[1]), c & 63));
-        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scb[0] : scb[1]), c & 63));
+        const int ca = c0 + c;
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca < 64 ? sca[0] : sca[1]), ca & 63));
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca < 64 ? scb[0] : scb[1]), ca & 63));
         return half ? s1 : s0;
     };
     auto tr_read = [&](int r, f32x4 (&w)[3], int buf) __attribute__((always_inline)) {
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         constexpr int NP = NU / 2;
         const int pfirst = XF ? 4 * wave : 16 + 5 * (wave - 4);
         // weights: a register ring of one chunk; slot (ks, j) = MFMA A operand of unit 2*pfirst + j at k-step ks
-        const float* ubase = p.wu + ((size_t)otile * p.nchunk * 4 * NUNIT + 2 * pfirst) * 64 + lane;
         constexpr size_t ustride = (size_t)4 * NUNIT * 64;       // floats per chunk
+        const float* ubase = p.wu + ((size_t)otile * p.nchunk * 4 * NUNIT + 2 * pfirst) * 64 + lane + (size_t)c0 * ustride;
         float ur[4][NU];
         auto load_u = [&](int c, int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
         if constexpr (XF == (SHG_W4_PRIO == 1)) __builtin_amdgcn_s_setprio(3);      // (arbitration study: 1 = transform waves first, 2 = fetch waves)
 #endif
         W4_TRACE_T(1);
-        const int last = p.nchunk - 1;
+        const int last = nch - 1;
         auto fetch = [&](const float* bb, int ks, int pb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) b[pb][q] = bb[(q * KC + ks * 2) * BT];
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
             if (!(p.dbg & 1)) ur[ks][j] = ubase[(size_t)c * ustride + (ks * NUNIT + j) * 64];
 #endif
         };
-        for (int c = 0; c < p.nchunk; ++c) {
+        for (int c = 0; c < nch; ++c) {
             const int buf = c & 1;
             const int cn = c < last ? c + 1 : last;
             const float* bb = bbase + buf * V_SZ;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const Wino4Params p)
             if (pass < 3) tail_load(pass + 1, t);                     // ahead of this pass's stores
             W4_TRACE_E(pass * 8 + 5);
             if (o < p.O && col_ok) {
-                float* yp = p.y + ((long)n * p.O + o) * plane;
+                float* yp = p.y + blockIdx.y * p.part_stride + ((long)n * p.O + o) * plane;
     #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (oy + i < p.H) *reinterpret_cast<f32x4*>(yp + rowoff[i]) = out[i];
@@ -531,10 +535,35 @@ extern "C" int shg_conv2d_wino4_supported(int NB, int I, int O, int H, int W) {
 }
 
 // y = act(out_scale[n,o] * conv3x3_same(x * in_scale[n,i], w) + noise*noise_strength + bias[o]) + residual, stride 1, pad 1.
-extern "C" int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
-                                    const float* in_scale, const float* out_scale, const float* bias, const float* noise,
-                                    int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
-                                    const float* residual, void* stream) {
+int shg_wino_ksplit(long tiles, int nchunk);                   // conv_wino.hip
+void shg_launch_wino_split_reduce(const float* part, float* y, int ks, int NB, int O, int H, int W, const float* out_scale, const float* bias,
+                                  const float* noise, int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                  const float* residual, hipStream_t s);
+
+static int wino4_plan(Wino4Params& p, int NB, int I, int OP, int H, int W) {
+    // tile shape: the same 32 blocks as 16 x 32 pixels, 8 x 64 for W >= 128 or 4 x 128 for W >= 256.  The 8 x 64 window has the
+    // same area as the 16 x 32 one (10 x 72 against 18 x 40 floats per channel), the 4 x 128 one a fourth piece per channel
+    // (6 x 136), but every output row piece is 256 / 512 contiguous bytes instead of 128, which is what the store path wants
+    // (DESIGN section 5): syn512.conv1 1286 -> 1237 -> 1226 us, 256^2 layers 1037 -> 1004 -> 990; at W = 64 no gain (809 vs 813).
+    const int shape = (W >= 256 && H >= 4) ? 2 : ((W >= 128 && H >= 8) ? 1 : 0);
+    p.tiles_x = shg_cdiv(W, 32 << shape); p.tiles_y = shg_cdiv(H, 16 >> shape);
+    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino4::KC);
+    return shape;
+}
+
+// bytes of scratch with which shg_conv2d_wino4_ws_f32 splits this problem along its input channels (0: it will not; see conv_wino.hip)
+extern "C" size_t shg_conv2d_wino4_workspace_bytes(int NB, int I, int O, int OP, int H, int W) {
+    if (NB < 1 || I < 1 || O < 1 || OP < 64 || H < 1 || W < 1) return 0;
+    Wino4Params p{};
+    wino4_plan(p, NB, I, OP, H, W);
+    const int ks = shg_wino_ksplit((long)p.n_ttiles * p.n_otiles, p.nchunk);
+    return ks > 1 ? (size_t)ks * NB * O * H * W * sizeof(float) : 0;
+}
+
+extern "C" int shg_conv2d_wino4_ws_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                       const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                       int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                       const float* residual, void* workspace, size_t ws_bytes, void* stream) {
     SHG_CHECK_ARG(x && wu && y, "conv2d_wino4: null pointer");
     SHG_CHECK_ARG(shg_conv2d_wino4_supported(NB, I, O, H, W), "conv2d_wino4: unsupported geometry (use shg_conv2d_wino_f32)");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_wino4: OP must be a multiple of 64 and >= O");
@@ -545,19 +574,36 @@ extern "C" int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, i
     p.x = x; p.wu = wu; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.bias = bias;
     p.noise = noise_mode ? noise : nullptr; p.residual = residual;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
-    // tile shape: the same 32 blocks as 16 x 32 pixels, 8 x 64 for W >= 128 or 4 x 128 for W >= 256.  The 8 x 64 window has the
-    // same area as the 16 x 32 one (10 x 72 against 18 x 40 floats per channel), the 4 x 128 one a fourth piece per channel
-    // (6 x 136), but every output row piece is 256 / 512 contiguous bytes instead of 128, which is what the store path wants
-    // (DESIGN section 5): syn512.conv1 1286 -> 1237 -> 1226 us, 256^2 layers 1037 -> 1004 -> 990; at W = 64 no gain (809 vs 813).
-    const int shape = (W >= 256 && H >= 4) ? 2 : ((W >= 128 && H >= 8) ? 1 : 0);
-    p.tiles_x = shg_cdiv(W, 32 << shape); p.tiles_y = shg_cdiv(H, 16 >> shape);
-    p.n_ttiles = p.tiles_x * p.tiles_y * NB; p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, wino4::KC);
+    const int shape = wino4_plan(p, NB, I, OP, H, W);
     p.noise_mode = noise ? noise_mode : 0; p.noise_strength = noise_strength;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
-    const dim3 grid(p.n_ttiles * p.n_otiles);
+    int ks = (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) ? shg_wino_ksplit((long)p.n_ttiles * p.n_otiles, p.nchunk) : 1;
+    const size_t out_bytes = (size_t)NB * O * H * W * sizeof(float);
+    while (ks > 1 && (size_t)ks * out_bytes > ws_bytes) ks /= 2;
+    p.cps = shg_cdiv(p.nchunk, ks);
+    ks = shg_cdiv(p.nchunk, p.cps);
+    p.part_stride = 0;
+    if (ks > 1) {                             // slices write raw sums; the tail moves to the reduction
+        p.y = (float*)workspace; p.part_stride = (long)NB * O * H * W;
+        p.out_scale = nullptr; p.bias = nullptr; p.noise = nullptr; p.noise_mode = 0; p.residual = nullptr; p.act = 0; p.gain = 1.f;
+    }
+    const dim3 grid(p.n_ttiles * p.n_otiles, ks);
     if (shape == 2) hipLaunchKernelGGL((conv_wino4_kernel<1, 32>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
     else if (shape == 1) hipLaunchKernelGGL((conv_wino4_kernel<2, 16>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wino4_kernel<4, 8>), grid, dim3(wino4::NT), 0, (hipStream_t)stream, p);
     SHG_CHECK_LAUNCH();
+    if (ks > 1) {
+        shg_launch_wino_split_reduce((const float*)workspace, y, ks, NB, O, H, W, out_scale, bias, noise_mode ? noise : nullptr, noise ? noise_mode : 0,
+                                     noise_strength, act, alpha, gain, clamp, residual, (hipStream_t)stream);
+        SHG_CHECK_LAUNCH();
+    }
     return SHG_OK;
+}
+
+extern "C" int shg_conv2d_wino4_f32(const float* x, const float* wu, float* y, int NB, int I, int O, int OP, int H, int W,
+                                    const float* in_scale, const float* out_scale, const float* bias, const float* noise,
+                                    int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                    const float* residual, void* stream) {
+    return shg_conv2d_wino4_ws_f32(x, wu, y, NB, I, O, OP, H, W, in_scale, out_scale, bias, noise, noise_mode, noise_strength, act, alpha, gain, clamp,
+                                   residual, nullptr, 0, stream);
 }

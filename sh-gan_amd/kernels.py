@@ -547,6 +547,7 @@ WINO = True
 WINO_MIN = 16
 WINO4 = True            # F(4x4,3x3) (conv_wino4.hip) where it is served and the image has at least WINO4_MIN rows; else F(2x2,3x3)
 WINO4_MIN = 32
+WINO_SPLIT = True       # (A/B switch: Winograd launches whose grid does not fill the chip split along the input channels)
 UP_POLY = True          # stride-2 transposed 3x3 convolutions in the polyphase-Winograd form (conv_wino_poly.hip)
 DOWN_POLY = True        # FIR-filtered stride-2 3x3 convolutions likewise (fir_down_planar + conv2d_down_poly)
 
@@ -587,16 +588,20 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
         if WINO4 and h >= WINO4_MIN and lib.shg_conv2d_wino4_supported(nb, i, pw.o, h, w):
             wu = pw.wino4()
             executed = 2.0 * nb * pw.o * i * 36.0 * ((h + 3) // 4) * ((w + 3) // 4)
+            ws_bytes = int(lib.shg_conv2d_wino4_workspace_bytes(nb, i, pw.o, pw.op, h, w)) if WINO_SPLIT else 0
+            ws = L.new((ws_bytes // 4,)) if ws_bytes else None
             with _timed(L, 'conv_wino4', direct, executed):
-                check(lib.shg_conv2d_wino4_f32(
+                check(lib.shg_conv2d_wino4_ws_f32(
                     _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise),
-                    nmode, float(noise_strength), a, al, g, cl, _ptr(residual), L.stream()), 'conv2d_wino4')
+                    nmode, float(noise_strength), a, al, g, cl, _ptr(residual), _ptr(ws), ws_bytes, L.stream()), 'conv2d_wino4')
             return y
         wu = pw.wino()
+        ws_bytes = int(lib.shg_conv2d_wino_workspace_bytes(nb, i, pw.o, pw.op, h, w)) if WINO_SPLIT else 0       # (small grids: split along the input channels)
+        ws = L.new((ws_bytes // 4,)) if ws_bytes else None
         with _timed(L, 'conv_wino', direct, direct * 16.0 / 36.0):
-            check(lib.shg_conv2d_wino_f32(
+            check(lib.shg_conv2d_wino_ws_f32(
                 _ptr(x), _ptr(wu), _ptr(y), nb, i, pw.o, pw.op, h, w, _ptr(in_scale), _ptr(out_scale), _ptr(bias), _ptr(noise), nmode,
-                float(noise_strength), a, al, g, cl, _ptr(residual), L.stream()), 'conv2d_wino')
+                float(noise_strength), a, al, g, cl, _ptr(residual), _ptr(ws), ws_bytes, L.stream()), 'conv2d_wino')
         return y
     if (UP_POLY and mode == MODE_UP2T and planar and pw.groups == 1 and pw._w is not None and out_scale is None and bias is None
             and noise is None and residual is None and not act and gain == 1.0 and x.data_ptr() % 16 == 0

@@ -1,6 +1,6 @@
 """Per-LAUNCH efficiency of one training step (kernels.KernelTimer keeps every launch with its algorithmic work): for every kernel class the
 launches whose work / time is far below the class's best -- small grids, serial loops, fixed costs that a class total hides.
-usage: python tools/launch_outliers.py [--fp16] [--infer [--res 512 --batch 16]] [--min-us 15] [--ratio 0.3]"""
+usage: python tools/launch_outliers.py [--fp16] [--infer [--res 512 --batch 16] | --reg Greg|Dreg] [--min-us 15] [--ratio 0.3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import runpy, torch
@@ -18,6 +18,32 @@ if '--infer' in sys.argv:              # the evaluation step instead: generator 
     torch.cuda.synchronize()
     t = kernels.KernelTimer(); kernels.set_timer(t)
     eval_harness.run_generator(G, x, z, noise_mode='random'); torch.cuda.synchronize(); kernels.set_timer(None)
+elif '--reg' in sys.argv:              # a lazy-regulariser phase (Greg: path length on batch / 2; Dreg: R1) of config 5 at full width
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    from shgan_amd import losses
+    from test_gpu_config5 import build_networks
+    phase = sys.argv[sys.argv.index('--reg') + 1]
+    DEV = torch.device('cuda:0')
+    G, D = build_networks(512, 61, 62, fp16='--fp16' in sys.argv)
+    G.requires_grad_(False); D.requires_grad_(False)
+    rs = np.random.RandomState(63)
+    real = torch.from_numpy(rs.uniform(-1, 1, size=(8, 3, 512, 512)).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(size=(8, 1, 512, 512)) < 0.7).astype(np.float32))
+    real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
+    Lz = losses.InpaintingLoss(DEV, G, D, noise_mode='random', style_mixing_prob=0.9)
+    z, c = torch.randn(8, 512, device=DEV), torch.zeros(8, 0, device=DEV)
+    mod = G if phase.startswith('G') else D
+
+    def run():
+        mod.requires_grad_(True)
+        for p_ in mod.parameters():
+            p_.grad = None
+        Lz.accumulate_gradients(phase, real4, c, z, c, gain={'Greg': 4, 'Dreg': 16}.get(phase, 1))
+        mod.requires_grad_(False)
+    run(); run(); torch.cuda.synchronize()
+    t = kernels.KernelTimer(); kernels.set_timer(t)
+    run(); torch.cuda.synchronize(); kernels.set_timer(None)
 else:
     sys.argv = [sys.argv[0]] + [a for a in sys.argv[1:] if a == '--fp16']
     ns = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'train_step_bench.py'), run_name='bench')
