@@ -166,7 +166,7 @@ def test_fp16_entry_points_validate_their_arguments_without_a_gpu():
 
 
 def test_round5_entry_points_validate_their_arguments_without_a_gpu():
-    """The entry points added with ABI 29-34 (Winograd-domain weight gradient, the fp16 route switch, the two glue kernels): geometry
+    """The entry points added with ABI 29-35 (Winograd-domain weight gradient, the fp16 route switch, the two glue kernels): geometry
     gates, workspace planning and argument checks are host code -- exercised here without a device."""
     lib = _lib.get_lib()
     P = ctypes.c_void_p(16)
@@ -199,6 +199,17 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.shg_sum_partials_f32(P, P, 1, 0, 64, None) == -1
     assert lib.shg_scale_cast_f32_f16(None, P, 16, 1.0, 1, None) == -1 and lib.shg_scale_cast_f32_f16(P, P, -1, 1.0, 1, None) == -1
     assert lib.shg_scale_cast_f32_f16(P, P, 0, 1.0, 1, None) == 0                      # empty: nothing launched
+    # Winograd launches that do not fill the chip split along the input channels (ABI 35): scratch = slices x output
+    out = lambda n, o, h, w: n * o * h * w * 4                                   # noqa: E731
+    wsw, wsw4 = lib.shg_conv2d_wino_workspace_bytes, lib.shg_conv2d_wino4_workspace_bytes
+    assert wsw(8, 512, 512, 512, 16, 16) == 4 * out(8, 512, 16, 16)            # 64 workgroups -> 4 slices of 16 chunks
+    assert wsw(4, 512, 512, 512, 16, 16) == 8 * out(4, 512, 16, 16)            # 32 -> 8 slices of 8 chunks (no thinner)
+    assert wsw(16, 64, 64, 64, 16, 16) == 0                                     # 8 chunks: nothing to split
+    assert wsw4(8, 512, 512, 512, 32, 32) == 2 * out(8, 512, 32, 32) and wsw4(16, 512, 512, 512, 32, 32) == 0
+    assert wsw4(16, 64, 64, 64, 512, 512) == 0
+    P2 = ctypes.c_void_p(32)
+    assert lib.shg_conv2d_wino_ws_f32(P2, P2, P2, 1, 64, 64, 64, 16, 18, None, None, None, None, 0, 0.0, 0, 0.2, 1.0, -1.0, None, None, 0, None) == -1 \
+        and b'W %' in lib.shg_last_error()
     # the native op over the plugin's whole operand range (ABI 34): dtype code, strides, the size rule of upfirdn2d.cpp:26-36
     st = (ctypes.c_long * 4)(96, 16, 4, 1)
     ufs = lib.shg_upfirdn2d_strided
