@@ -153,6 +153,10 @@ int shg_conv_weight_prep_up_poly_f32(const float* w, const float* wscale, float*
 int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W);
 int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O,
                            int OP, int H, int W, const float* in_scale, void* stream);
+/* ... with scratch for the split along the input channels on small grids (see shg_conv2d_wino_ws_f32): 16^2 / 32^2 inputs */
+size_t shg_conv2d_up_poly_workspace_bytes(int NB, int I, int O, int OP, int H, int W);
+int shg_conv2d_up_poly_ws_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I, int O,
+                              int OP, int H, int W, const float* in_scale, void* workspace, size_t ws_bytes, void* stream);
 /* Polyphase-Winograd form of the FIR-filtered stride-2 3x3 convolution (conv2d_resample.py:116-120), same reduction of the
  * multiply count.  shg_fir_down_planar_f32 applies the 4x4 pre-filter (padding 2) to x [N,C,H,W] and writes the (H+1)x(W+1)
  * result as its four polyphase planes xp [4][N*C][H/2+1][PP] (PP = a multiple of 4 >= W/2+1); shg_conv2d_down_poly_f32 then

@@ -92,6 +92,8 @@ _SIGS = {
     'shg_conv_weight_prep_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_up_poly_supported': [c_i, c_i, c_i, c_i, c_i],
     'shg_conv2d_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp],
+    'shg_conv2d_up_poly_ws_f32': [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, ctypes.c_size_t, c_fp],
+    'shg_conv2d_up_poly_workspace_bytes': [c_i] * 6,
     'shg_fir_down_planar_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'shg_fir_pad2_sep_supported': [c_i, c_i, c_i],
     'shg_fir_resample2_sep_supported': [c_i, c_i, c_i],

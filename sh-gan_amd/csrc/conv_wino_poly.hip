@@ -65,6 +65,10 @@ struct PolyParams {
     const float* residual;   // like y, added after the activation, or null
     int act;
     float alpha, gain, clamp;
+    // up launches on small grids: split along the input channels (conv_wino.hip, K-split): chunks per slice, slice = blockIdx.y,
+    // floats between the slices' partial planes (0 and cps = nchunk: not split; the down schemes never split)
+    int cps;
+    long part_stride;
 };
 
 namespace poly {
@@ -116,6 +120,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     constexpr int PW = G::PW, PW4 = G::PW4, PATCH4 = G::PATCH4, RP = G::RP, R_SZ = G::R_SZ, BS = G::BS, NPIECE = G::NPIECE;
     constexpr bool FLAT = NBX > 0;
     constexpr bool DOWN = SCHEME == DA || SCHEME == DB;
+    const int c0 = DOWN ? 0 : blockIdx.y * p.cps, nch = DOWN ? p.nchunk : min(p.cps, p.nchunk - c0), iend = min(p.I, (c0 + nch) * poly::KC);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,8 +179,8 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         for (int q = 0; q < CPL; ++q) {
             const int k = (wave - NXF) * CPL + q;
             if (k >= KC) continue;
-            const int ch = c * KC + k;
-            const bool chok = ch < p.I;
+            const int ch = (c0 + c) * KC + k;
+            const bool chok = ch < iend;
 #pragma unroll
             for (int j = 0; j < NPIECE; ++j) {
                 const float* src = (chok && roff[j] >= 0) ? p.x + ((long)roff[j] + (long)ch * HW) : shg_poly_zeros;
@@ -187,8 +192,8 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     };
 
     constexpr int NU = KC / 4;
-    const f32x4* ubase = reinterpret_cast<const f32x4*>(q.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC);
     const size_t ustride = (size_t)16 * 64 * KC / 4;
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(q.wu + (((size_t)otile * p.nchunk * 16 + wave) * 64 + lane) * KC) + (size_t)c0 * ustride;
     f32x4 ua[NU], ub[NU];
     auto load_u = [&](f32x4 (&dst)[NU], int c) __attribute__((always_inline)) {
 #pragma unroll
@@ -207,7 +212,8 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         scv[v] = (p.in_scale && xformer && ch < p.I) ? p.in_scale[(long)n * p.I + ch] : 1.f;
     }
     auto transform = [&](int c, int buf) __attribute__((always_inline)) {
-        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c < 64 ? scv[0] : scv[1]), c & 63));
+        const int ca = c0 + c;
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca < 64 ? scv[0] : scv[1]), ca & 63));
         const float* rb = rbase + buf * R_SZ;
         float* vb = vbase + buf * V_SZ;
         if constexpr (SCHEME == DB) {
@@ -291,7 +297,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
     load_u(ua, 0);
     if (!xformer) {
         dma_raw(0, 0);
-        if (p.nchunk > 1) dma_raw(1, 1);
+        if (nch > 1) dma_raw(1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -309,7 +315,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         constexpr int PAR = decltype(par)::value;
         f32x4 (&ucur)[NU] = PAR ? ub : ua;
         f32x4 (&unxt)[NU] = PAR ? ua : ub;
-        const bool more = c + 1 < p.nchunk;
+        const bool more = c + 1 < nch;
         const float* bb = bbase + PAR * V_SZ;
         auto fetch = [&](int ks, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -321,7 +327,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         __builtin_amdgcn_sched_barrier(0);
         if (more) load_u(unxt, c + 1);
         if (!xformer) {
-            if (c + 2 < p.nchunk) dma_raw(c + 2, PAR);
+            if (c + 2 < nch) dma_raw(c + 2, PAR);
         } else if (more) {
             transform(c + 1, PAR ^ 1);
         }
@@ -337,9 +343,9 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    for (int c = 0; c < p.nchunk; c += 2) {
+    for (int c = 0; c < nch; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);
-        if (c + 1 < p.nchunk) chunk(std::integral_constant<int, 1>{}, c + 1);
+        if (c + 1 < nch) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     mma(apend[0], apend[1], 1);
 
@@ -387,7 +393,7 @@ __device__ __forceinline__ void poly_body(const PolyParams& p, const PolySub& q,
         const int by = FLAT ? (id0 + t) / (NBX ? NBX : 1) : by0 + t / TX, bx = FLAT ? (id0 + t) % (NBX ? NBX : 1) : bx0 + t % TX;
         const int o = o0 + ob * 32 + o_l;
         if (o < p.O && by < q.nby && bx < q.nbx) {
-            float* yb = p.y + ((long)n * p.O + o) * plane;             // + phase * NB*O*plane
+            float* yb = p.y + (DOWN ? 0 : blockIdx.y * p.part_stride) + ((long)n * p.O + o) * plane;             // + phase * NB*O*plane
             const long pstride = (long)p.NB * p.O * plane;
             if constexpr (G::A) {
                 // A^T m A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
@@ -486,8 +492,9 @@ __device__ __forceinline__ void poly_strip_body(const PolyParams& p, const int t
     const float* xb = p.x + (long)n * p.I * HW + (pok ? (col ? pos * p.W + p.W - 1 : (p.H - 1) * p.W + pos) : 0);
     const float* wb = wt + ((long)(ot32 >> 1) * IPK + tap) * 64 + (ot32 & 1) * 32 + l31;     // + i*9*64
     const float* sb = p.in_scale ? p.in_scale + (long)n * p.I : nullptr;
-    const int kper = ((p.I + 7) / 8) * 2;                     // channels per wave (even)
-    const int kbeg = wave * kper, kend = min(p.I, kbeg + kper);
+    const int i_lo = blockIdx.y * p.cps * poly::KC, i_hi = min(p.I, i_lo + p.cps * poly::KC);      // this slice's input channels (all of them when not split)
+    const int kper = ((i_hi - i_lo + 7) / 8) * 2;             // channels per wave (even)
+    const int kbeg = i_lo + wave * kper, kend = min(i_hi, kbeg + kper);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -514,7 +521,7 @@ __device__ __forceinline__ void poly_strip_body(const PolyParams& p, const int t
     const int PWg = p.W + 1;
     const long plane = (long)(p.H + 1) * PWg;
     const long pix = col ? (long)pos * PWg + p.W : (long)p.H * PWg + pos;
-    float* yb = p.y + (long)(col ? 2 : 1) * p.NB * p.O * plane + (long)n * p.O * plane + pix;
+    float* yb = p.y + blockIdx.y * p.part_stride + (long)(col ? 2 : 1) * p.NB * p.O * plane + (long)n * p.O * plane + pix;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr;
@@ -649,8 +656,47 @@ extern "C" int shg_conv2d_up_poly_supported(int NB, int I, int O, int H, int W) 
 // Phase planes of the stride-2 transposed 3x3 convolution of x * in_scale[n,i]: y [4][NB,O,H+1,W+1] (same contract as
 // shg_conv2d_f32 mode 2 / out_mode 1 without epilogue operands).  wt = GEMM-layout weights of shg_conv_weight_prep_f32
 // (for the strips), wu_a / wu_b from shg_conv_weight_prep_up_poly_f32.
-extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I,
-                                      int O, int OP, int H, int W, const float* in_scale, void* stream) {
+int shg_wino_ksplit(long tiles, int nchunk);                   // conv_wino.hip
+void shg_launch_wino_split_reduce(const float* part, float* y, int ks, int NB, int O, int H, int W, const float* out_scale, const float* bias,
+                                  const float* noise, int noise_mode, float noise_strength, int act, float alpha, float gain, float clamp,
+                                  const float* residual, hipStream_t s);
+
+// tiling of an up launch; returns the kernel variant: 0 narrow, 1 / 2 / 3 flat with 11 / 22 / 43 block columns, 4 wide, 5 rectangular 8 x 8
+static int up_poly_plan(PolyParams& p, int NB, int I, int OP, int H, int W) {
+    p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
+    // scheme UB: 2x2 body blocks, 4 x 16 blocks per tile (8 x 8 for images narrower than 32)
+    const bool bwide = W >= 32;
+    p.b.nby = H / 2; p.b.nbx = W / 2;
+    p.b.tiles_x = shg_cdiv(p.b.nbx, bwide ? 16 : 8); p.b.tiles_y = shg_cdiv(p.b.nby, bwide ? 4 : 8);
+    p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
+    // scheme UA: 3x3 blocks of the ee plane; flat tiling for the block-row lengths of the generator's layers, else the
+    // rectangular tile shape with the smaller padding waste
+    p.a.nby = shg_cdiv(H + 1, 3); p.a.nbx = shg_cdiv(W + 1, 3);
+    const bool flat = bwide && (p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43);
+    const long w88 = (long)shg_cdiv(p.a.nbx, 8) * shg_cdiv(p.a.nby, 8), w416 = (long)shg_cdiv(p.a.nbx, 16) * shg_cdiv(p.a.nby, 4);
+    const bool wide = bwide && w416 < w88;
+    if (flat) { p.a.tiles_x = shg_cdiv(p.a.nby * p.a.nbx, 64); p.a.tiles_y = 1; }
+    else { p.a.tiles_x = shg_cdiv(p.a.nbx, wide ? 16 : 8); p.a.tiles_y = shg_cdiv(p.a.nby, wide ? 4 : 8); }
+    p.a.n_ttiles = p.a.tiles_x * p.a.tiles_y * NB;
+    // strips: tiles of 32 channels x 32 positions, four per workgroup
+    p.IPK = (I + 31) / 32 * 32 * 9;
+    p.n_strip_tiles = (shg_cdiv(W, 32) + shg_cdiv(H, 32)) * (OP / 32) * NB;
+    if (!bwide) return 0;
+    if (flat) return p.a.nbx == 11 ? 1 : (p.a.nbx == 22 ? 2 : 3);
+    return wide ? 4 : 5;
+}
+
+// bytes of scratch with which shg_conv2d_up_poly_ws_f32 splits this problem along its input channels (0: it will not; conv_wino.hip, K-split)
+extern "C" size_t shg_conv2d_up_poly_workspace_bytes(int NB, int I, int O, int OP, int H, int W) {
+    if (!shg_conv2d_up_poly_supported(NB, I, O, H, W) || OP < 64) return 0;
+    PolyParams p{};
+    up_poly_plan(p, NB, I, OP, H, W);
+    const int ks = shg_wino_ksplit((long)(p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles, p.nchunk);
+    return ks > 1 ? (size_t)ks * 4 * NB * O * (H + 1) * (W + 1) * sizeof(float) : 0;
+}
+
+extern "C" int shg_conv2d_up_poly_ws_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I,
+                                         int O, int OP, int H, int W, const float* in_scale, void* workspace, size_t ws_bytes, void* stream) {
     SHG_CHECK_ARG(x && wt && wu_a && wu_b && y, "conv2d_up_poly: null pointer");
     SHG_CHECK_ARG(shg_conv2d_up_poly_supported(NB, I, O, H, W), "conv2d_up_poly: unsupported geometry (use shg_conv2d_f32 mode 2)");
     SHG_CHECK_ARG(OP % 64 == 0 && OP >= O, "conv2d_up_poly: OP must be a multiple of 64 and >= O");
@@ -660,33 +706,35 @@ extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const flo
     PolyParams p{};
     p.x = x; p.y = y; p.in_scale = in_scale;
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = H; p.W = W;
-    p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
-    // scheme UB: 2x2 body blocks, 4 x 16 blocks per tile (8 x 8 for images narrower than 32)
-    const bool bwide = W >= 32;
-    p.b.wu = wu_b; p.b.nby = H / 2; p.b.nbx = W / 2;
-    p.b.tiles_x = shg_cdiv(p.b.nbx, bwide ? 16 : 8); p.b.tiles_y = shg_cdiv(p.b.nby, bwide ? 4 : 8);
-    p.b.n_ttiles = p.b.tiles_x * p.b.tiles_y * NB;
-    // scheme UA: 3x3 blocks of the ee plane; flat tiling for the block-row lengths of the generator's layers, else the
-    // rectangular tile shape with the smaller padding waste
-    p.a.wu = wu_a; p.a.nby = shg_cdiv(H + 1, 3); p.a.nbx = shg_cdiv(W + 1, 3);
-    const bool flat = bwide && (p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43);
-    const long w88 = (long)shg_cdiv(p.a.nbx, 8) * shg_cdiv(p.a.nby, 8), w416 = (long)shg_cdiv(p.a.nbx, 16) * shg_cdiv(p.a.nby, 4);
-    const bool wide = bwide && w416 < w88;
-    if (flat) { p.a.tiles_x = shg_cdiv(p.a.nby * p.a.nbx, 64); p.a.tiles_y = 1; }
-    else { p.a.tiles_x = shg_cdiv(p.a.nbx, wide ? 16 : 8); p.a.tiles_y = shg_cdiv(p.a.nby, wide ? 4 : 8); }
-    p.a.n_ttiles = p.a.tiles_x * p.a.tiles_y * NB;
-    // strips: tiles of 32 channels x 32 positions, four per workgroup
-    p.wt = wt; p.IPK = (I + 31) / 32 * 32 * 9;
-    p.n_strip_tiles = (shg_cdiv(W, 32) + shg_cdiv(H, 32)) * (OP / 32) * NB;
-    const dim3 grid((p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles + shg_cdiv(p.n_strip_tiles, 4));
-    if (!bwide) hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 8, 8>), grid, dim3(poly::NT), 0, s, p);
-    else if (flat && p.a.nbx == 11) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 11, 4, 16>), grid, dim3(poly::NT), 0, s, p);
-    else if (flat && p.a.nbx == 22) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 22, 4, 16>), grid, dim3(poly::NT), 0, s, p);
-    else if (flat) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43, 4, 16>), grid, dim3(poly::NT), 0, s, p);
-    else if (wide) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    p.a.wu = wu_a; p.b.wu = wu_b; p.wt = wt;
+    const int variant = up_poly_plan(p, NB, I, OP, H, W);
+    // K split (small grids): slices write partial planes, one small launch adds them
+    const size_t out_bytes = (size_t)4 * NB * O * (H + 1) * (W + 1) * sizeof(float);
+    int ks = (workspace && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+                 ? shg_wino_ksplit((long)(p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles, p.nchunk) : 1;
+    while (ks > 1 && (size_t)ks * out_bytes > ws_bytes) ks /= 2;
+    p.cps = shg_cdiv(p.nchunk, ks);
+    ks = shg_cdiv(p.nchunk, p.cps);
+    p.part_stride = 0;
+    if (ks > 1) { p.y = (float*)workspace; p.part_stride = (long)(out_bytes / sizeof(float)); }
+    const dim3 grid((p.a.n_ttiles + p.b.n_ttiles) * p.n_otiles + shg_cdiv(p.n_strip_tiles, 4), ks);
+    if (variant == 0) hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 8, 8>), grid, dim3(poly::NT), 0, s, p);
+    else if (variant == 1) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 11, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (variant == 2) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 22, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (variant == 3) hipLaunchKernelGGL((conv_poly_up_kernel<1, 64, 43, 4, 16>), grid, dim3(poly::NT), 0, s, p);
+    else if (variant == 4) hipLaunchKernelGGL((conv_poly_up_kernel<4, 16, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
     else hipLaunchKernelGGL((conv_poly_up_kernel<8, 8, 0, 4, 16>), grid, dim3(poly::NT), 0, s, p);
     SHG_CHECK_LAUNCH();
+    if (ks > 1) {
+        shg_launch_wino_split_reduce((const float*)workspace, y, ks, 4 * NB, O, H + 1, W + 1, nullptr, nullptr, nullptr, 0, 0.f, 0, 0.f, 1.f, -1.f, nullptr, s);
+        SHG_CHECK_LAUNCH();
+    }
     return SHG_OK;
+}
+
+extern "C" int shg_conv2d_up_poly_f32(const float* x, const float* wt, const float* wu_a, const float* wu_b, float* y, int NB, int I,
+                                      int O, int OP, int H, int W, const float* in_scale, void* stream) {
+    return shg_conv2d_up_poly_ws_f32(x, wt, wu_a, wu_b, y, NB, I, O, OP, H, W, in_scale, nullptr, 0, stream);
 }
 
 // ---- stride-2 3x3 convolution (mode 1 of shg_conv2d_f32 after the FIR pre-filter) -----------------------------------------
@@ -730,6 +778,7 @@ extern "C" int shg_conv2d_down_poly_f32(const float* xp, const float* wu_a, cons
     p.NB = NB; p.I = I; p.O = O; p.OP = OP; p.H = OH; p.W = OW; p.PH2 = OH + 1; p.PP = PP;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.n_otiles = OP / 64; p.nchunk = shg_cdiv(I, poly::KC);
+    p.cps = p.nchunk; p.part_stride = 0;
     // scheme DA: 3x3 output blocks (flat tiling for the generator's block-row lengths)
     p.a.wu = wu_a; p.a.nby = shg_cdiv(OH, 3); p.a.nbx = shg_cdiv(OW, 3);
     const bool flat = p.a.nbx == 11 || p.a.nbx == 22 || p.a.nbx == 43;

@@ -609,9 +609,11 @@ def conv2d(x, pw, mode=MODE_SAME, pad=0, in_scale=None, out_scale=None, bias=Non
         wa, wb = pw.up_poly()
         nba, nbb = ((h + 1 + 2) // 3) * ((w + 1 + 2) // 3), (h // 2) * (w // 2)
         executed = 2.0 * nb * pw.o * i * (16.0 * (nba + nbb) + h + w)
+        ws_bytes = int(lib.shg_conv2d_up_poly_workspace_bytes(nb, i, pw.o, pw.op, h, w)) if WINO_SPLIT else 0
+        ws = L.new((ws_bytes // 4,)) if ws_bytes else None
         with _timed(L, 'conv_poly_up', 2.0 * nb * pw.o * i * 9 * h * w, executed):
-            check(lib.shg_conv2d_up_poly_f32(_ptr(x), _ptr(pw.wt), _ptr(wa), _ptr(wb), _ptr(y), nb, i, pw.o, pw.op, h, w,
-                                             _ptr(in_scale), L.stream()), 'conv2d_up_poly')
+            check(lib.shg_conv2d_up_poly_ws_f32(_ptr(x), _ptr(pw.wt), _ptr(wa), _ptr(wb), _ptr(y), nb, i, pw.o, pw.op, h, w,
+                                                _ptr(in_scale), _ptr(ws), ws_bytes, L.stream()), 'conv2d_up_poly')
         return y
     ws, ws_bytes = None, 0
     if mode != MODE_UP2T or planar:      # split-K of the transposed conv is wired for the planar output only

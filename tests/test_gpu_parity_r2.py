@@ -310,6 +310,7 @@ POLY_UP_CASES = [
     # n, ci, co, h, w: ragged channel counts (I % 8, O % 64), several tiles per image, both tile shapes of both schemes
     (2, 16, 64, 32, 32), (1, 13, 70, 34, 40), (2, 72, 130, 64, 64), (1, 8, 3, 32, 128), (3, 24, 24, 66, 36), (1, 128, 64, 128, 128),
     (2, 40, 70, 16, 16), (1, 16, 64, 18, 20), (16, 64, 64, 16, 16),      # 8 x 8 block tiles of both schemes (images narrower than 32)
+    (2, 512, 512, 16, 16), (4, 256, 100, 32, 32), (1, 200, 64, 16, 20),  # small grids: split along the input channels (strips included; ragged last slice)
 ]
 
 

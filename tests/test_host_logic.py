@@ -207,6 +207,8 @@ def test_round5_entry_points_validate_their_arguments_without_a_gpu():
     assert wsw(16, 64, 64, 64, 16, 16) == 0                                     # 8 chunks: nothing to split
     assert wsw4(8, 512, 512, 512, 32, 32) == 2 * out(8, 512, 32, 32) and wsw4(16, 512, 512, 512, 32, 32) == 0
     assert wsw4(16, 64, 64, 64, 512, 512) == 0
+    wsu = lib.shg_conv2d_up_poly_workspace_bytes
+    assert wsu(4, 512, 512, 512, 16, 16) == 4 * (4 * out(4, 512, 17, 17)) and wsu(16, 512, 512, 512, 16, 16) == 0 and wsu(4, 512, 512, 512, 16, 18) == 0
     P2 = ctypes.c_void_p(32)
     assert lib.shg_conv2d_wino_ws_f32(P2, P2, P2, 1, 64, 64, 64, 16, 18, None, None, None, None, 0, 0.0, 0, 0.2, 1.0, -1.0, None, None, 0, None) == -1 \
         and b'W %' in lib.shg_last_error()

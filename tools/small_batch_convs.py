@@ -22,7 +22,7 @@ def t(fn, reps=20):
 w = torch.randn(512, 512, 3, 3, device='cuda') / 68.0
 pw = kernels.conv_weight_prep(w)
 pwt = kernels.conv_weight_prep(w.transpose(0, 1).contiguous())
-for res in (64, 32, 16):
+for res in (64, 32, 16, 8, 4):
     for n in (2, 4, 8, 16):
         x = torch.randn(n, 512, res, res, device='cuda')
         xs2 = torch.randn(n, 512, res + 1, res + 1, device='cuda')
