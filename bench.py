@@ -126,6 +126,8 @@ def parse():
     ap.add_argument('--cpu-forwards', type=int, default=3, help='timed CPU forwards after one warm-up (SURVEY 8d: >= 3)')
     ap.add_argument('--no-second-config', action='store_true', help='skip the 256x256 batch-32 block (BASELINE config 2)')
     ap.add_argument('--no-train-step', action='store_true', help='skip the config-5 training-step block')
+    ap.add_argument('--no-eval-loop', action='store_true', help='skip the config-4 evaluation-loop block')
+    ap.add_argument('--eval-loop', action='store_true', help='N > 1: run the evaluation-loop block too (its all-gather / all-reduce then span the ranks)')
     ap.add_argument('--all-blocks', action='store_true',
                     help='N > 1: also run the informational second_config / train_step blocks (default: N = 1 only, so that a scaling run '
                          'measures the headline and nothing can stand between it and its JSON line)')
@@ -162,6 +164,81 @@ def max_over_ranks(dt, use_dist, backend, dev):
     return dt
 
 
+def class_tables(tsum, psteps, f16_peak=None):
+    """Per kernel class of an instrumented pass (kernels.KernelTimer summary): convolution classes against the dense MFMA peak of their
+    arithmetic type (executed flops: Winograd counts its transformed products), the streaming classes against 8 TB/s."""
+    conv, hbm = {}, {}
+    for name in sorted(tsum):
+        d = tsum[name]
+        if d['ms'] <= 0 or not d['calls']:
+            continue
+        sec = d['ms'] * 1e-3
+        if name.startswith('conv'):
+            peak = f16_peak if (f16_peak and 'f16' in name) else PEAK_FP32_MFMA_TFLOPS
+            conv[name] = {'launches_per_step': d['calls'] // psteps, 'ms_per_step': round(d['ms'] / psteps, 3),
+                          'avg_launch_us': round(d['ms'] / d['calls'] * 1e3, 1), 'executed_tflops': round(d['executed'] / sec / 1e12, 2),
+                          'frac_of_mfma_peak': round(d['executed'] / sec / 1e12 / peak, 4), 'peak_tflops': peak,
+                          'direct_form_tflops': round(d['work'] / sec / 1e12, 2)}
+        elif name in ('upfirdn2d', 'fir_up_planar', 'torgb', 'fromrgb', 'composite_u8', 'upfirdn2d_f16', 'modtail_f16', 'relayout'):
+            gbs = d['work'] / sec / 1e9
+            hbm[name] = {'launches_per_step': d['calls'] // psteps, 'ms_per_step': round(d['ms'] / psteps, 3),
+                         'achieved_GBps': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4)}
+    dom = max(conv, key=lambda k: conv[k]['ms_per_step'], default=None)
+    return {'mfma': conv, 'hbm': hbm, 'dominant': dom, 'dominant_frac_of_mfma_peak': conv[dom]['frac_of_mfma_peak'] if dom else None,
+            'all_kernels_ms_per_step': round(sum(d['ms'] for d in tsum.values()) / psteps, 3)}
+
+
+def eval_loop_block(G, res, batch, steps, a, dev, rank, world, barrier, use_dist, backend):
+    """BASELINE config 4, one rank's share: the evaluation LOOP around the hot path (shgan_default.py:264-300) --
+    per batch: decoded uint8 images from the loader (pinned host memory; a pool of pre-drawn batches stands in for the decode workers)
+    -> H2D on the copy stream -> freeform masks drawn on the device from the reference's numpy draws -> input assembly -> z ~ N(0,1) ->
+    G + uint8 composite into the result buffer -> stand-in [B,2048] features (the Inception detector is a download) -> fp64 FID
+    moments; at the end one all-reduce of the moments and one all-gather + re-interleave of the uint8 results.  Timed barrier to
+    barrier with everything above inside; max over ranks."""
+    import numpy as np
+    import torch
+    from shgan_amd import eval_harness
+    n_items = world * batch * steps
+
+    def make(n):
+        return eval_harness.EvalLoop(G, dev, res, n, rank=rank, world=world, noise_mode=a.noise_mode, seed=0, depth=a.pipeline_depth,
+                                     feature_fn=eval_harness.standin_features)
+    warm = make(world * batch * 4)
+    pool = eval_harness.PinnedU8Loader(warm.ids, batch, res, seed=1000, pool=4)
+    np.random.seed(1000 + rank)
+    warm.run(pool)
+    warm.gather()
+    torch.cuda.synchronize()
+    del warm
+    loop = make(n_items)
+    loader = eval_harness.PinnedU8Loader(loop.ids, batch, res, seed=1000, pool=4)
+    loader._cache = pool._cache                            # the pinned pool drawn during the warm-up
+    np.random.seed(2000 + rank)                            # mask draws: numpy's global generator, as the reference's workers
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.run(loader)
+    t_issue = time.perf_counter() - t0                     # host side of the loop: everything enqueued (the device may still be busy)
+    torch.cuda.synchronize()
+    t_loop = time.perf_counter() - t0
+    images, fid = loop.gather()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev)
+    n_fid = float(fid.S[fid.dim, fid.dim].item())
+    ok = tuple(images.shape) == (n_items, 3, res, res) and images.dtype == torch.uint8
+    del loop, images, fid
+    torch.cuda.empty_cache()
+    return {'workload': f'Places2/FFHQ-{res} evaluation loop, one rank\'s share: {steps} batches of {batch} per GPU -- uint8 loader -> H2D (copy stream) -> '
+                        'device freeform masks -> assemble -> G + u8 composite (streamed into the result buffer) -> stand-in features '
+                        '[B,2048] -> fp64 FID moments; then all-reduce(moments) + all-gather(u8) + zipzap',
+            'images_per_s': round(n_items / dt, 3), 'ms_per_batch': round(dt / steps * 1e3, 3), 'batches': steps, 'n_gpus': world,
+            'ms_per_batch_loop_only': round(t_loop / steps * 1e3, 3), 'host_issue_ms_per_batch': round(t_issue / steps * 1e3, 3),
+            'gather_and_reduce_ms': round((dt - t_loop) * 1e3, 3), 'fid_samples_counted': n_fid, 'result_ok': bool(ok),
+            'not_in_the_loop': 'PNG / zip decode (dataset workers) and the Inception-v3 detector (a download): a pinned pool of pre-drawn '
+                               'uint8 batches and a fixed linear map stand in for them'}
+
+
 def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     """The headline loop on another configuration (BASELINE config 2: FFHQ-256 batch 32): same pipeline, same barrier / max-over-ranks timing."""
     import torch
@@ -192,6 +269,16 @@ def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_d
         step()
     torch.cuda.synchronize()
     lat = (time.perf_counter() - t1) / 3 * 1e3
+    classes = None
+    if rank == 0 and a.profile_steps > 0:                 # the same instrumented pass as the headline's: HIP events around every launch
+        from shgan_amd import kernels
+        timer = kernels.KernelTimer()
+        kernels.set_timer(timer)
+        for _ in range(a.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        kernels.set_timer(None)
+        classes = class_tables(timer.summary(), a.profile_steps, PEAK_F16_MFMA_TFLOPS if fp16 else None)
     barrier()
     del G, x, z
     torch.cuda.empty_cache()
@@ -200,7 +287,8 @@ def forward_block(res, batch, steps, warmup, a, dev, rank, world, barrier, use_d
                            'shipped configuration (use_fp16_*: null) and not the headline' if fp16 else ''),
             'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'value': round(world * batch * steps / dt, 3),
             'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warmup, 'n_gpus': world,
-            'ms_per_step_single_stream': round(lat, 3), 'gflop_per_image_direct_form': GFLOP_PER_IMAGE.get(res)}
+            'ms_per_step_single_stream': round(lat, 3), 'gflop_per_image_direct_form': GFLOP_PER_IMAGE.get(res),
+            'roofline_classes': classes}
 
 
 def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
@@ -223,7 +311,7 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     real = torch.rand(b, 3, res, res, device=dev) * 2 - 1
     mask = (torch.rand(b, 1, res, res, device=dev) < 0.7).float()
     real4 = torch.cat([mask - 0.5, real], dim=1)
-    L = losses.InpaintingLoss(dev, G, D, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
+    L = losses.InpaintingLoss(dev, G, D, composite_fake=True, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
     use_graph = world == 1 and a.graph != 'off'           # phases as HIP graphs (train_stage.PhaseGraphs); eager loop timed beside it
     kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=use_graph, fused=True)     # one multi-tensor kernel per optimiser step
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
@@ -250,8 +338,11 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     ms_greg = timed([4, 4])                               # Gmain + Greg + Dmain (batch_idx % 4 == 0, % 16 != 0)
     ms_all = timed([0])                                   # Gmain + Greg + Dmain + Dreg
     graph_info = {'used': False}
+    if world > 1 and a.graph != 'off':
+        graph_info['reason'] = ('train_stage.PhaseGraphs is single-process (it raises on an active BucketedAllReduce: a captured phase cannot hold '
+                                'the hook-launched RCCL all-reduces that overlap with backward); with N > 1 ranks the step is the eager loop')
     if use_graph:
-        eager = (ms_main, ms_all)
+        eager = (ms_main, ms_greg, ms_all)
         try:
             mode['graph'] = True
             for _ in range(3):
@@ -260,13 +351,13 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             g_main = timed([1 + (k % 3) for k in range(a.train_steps)])
             g_greg = timed([4, 4])
             g_all = timed([0])
-            graph_info = {'used': True, 'eager_ms_per_step': round(eager[0], 2), 'eager_ms_iteration_with_both_lazy_regularisers': round(eager[1], 2),
+            graph_info = {'used': True, 'eager_ms_per_step': round(eager[0], 2), 'eager_ms_iteration_with_both_lazy_regularisers': round(eager[2], 2),
                           'note': 'every phase captured once as a HIP graph (train_stage.PhaseGraphs) and replayed; the eager loop '
                                   '(Python + autograd + ctypes enqueue of ~4 500 launches per step) timed beside it'}
             ms_main, ms_greg, ms_all = g_main, g_greg, g_all
         except Exception as e:
             graph_info = {'used': False, 'error': repr(e)[:400]}
-            ms_main, ms_all, ms_greg = eager
+            ms_main, ms_greg, ms_all = eager
         mode['graph'] = False
         try:
             torch.cuda.synchronize()
@@ -313,8 +404,9 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             'ms_per_step': round(ms_main, 2), 'images_per_s_main_phases_only': round(world * b / ms_main * 1e3, 2), 'steps': a.train_steps, 'n_gpus': world,
             'ms_iteration_with_both_lazy_regularisers': round(ms_all, 2),
             'lazy_regularisers': 'Greg (path length, batch/2) every 4th, Dreg (R1) every 16th iteration (stylegan_default.py:304-321)',
-            'objective': 'stylegan_default_loss.py:53-128 on the raw generator output (InpaintingLoss composite_fake=False, the mode the '
-                         'reference-autograd fixtures pin); Dmain judges fake + real as one stacked critic pass (same logits and gradients)',
+            'objective': 'stylegan_default_loss.py:53-128 with the generator output composited with the known pixels before the critic sees it '
+                         '(InpaintingLoss composite_fake=True, the objective to train an inpainting generator with; rounds 3-5 timed the raw-output '
+                         'form: one more elementwise pass per generator call); Dmain judges fake + real as one stacked critic pass (same logits and gradients)',
             'dtype': 'f16 blocks + f32' if fp16 else 'f32', 'losses_finite': finite, 'peak_memory_GiB': round(mem, 1),
             'grad_all_reduce': (backend if world > 1 else None), 'hip_graph': graph_info, 'kernel_classes_one_step_rank0': cls,
             'conv_kernel_ms': round(sum(v['ms_per_step'] for k, v in cls.items() if k.startswith('conv')), 2) if cls else None}
@@ -425,6 +517,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = loop(gpipe, a.steps, True) if gpipe is not None else loop(pipe, a.steps, False)
+    t_issue = time.perf_counter() - t0                  # host side: K steps enqueued (nothing in the loop waits for the device)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     barrier()
@@ -435,6 +528,12 @@ def worker(local_rank, a, spawned_world=None, port=None):
         t[rank] = dt_local / a.steps * 1e3
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rank_ms = [float(v) for v in t.tolist()]
+    issue_ms = [t_issue / a.steps * 1e3]
+    if use_dist:                           # every rank's host enqueue time per step: N interpreters on one host compete for cores
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        t[rank] = t_issue / a.steps * 1e3
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        issue_ms = [float(v) for v in t.tolist()]
     ranks_counted = 1
     if use_dist:                           # every rank contributes 1: the line proves how many ranks the collective really spanned
         t = torch.ones(1, dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
@@ -475,8 +574,15 @@ def worker(local_rank, a, spawned_world=None, port=None):
     barrier()
     del pipe, gpipe
     torch.cuda.empty_cache()
-    second = train = fp16_eval = None
+    second = train = fp16_eval = evloop = None
     extra = world == 1 or a.all_blocks
+    if (extra or a.eval_loop) and not a.no_eval_loop:
+        try:
+            evloop = eval_loop_block(G, res, batch, a.steps, a, dev, rank, world, barrier, use_dist, backend)
+        except Exception as e:             # informational block: never lose the headline over it
+            if world > 1:
+                raise
+            evloop = {'error': repr(e)[:400]}
     if extra and not a.no_second_config and res == 512 and a.batch is None:
         second = forward_block(256, 32, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend)
         fp16_eval = forward_block(512, 16, max(10, a.steps // 2), 6, a, dev, rank, world, barrier, use_dist, backend, fp16=True)
@@ -581,7 +687,11 @@ def worker(local_rank, a, spawned_world=None, port=None):
                        'stream_pipeline_depth': a.pipeline_depth, 'hip_graph': graph_info,
                        'ms_per_step_by_rank': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3),
                                                'all': [round(v, 3) for v in rank_ms],
-                                               'note': 'each rank\'s own loop time (before the closing barrier); ms_per_step = barrier-to-barrier, max over ranks'}},
+                                               'note': 'each rank\'s own loop time (before the closing barrier); ms_per_step = barrier-to-barrier, max over ranks'},
+                       'host_enqueue_ms_per_step_by_rank': {'min': round(min(issue_ms), 3), 'max': round(max(issue_ms), 3),
+                                                            'all': [round(v, 3) for v in issue_ms],
+                                                            'note': 'wall time a rank\'s interpreter needs to enqueue one step (eager: ~150 ctypes '
+                                                                    'launches; graph: one replay); the step is host-bound where this reaches ms_per_step'}},
             'pipeline': {'depth': a.pipeline_depth, 'ms_per_step_single_stream': round(lat_ms, 3) if lat_ms else None,
                          'note': 'the K timed steps are independent batches issued round-robin on `depth` HIP streams '
                                  '(eval_harness.StreamPipeline, the evaluation loop of the product): the launch-boundary gaps of '
@@ -592,6 +702,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
             'roofline': roof,
             'hbm': {'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'classes': hbm},
             'shu': shu,
+            'eval_loop': evloop,
             'second_config': second,
             'fp16_blocks_eval': fp16_eval,
             'train_step': train,

@@ -62,6 +62,16 @@ int shg_bias_act_backward_f32(const float* g, const float* y, float* dx, long to
                               void* stream);
 /* stylegan_utils/fma.py:15 -- y = a*b + c, elementwise on `total` floats. */
 int shg_fma_f32(const float* a, const float* b, const float* c, float* y, long total, void* stream);
+/* stylegan_utils/fma.py:15-58 with NumPy broadcasting and without materialising it: y (contiguous, `shape`) = a*b + c, each operand
+ * addressed through element strides (0 on a broadcast dimension); c may be NULL (y = a*b, the product of fma.py:41,44).  nd <= 6
+ * (collapse neighbouring dimensions first); f64 != 0: operands are doubles. */
+int shg_fma_bcast(const void* a, const void* b, const void* c, void* y, int nd, const long* shape, const long* sa, const long* sb,
+                  const long* sc, int f64, void* stream);
+/* `_unbroadcast(g * b, shape)` (fma.py:48-58) in one pass: dimensions ordered kept-first (nk of them), reduced-last; out (contiguous,
+ * the kept sizes) = sum over the reduced index of g*b (b NULL: of g).  inner_kept != 0 when g's fastest-varying dimension is a kept
+ * one (one thread per output), 0 for one workgroup per output along the reduced index.  Fixed summation order: deterministic. */
+int shg_mul_reduce(const void* g, const void* b, void* out, int nd, int nk, const long* shape, const long* sg, const long* sb,
+                   int inner_kept, int f64, void* stream);
 /* stylegan.py:173 -- y[nc,:] = x[nc,:] * s[nc]. */
 int shg_scale_channels_f32(const float* x, const float* s, float* y, int NC, int HW, void* stream);
 /* out [N,K] = sum over b of part [N,B,K] in block order (the per-workgroup partial sums of shg_modtail_backward_*: deterministic). */
@@ -275,6 +285,9 @@ int shg_composite_u8(const float* x4, const float* img, uint8_t* out, int N, int
 /* ---- input hand-off of the eval loop (lib/experiments/shgan_default.py:267-274): x = cat([mask-0.5, real*mask]).
  * real [N,3,H,W] in [-1,1], mask [N,H,W] in {0,1} -> x [N,4,H,W]. */
 int shg_assemble_input_f32(const float* real, const float* mask, float* x, int N, int H, int W, void* stream);
+/* The same from decoded uint8 pixels (ds_ffhq.py:307-347 + shgan_default.py:267-274): real [N,3,H,W] uint8, lut [256] = the float value of
+ * every code as the host formatter computes it (torch: u8.float().div(255)*2-1), so the result equals the host route bit for bit. */
+int shg_assemble_input_u8(const uint8_t* real, const float* mask, const float* lut, float* x, int N, int H, int W, void* stream);
 
 /* ---- next row N2: freeform-mask rasteriser (lib/data_factory/ds_ffhq.py:145-217).  The host makes the random draws in the
  * reference's order and emits 8-word int32 records per mask (RECT / DISC / QUAD + 4 EDGE / POINT, see csrc/mask_raster.hip);

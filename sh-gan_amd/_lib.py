@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libshgan_hip.so')
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 c_fp = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
@@ -42,6 +42,8 @@ _SIGS = {
     'shg_upfirdn2d_epilogue_f32': [c_fp, c_fp, c_fp] + [c_i] * 15 + [c_f, c_fp, c_fp, c_fp, c_i, c_f, c_i, c_f, c_f, c_f, c_fp, c_fp],
     'shg_bias_act_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp],
     'shg_fma_f32': [c_fp, c_fp, c_fp, c_fp, c_l, c_fp],
+    'shg_fma_bcast': [c_fp, c_fp, c_fp, c_fp, c_i] + [ctypes.POINTER(c_l)] * 4 + [c_i, c_fp],
+    'shg_mul_reduce': [c_fp, c_fp, c_fp, c_i, c_i] + [ctypes.POINTER(c_l)] * 3 + [c_i, c_i, c_fp],
     'shg_scale_channels_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_fp],
     'shg_sum_partials_f32': [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_scale_cast_f32_f16': [c_fp, c_fp, c_l, c_f, c_i, c_fp],
@@ -89,6 +91,7 @@ _SIGS = {
     'shg_shu_split_adjoint_f32': [c_pp, ctypes.POINTER(c_l), c_pp, c_fp, c_i, c_i, c_fp],
     'shg_composite_u8': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_assemble_input_f32': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'shg_assemble_input_u8': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'shg_conv_weight_prep_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'shg_conv2d_up_poly_supported': [c_i, c_i, c_i, c_i, c_i],
     'shg_conv2d_up_poly_f32': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp],
@@ -157,6 +160,9 @@ def get_lib():
     lib.shg_last_error.restype = ctypes.c_char_p
     lib.shg_conv2d_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_wino_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_wino4_workspace_bytes.restype = ctypes.c_size_t
+    lib.shg_conv2d_up_poly_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_wino_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_wgrad_f16_workspace_bytes.restype = ctypes.c_size_t
     lib.shg_conv2d_f16_packed_weight_elems.restype = c_l

@@ -14,7 +14,7 @@ void shg_set_error(const char* fmt, ...) {
 extern "C" const char* shg_last_error(void) { return g_err; }
 
 // bump when an exported signature changes (checked by the Python loader)
-extern "C" int shg_abi_version(void) { return 35; }
+extern "C" int shg_abi_version(void) { return 36; }
 
 // name of the GCN arch of device `dev` (e.g. "gfx950:sramecc+:xnack-") into buf; returns CU count or <0
 extern "C" int shg_device_info(int dev, char* buf, int buflen) {

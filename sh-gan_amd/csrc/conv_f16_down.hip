@@ -249,19 +249,15 @@ int conv_down_launch(const ConvP& p0, int pad, hipStream_t st) {
     if (ntiles > 0x7fffffffL) { shg_set_error("conv2d_f16 (stride 2): too many tiles"); return SHG_ERR_ARG; }
     P.ntiles = (int)ntiles;
     P.m_ot = 0xFFFFFFFFu / (unsigned)P.n_ot; P.m_tx = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.m_ty = 0xFFFFFFFFu / (unsigned)P.tiles_y;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    static bool attr = false;
-    if (!attr) {
+    const int cus = shg_cu_count();
+    static ShgDeviceOnce attr_once;
+    const int dev_now = shg_current_device();
+    if (attr_once.pending(dev_now)) {
         if (hipFuncSetAttribute((const void*)down::conv_f16_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, down::LDS_BYTES) != hipSuccess) {
             shg_set_error("conv2d_f16 (stride 2): cannot reserve %d bytes of LDS", down::LDS_BYTES);
             return SHG_ERR_LAUNCH;
         }
-        attr = true;
+        attr_once.mark(dev_now);
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
     hipLaunchKernelGGL(down::conv_f16_down_kernel, dim3(grid), dim3(512), down::LDS_BYTES, st, P);

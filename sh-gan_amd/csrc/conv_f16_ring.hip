@@ -406,19 +406,15 @@ int conv_ring_launch(const ConvP& p0, int span_y, int span_x, hipStream_t st) {
     p.tiles_x = shg_cdiv(p.GW, ring::TW);
     const int n_ot = (p.O + 63) / 64;
     const long ntiles = (long)p.N * p.tiles_y * p.tiles_x * n_ot;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    static bool attr = false;
-    if (!attr) {
+    const int cus = shg_cu_count();
+    static ShgDeviceOnce attr_once;
+    const int dev_now = shg_current_device();
+    if (attr_once.pending(dev_now)) {
         if (hipFuncSetAttribute((const void*)ring::conv_f16_ring_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ring::LDS_BYTES) != hipSuccess) {
             shg_set_error("conv2d_f16 (ring): cannot reserve %d bytes of LDS", ring::LDS_BYTES);
             return SHG_ERR_LAUNCH;
         }
-        attr = true;
+        attr_once.mark(dev_now);
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
     const ring::RingDiv dv{(unsigned)n_ot, (unsigned)p.tiles_x, (unsigned)p.tiles_y, 0xFFFFFFFFu / (unsigned)n_ot, 0xFFFFFFFFu / (unsigned)p.tiles_x,

@@ -268,19 +268,15 @@ int convt_upring_launch(const ConvP& p0, int crop, hipStream_t st) {
     if (ntiles > 0x7fffffffL) { shg_set_error("conv2d_f16 (transposed): too many tiles"); return SHG_ERR_ARG; }
     P.ntiles = (int)ntiles;
     P.m_ot = 0xFFFFFFFFu / (unsigned)P.n_ot; P.m_tx = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.m_ty = 0xFFFFFFFFu / (unsigned)P.tiles_y;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    static bool attr = false;
-    if (!attr) {
+    const int cus = shg_cu_count();
+    static ShgDeviceOnce attr_once;
+    const int dev_now = shg_current_device();
+    if (attr_once.pending(dev_now)) {
         if (hipFuncSetAttribute((const void*)upring::conv_f16_upring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, upring::LDS_BYTES) != hipSuccess) {
             shg_set_error("conv2d_f16 (transposed): cannot reserve %d bytes of LDS", upring::LDS_BYTES);
             return SHG_ERR_LAUNCH;
         }
-        attr = true;
+        attr_once.mark(dev_now);
     }
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
     hipLaunchKernelGGL(upring::conv_f16_upring_kernel, dim3(grid), dim3(512), upring::LDS_BYTES, st, P);

@@ -644,16 +644,7 @@ static int conv_up_min() {
 #endif
 }
 
-static int conv_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int conv_cu_count() { return shg_cu_count(); }
 
 // Upper bound of the tail-split workspace of the one-workgroup-per-CU kernels: < CU-count tile-slices of at most
 // 128 x 128 x 4 (transposed) or 128 x 256 accumulators.

@@ -246,8 +246,9 @@ extern "C" int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* 
     const size_t need = p.nslice > 1 ? (size_t)p.nslice * O * I * 9 * sizeof(float) : 0;
     SHG_CHECK_ARG(need == 0 || (workspace && ws_bytes >= need), "conv2d_wgrad_wino: workspace too small (shg_conv2d_wgrad_wino_workspace_bytes)");
     p.out = p.nslice > 1 ? (float*)workspace : dw;
-    static bool attr = false;
-    if (!attr) {
+    static ShgDeviceOnce attr_once;
+    const int dev_now = shg_current_device();
+    if (attr_once.pending(dev_now)) {
         if (hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
             hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
             hipFuncSetAttribute((const void*)wgw::conv_wgrad_wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * wgw::STAGE) != hipSuccess ||
@@ -255,7 +256,7 @@ extern "C" int shg_conv2d_wgrad_wino_f32(const float* x, const float* g, float* 
             shg_set_error("conv2d_wgrad_wino: cannot reserve %d bytes of LDS", 2 * wgw::STAGE);
             return SHG_ERR_LAUNCH;
         }
-        attr = true;
+        attr_once.mark(dev_now);
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(shg_cdiv(I, wgw::BI), shg_cdiv(O, wgw::BO), p.nslice);

@@ -152,6 +152,182 @@ extern "C" int shg_fma_f32(const float* a, const float* b, const float* c, float
 }
 
 // ---------------------------------------------------------------------------------------------
+// The generic op with NumPy broadcasting (stylegan_utils/fma.py:15-58): operands are addressed through element strides (0 on a
+// broadcast dimension) so that nothing is materialised, and the gradient of a broadcast operand -- `_unbroadcast(dout * b)`,
+// fma.py:40-58 -- is ONE product + reduction pass.  float32 and float64 (the public op is differentiable twice and is held to
+// finite differences in float64).  Dimensions are collapsed by the caller; at most SHG_BC_DIMS remain.
+// ---------------------------------------------------------------------------------------------
+#define SHG_BC_DIMS 6
+struct ShgBcast {
+    int nd;
+    long size[SHG_BC_DIMS];
+    long sa[SHG_BC_DIMS], sb[SHG_BC_DIMS], sc[SHG_BC_DIMS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void fma_bcast_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                        T* __restrict__ y, long total, ShgBcast g) {
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        long r = e, ia = 0, ib = 0, ic = 0;
+#pragma unroll
+        for (int d = SHG_BC_DIMS - 1; d >= 0; --d) {
+            if (d < g.nd) {
+                const long q = r / g.size[d], i = r - q * g.size[d];
+                r = q;
+                ia += i * g.sa[d];
+                ib += i * g.sb[d];
+                ic += i * g.sc[d];
+            }
+        }
+        const T p = a[ia] * b[ib];
+        y[e] = c ? T(a[ia] * b[ib] + c[ic]) : p;
+    }
+}
+// float32: one rounding, as torch.addcmul's fused form on the device
+template <>
+__global__ __launch_bounds__(256) void fma_bcast_kernel<float>(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ c, float* __restrict__ y, long total, ShgBcast g) {
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        long r = e, ia = 0, ib = 0, ic = 0;
+#pragma unroll
+        for (int d = SHG_BC_DIMS - 1; d >= 0; --d) {
+            if (d < g.nd) {
+                const long q = r / g.size[d], i = r - q * g.size[d];
+                r = q;
+                ia += i * g.sa[d];
+                ib += i * g.sb[d];
+                ic += i * g.sc[d];
+            }
+        }
+        y[e] = c ? fmaf(a[ia], b[ib], c[ic]) : a[ia] * b[ib];
+    }
+}
+
+static int shg_bcast_fill(ShgBcast& g, int nd, const long* shape, const long* sa, const long* sb, const long* sc, long& total) {
+    if (nd < 0 || nd > SHG_BC_DIMS) return -1;
+    g.nd = nd;
+    total = 1;
+    for (int d = 0; d < SHG_BC_DIMS; ++d) {
+        g.size[d] = d < nd ? shape[d] : 1;
+        g.sa[d] = d < nd && sa ? sa[d] : 0;
+        g.sb[d] = d < nd && sb ? sb[d] : 0;
+        g.sc[d] = d < nd && sc ? sc[d] : 0;
+        if (g.size[d] < 0) return -1;
+        total *= g.size[d];
+    }
+    return 0;
+}
+
+extern "C" int shg_fma_bcast(const void* a, const void* b, const void* c, void* y, int nd, const long* shape, const long* sa,
+                             const long* sb, const long* sc, int f64, void* stream) {
+    SHG_CHECK_ARG(a && b && y && (nd == 0 || (shape && sa && sb)) && (!c || nd == 0 || sc), "fma_bcast: null pointer");
+    ShgBcast g;
+    long total;
+    SHG_CHECK_ARG(shg_bcast_fill(g, nd, shape, sa, sb, sc, total) == 0, "fma_bcast: at most %d (collapsed) dimensions, sizes >= 0", SHG_BC_DIMS);
+    if (total == 0) return SHG_OK;
+    int grid = shg_cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    if (f64)
+        hipLaunchKernelGGL(fma_bcast_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double*)a, (const double*)b,
+                           (const double*)c, (double*)y, total, g);
+    else
+        hipLaunchKernelGGL(fma_bcast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
+                           (const float*)c, (float*)y, total, g);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// out[kept index] = sum over the reduced index of g * b (b == nullptr: of g).  The caller orders the dimensions KEPT FIRST, REDUCED
+// LAST (nk kept dimensions), so that `out` is the contiguous tensor of the kept sizes.  Two mappings, chosen by the caller from
+// the strides: `inner_kept` -- the fastest-varying dimension of g is a kept one: one thread per output, neighbouring threads read
+// neighbouring addresses, the reduction is a serial walk; otherwise one workgroup per output with its 256 lanes along the
+// reduced index (coalesced when the fastest dimension is reduced) and a fixed-order tree in LDS.  Both orders are fixed: deterministic.
+template <typename T>
+__device__ __forceinline__ T mul_reduce_term(const T* __restrict__ g, const T* __restrict__ b, long r, long og, long ob, const ShgBcast& s, int nk) {
+    long ig = og, ib = ob;
+#pragma unroll
+    for (int d = SHG_BC_DIMS - 1; d >= 0; --d) {
+        if (d >= nk && d < s.nd) {
+            const long q = r / s.size[d], i = r - q * s.size[d];
+            r = q;
+            ig += i * s.sa[d];
+            ib += i * s.sb[d];
+        }
+    }
+    return b ? g[ig] * b[ib] : g[ig];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mul_reduce_kernel(const T* __restrict__ g, const T* __restrict__ b, T* __restrict__ out, long n_out,
+                                                         long n_red, ShgBcast s, int nk, int inner_kept) {
+    __shared__ T part[256];
+    if (inner_kept) {
+        const long o = (long)blockIdx.x * 256 + threadIdx.x;
+        if (o >= n_out) return;
+        long r = o, og = 0, ob = 0;
+#pragma unroll
+        for (int d = SHG_BC_DIMS - 1; d >= 0; --d) {
+            if (d < nk) {
+                const long q = r / s.size[d], i = r - q * s.size[d];
+                r = q;
+                og += i * s.sa[d];
+                ob += i * s.sb[d];
+            }
+        }
+        T acc = T(0);
+        for (long k = 0; k < n_red; ++k) acc += mul_reduce_term(g, b, k, og, ob, s, nk);
+        out[o] = acc;
+        return;
+    }
+    for (long o = blockIdx.x; o < n_out; o += gridDim.x) {
+        long r = o, og = 0, ob = 0;
+#pragma unroll
+        for (int d = SHG_BC_DIMS - 1; d >= 0; --d) {
+            if (d < nk) {
+                const long q = r / s.size[d], i = r - q * s.size[d];
+                r = q;
+                og += i * s.sa[d];
+                ob += i * s.sb[d];
+            }
+        }
+        T acc = T(0);
+        for (long k = threadIdx.x; k < n_red; k += 256) acc += mul_reduce_term(g, b, k, og, ob, s, nk);
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[o] = part[0];
+        __syncthreads();
+    }
+}
+
+extern "C" int shg_mul_reduce(const void* g, const void* b, void* out, int nd, int nk, const long* shape, const long* sg, const long* sb,
+                              int inner_kept, int f64, void* stream) {
+    SHG_CHECK_ARG(g && out && (nd == 0 || (shape && sg)) && (!b || nd == 0 || sb), "mul_reduce: null pointer");
+    SHG_CHECK_ARG(nk >= 0 && nk <= nd, "mul_reduce: kept dimensions %d of %d", nk, nd);
+    ShgBcast s;
+    long total;
+    SHG_CHECK_ARG(shg_bcast_fill(s, nd, shape, sg, sb, nullptr, total) == 0, "mul_reduce: at most %d (collapsed) dimensions, sizes >= 0", SHG_BC_DIMS);
+    long n_out = 1, n_red = 1;
+    for (int d = 0; d < nd; ++d) (d < nk ? n_out : n_red) *= shape[d];
+    if (n_out == 0) return SHG_OK;
+    long grid = inner_kept ? (n_out + 255) / 256 : (n_out < 65536 ? n_out : 65536);
+    SHG_CHECK_ARG(grid <= 0x7fffffffL, "mul_reduce: too many outputs");
+    if (f64)
+        hipLaunchKernelGGL(mul_reduce_kernel<double>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const double*)g, (const double*)b,
+                           (double*)out, n_out, n_red, s, nk, inner_kept);
+    else
+        hipLaunchKernelGGL(mul_reduce_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)b,
+                           (float*)out, n_out, n_red, s, nk, inner_kept);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Thin 1x1 convolution: y[n,o,p] = act(sum_i w[o,i]*wgain * x[n,i,p] * s[n,i] + bias[o]) [+ base]
 // for small I (fromrgb, I = 4) or small O (torgb, O = 3): one lane per 4 pixels, float4 I/O.
 // `base_up` (optional) is the previous-resolution RGB image [N,O,H/2,W/2]; it is FIR-upsampled x2
@@ -686,6 +862,39 @@ extern "C" int shg_assemble_input_f32(const float* real, const float* mask, floa
     if (N == 0) return SHG_OK;
     const long total4 = (long)N * (H * W / 4);
     hipLaunchKernelGGL(assemble_input_kernel, dim3(shg_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, real, mask, x, H * W / 4, total4);
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
+// The same hand-off from the DECODED bytes (ds_ffhq.py:307-347: uint8 -> ToTensor /255 -> *2-1; shgan_default.py:267-274): the loader
+// ships uint8 pixels (a quarter of the PCIe bytes of float images) and the value of every code comes from a 256-entry table the
+// caller computed with the host formatter's own arithmetic, so x is bit-identical to the host route whatever that arithmetic rounds to.
+__global__ __launch_bounds__(256) void assemble_input_u8_kernel(const uint8_t* real, const float* mask, const float* lut, float* x, int HW4,
+                                                                long total4) {
+    __shared__ float tab[256];
+    tab[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;          // four pixels of one image plane
+    if (e >= total4) return;
+    const int n = (int)(e / HW4), q = (int)(e - (long)n * HW4);
+    const float4 m = reinterpret_cast<const float4*>(mask)[(long)n * HW4 + q];
+    float4* xo = reinterpret_cast<float4*>(x) + (long)n * 4 * HW4 + q;
+    xo[0] = make_float4(m.x - 0.5f, m.y - 0.5f, m.z - 0.5f, m.w - 0.5f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uchar4 r = reinterpret_cast<const uchar4*>(real)[((long)n * 3 + c) * HW4 + q];
+        xo[(long)(c + 1) * HW4] = make_float4(tab[r.x] * m.x, tab[r.y] * m.y, tab[r.z] * m.z, tab[r.w] * m.w);
+    }
+}
+
+extern "C" int shg_assemble_input_u8(const uint8_t* real, const float* mask, const float* lut, float* x, int N, int H, int W, void* stream) {
+    SHG_CHECK_ARG(real && mask && lut && x, "assemble_input_u8: null pointer");
+    SHG_CHECK_ARG(N >= 0 && H >= 1 && W >= 1 && (H * W) % 4 == 0, "assemble_input_u8: H*W must be a positive multiple of 4");
+    SHG_CHECK_ARG(((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (reinterpret_cast<uintptr_t>(real) & 3) == 0,
+                  "assemble_input_u8: mask / x must be 16-byte aligned, real 4-byte aligned");
+    if (N == 0) return SHG_OK;
+    const long total4 = (long)N * (H * W / 4);
+    hipLaunchKernelGGL(assemble_input_u8_kernel, dim3(shg_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, real, mask, lut, x, H * W / 4, total4);
     SHG_CHECK_LAUNCH();
     return SHG_OK;
 }

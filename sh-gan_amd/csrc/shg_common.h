@@ -33,6 +33,31 @@ void shg_set_error(const char* fmt, ...);
 
 static inline int shg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Per-device launch state.  A process may drive several devices (threaded data parallelism, a consumer that switches devices): the
+// CU count and the "dynamic LDS above 64 KiB" function attribute belong to the CURRENT device, not to the process.  Lock-free: a
+// racing thread recomputes the same value / sets the same attribute again.
+#define SHG_MAX_DEVICES 64
+static inline int shg_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SHG_MAX_DEVICES) d = 0;
+    return d;
+}
+static inline int shg_cu_count() {
+    static int cus[SHG_MAX_DEVICES];
+    const int d = shg_current_device();
+    int c = __atomic_load_n(&cus[d], __ATOMIC_RELAXED);
+    if (!c) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+        __atomic_store_n(&cus[d], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
+struct ShgDeviceOnce {
+    int done[SHG_MAX_DEVICES];
+    bool pending(int d) const { return !__atomic_load_n(&done[d], __ATOMIC_ACQUIRE); }
+    void mark(int d) { __atomic_store_n(&done[d], 1, __ATOMIC_RELEASE); }
+};
+
 // leaky-relu -> *gain -> clamp  (common/utils.py:135-143); clamp < 0 disables clamping.
 __device__ __forceinline__ float shg_lrelu_agc(float v, float alpha, float gain, float clamp) {
     v = v < 0.f ? v * alpha : v;

@@ -13,18 +13,22 @@ from .data import DistributedSampler, RandomMask, zipzap_arrange
 def assemble_input(real, mask):
     """real [N,3,R,R] in [-1,1], mask [N,1,R,R] in {0,1} -> x = cat([mask-0.5, real*mask]) (shgan_default.py:270-274)."""
     if real.is_cuda:
-        return kernels.assemble_input(real.float(), mask.float())       # one HIP kernel instead of sub + mul + cat
+        # one HIP kernel instead of sub + mul + cat; decoded uint8 pixels are converted in the same pass (kernels.u8_value_table)
+        return kernels.assemble_input(real if real.dtype == torch.uint8 else real.float(), mask.float())
+    if real.dtype == torch.uint8:                                       # decoded pixels: ToTensor (/255) + the formatter's *2-1
+        real = kernels.u8_value_table('cpu')[real.long()]
     return torch.cat([mask - 0.5, real * mask], dim=1)                  # host tensors (dataloader side): plain torch
 
 
-def run_generator(G, x, z, c=None, noise_mode='random'):
+def run_generator(G, x, z, c=None, noise_mode='random', out=None):
     """x [N,4,R,R], z [N,z_dim] -> uint8 [N,3,R,R]: generated pixels inside the hole, the known pixels
-    elsewhere (shgan_default.py:257-262; float->uint8 is a truncation)."""
+    elsewhere (shgan_default.py:257-262; float->uint8 is a truncation).  ``out``: write into this uint8 tensor (a slice of
+    the evaluation loop's result buffer)."""
     if c is None:
         c = torch.zeros([x.shape[0], G.c_dim], device=x.device)
     with torch.no_grad():
         img = G(x=x, z=z, c=c, noise_mode=noise_mode)
-    return kernels.composite_u8(x, img)
+    return kernels.composite_u8(x, img, out=out)
 
 
 def synthetic_batch(n, resolution, z_dim=512, seed=0, device='cuda', masks='freeform'):
@@ -95,8 +99,10 @@ class StreamPipeline:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)] if (depth > 1 and self.device.type == 'cuda') else []
         self.k = 0
         self.outs = []
+        self.last_stream = None        # the stream the latest batch was issued on (None: the caller's)
 
     def run(self, fn, *args):
+        self.last_stream = None
         if not self.streams:
             return fn(*args)
         if self.k == 0:
@@ -108,6 +114,7 @@ class StreamPipeline:
             return out
         s = self.streams[self.k % len(self.streams)]
         self.k += 1
+        self.last_stream = s
         s.wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
         with torch.cuda.stream(s):
             out = fn(*args)
@@ -122,8 +129,9 @@ class StreamPipeline:
         for s in self.streams:
             cur.wait_stream(s)
         for o in self.outs:
-            if torch.is_tensor(o) and o.is_cuda:
-                o.record_stream(cur)
+            for t in (o if isinstance(o, (tuple, list)) else (o,)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
         self.outs = []
 
 
@@ -237,3 +245,186 @@ def sharded_eval(G, n_items, batch_size, resolution, rank=0, world=1, seed=0, ga
     order = zipzap_arrange(per_rank_ids)[:n_items]
     merged = zipzap_arrange([full[r].cpu().numpy() for r in range(world)])[:n_items]
     return order, merged
+
+
+def zipzap_device(full, n_items):
+    """``zipzap_arrange`` (eva_base.py:196-230) of equally long rank shards, on the device: full [world, n_local, ...] (rank r's
+    k-th result at [r, k]) -> [n_items, ...] in dataset order (item k*world + r), the padded duplicates of
+    ``DistributedSampler(extend=True)`` cut off.  One transposing copy instead of a host round trip of the whole result set."""
+    world, n_local = full.shape[:2]
+    return full.transpose(0, 1).reshape((world * n_local,) + tuple(full.shape[2:]))[:n_items]
+
+
+def standin_features(images_u8, dim=2048):
+    """Stand-in for the feature detector of the FID stage (eva_fid.py:145-158,194-206: an Inception-v3 TorchScript download, not
+    reproducible offline): a fixed linear map of the uint8 images to [B, dim] -- the mean of ``dim`` contiguous pixel runs.  It only
+    gives the moment accumulation, the collectives and the loop's timing a feature tensor of the real shape; it measures nothing."""
+    b = images_u8.shape[0]
+    flat = images_u8.reshape(b, -1)
+    per = flat.shape[1] // dim
+    return flat[:, :per * dim].reshape(b, dim, per).to(torch.float32).mean(dim=2)
+
+
+def broadcast_state(module, src=0, group=None):
+    """Rank ``src``'s parameters and buffers to every rank in ONE flat float32 ``dist.broadcast`` (RCCL over xGMI on GPUs, gloo on
+    CPU tensors): what the reference gets from the ``DistributedDataParallel`` constructor after rank 0 alone has read the
+    checkpoint (shgan_default.py:138-154,223-231; 317 MB for the 512 generator, SURVEY 8(e) collective (1)).  Non-float32 state
+    (integer counters) travels in a second, small broadcast.  Parameters are written with ``copy_`` so the prepared-weight caches
+    (version counters) follow.  No-op without an initialised process group; a 1-rank group runs the collective too.
+    Returns the number of bytes broadcast."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    tensors = [t for _, t in sorted(list(module.named_parameters()) + list(module.named_buffers()), key=lambda kv: kv[0])]
+    f32 = [t for t in tensors if t.dtype == torch.float32]
+    other = [t for t in tensors if t.dtype != torch.float32]
+    total = 0
+    with torch.no_grad():
+        for grp, dt in ((f32, torch.float32), (other, torch.float64)):
+            if not grp:
+                continue
+            dev = grp[0].device
+            flat = torch.empty(sum(t.numel() for t in grp), dtype=dt, device=dev)
+            if dist.get_rank(group) == src:
+                off = 0
+                for t in grp:
+                    flat[off:off + t.numel()].copy_(t.detach().reshape(-1))
+                    off += t.numel()
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in grp:
+                t.copy_(flat[off:off + t.numel()].reshape(t.shape).to(t.dtype))
+                off += t.numel()
+            total += flat.numel() * flat.element_size()
+    return total
+
+
+class EvalLoop:
+    """The evaluation loop the path exists for (lib/experiments/shgan_default.py:264-300; BASELINE config 4 = one rank of it), as a
+    streamed loop on ONE rank's shard:
+
+        per batch   loader (host: decoded uint8 or float images, ids)  ->  H2D on the copy stream under the previous batch's kernels
+                    (datasets.DeviceFeeder)  ->  freeform masks drawn on the device (masks.random_masks, the reference's numpy
+                    draws in its order)  ->  x = cat([mask - .5, real * mask])  ->  z ~ N(0, 1)  ->  G + uint8 composite written
+                    INTO the rank's result buffer at the batch's position  ->  features (``feature_fn``, the detector hand-off of
+                    eva_fid.py:194-206)  ->  fp64 moments on the device (fid_stats.FidStats; padded duplicates weigh 0);
+        at the end  ONE all-reduce of the moments and ONE all-gather of the uint8 results + the zipzap re-interleave on the device
+                    (the reference: 3 x world broadcasts per batch, eva_base.py:96-188, python lists on rank 0).
+
+    Consecutive batches are issued round-robin on ``depth`` HIP streams (StreamPipeline); the moment kernel accumulates in place and
+    therefore runs on one statistics stream, in batch order, behind an event of the batch's stream.  Nothing in the loop waits for
+    the device except the mask rasteriser's hole-count read (one small D2H per batch on the caller's stream, which carries only the
+    input staging).  ``latent_fn(ids, B) -> z`` replaces ``torch.randn`` (tests: per-item latents so that a result can be compared
+    id by id); ``on_batch(ids, images_u8, event)`` hands every finished batch to a consumer (host metrics) without ending the loop."""
+
+    def __init__(self, G, device, resolution, n_items, rank=0, world=1, noise_mode='random', seed=0, depth=None, feature_fn=None,
+                 fid_dim=2048, latent_fn=None, device_masks=True, hole_range=(0, 1), keep_images=True, on_batch=None, step_fn=None,
+                 fid_accumulate_fn=None):
+        from .datasets import DeviceFeeder
+        from .fid_stats import FidStats
+        self.G, self.device, self.res = G, torch.device(device), int(resolution)
+        self.n_items, self.rank, self.world = int(n_items), int(rank), int(world)
+        self.noise_mode, self.seed, self.depth = noise_mode, seed, depth
+        self.feature_fn, self.latent_fn, self.on_batch = feature_fn, latent_fn, on_batch
+        self.step_fn = step_fn          # (x4, z, out) -> uint8 images: the CPU world-size-2 tests inject a stand-in; the product path is run_generator
+        self.ids = shard_ids(self.n_items, self.rank, self.world)
+        self.feeder = DeviceFeeder(self.device, self.res, hole_range=hole_range, device_masks=device_masks)
+        self.fid = FidStats(fid_dim, device=self.device, accumulate_fn=fid_accumulate_fn) if feature_fn is not None else None
+        self.images = (torch.empty((len(self.ids), 3, self.res, self.res), dtype=torch.uint8, device=self.device) if keep_images else None)
+        self.stats_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self.seen = 0
+
+    def run(self, loader):
+        """``loader`` yields this rank's items in ``shard_ids`` order as (images [B,3,R,R] uint8 or float32 in [-1,1], ids) or
+        (images, masks [B,R,R], ids).  Returns self (``images``, ``fid``, ``seen``)."""
+        if self.noise_mode == 'random':
+            torch.manual_seed(self.seed * self.world + self.rank)          # shgan_default.py:165-167
+        pipe = StreamPipeline(self.device, depth=self.depth)
+        G, buf = self.G, self.images
+        for x4, real, mask, ids in self.feeder(loader):
+            b, k0 = x4.shape[0], self.seen
+            if k0 + b > len(self.ids):
+                raise ValueError(f'EvalLoop: the loader yielded more than the {len(self.ids)} items of this rank\'s shard')
+            z = self.latent_fn(ids, b) if self.latent_fn is not None else torch.randn([b, G.z_dim], device=self.device)
+            gen = self.step_fn if self.step_fn is not None else (lambda x_, z_, o_: run_generator(G, x_, z_, noise_mode=self.noise_mode, out=o_))
+            dst = buf[k0:k0 + b] if buf is not None else None
+
+            def step(x4_, z_, dst=dst):
+                out = gen(x4_, z_, dst)
+                return out, (self.feature_fn(out) if self.feature_fn is not None else None)
+            out, feats = pipe.run(step, x4, z)
+            ev = None
+            if self.stats_stream is not None and (self.fid is not None or self.on_batch is not None):
+                ev = torch.cuda.Event()
+                ev.record(pipe.last_stream or torch.cuda.current_stream(self.device))
+            if self.fid is not None and self.stats_stream is not None:
+                self.stats_stream.wait_event(ev)
+                with torch.cuda.stream(self.stats_stream):
+                    self.fid.add_shard(feats, k0, self.rank, self.world, self.n_items)
+                feats.record_stream(self.stats_stream)
+            elif self.fid is not None:
+                self.fid.add_shard(feats, k0, self.rank, self.world, self.n_items)
+            if self.on_batch is not None:
+                self.on_batch(ids, out, ev)
+            self.seen += b
+        pipe.join()
+        if self.stats_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stats_stream)
+        return self
+
+    def gather(self):
+        """-> (uint8 images [n_items,3,R,R] in dataset order on the device, FidStats summed over the ranks | None).  One
+        ``all_gather_into_tensor`` + ``zipzap_device``; one ``all_reduce`` of the moments.  Every rank must have run its whole shard."""
+        import torch.distributed as dist
+        if self.seen != len(self.ids):
+            raise ValueError(f'EvalLoop.gather: {self.seen} of {len(self.ids)} items of this rank\'s shard were processed')
+        use = dist.is_available() and dist.is_initialized()
+        images = None
+        if self.images is not None:
+            if use:
+                # RCCL gathers device tensors over xGMI; a gloo group (CPU tests, ranks sharing one device) is handed host tensors
+                via_host = dist.get_backend() == 'gloo' and self.images.is_cuda
+                local = self.images.cpu() if via_host else self.images
+                full = torch.empty((self.world,) + tuple(local.shape), dtype=torch.uint8, device=local.device)
+                dist.all_gather_into_tensor(full.view((-1,) + tuple(local.shape[1:])), local)
+                full = full.to(self.device)
+            else:
+                full = self.images[None]
+            images = zipzap_device(full, self.n_items)
+        if self.fid is not None:
+            self.fid.all_reduce()
+        return images, self.fid
+
+
+class PinnedU8Loader:
+    """Synthetic stand-in for the decode workers of the dataset (ds_ffhq.py:307-330; PNG / zip decode is outside the path): yields
+    (uint8 images [B,3,R,R] in pinned host memory, ids) for ``ids`` in order.  Item i is drawn from a generator seeded with
+    (seed, i) -- the same pixels whichever rank / batch holds it; ``pool`` > 0 cycles through that many pre-drawn batches instead
+    (throughput runs: drawing 12.6 MB of random bytes per batch on the host would time numpy, not the loop)."""
+
+    def __init__(self, ids, batch_size, resolution, seed=0, pool=0):
+        self.ids, self.b, self.res, self.seed, self.pool = list(ids), int(batch_size), int(resolution), seed, int(pool)
+        self._cache = []
+
+    def _draw(self, ids):
+        out = torch.empty((len(ids), 3, self.res, self.res), dtype=torch.uint8)
+        g = torch.Generator()
+        for k, i in enumerate(ids):
+            g.manual_seed(int(self.seed) * 1000003 + int(i))
+            out[k].random_(0, 256, generator=g)
+        return out.pin_memory() if torch.cuda.is_available() else out
+
+    def __len__(self):
+        return (len(self.ids) + self.b - 1) // self.b
+
+    def __iter__(self):
+        for n, b0 in enumerate(range(0, len(self.ids), self.b)):
+            ids = self.ids[b0:b0 + self.b]
+            if self.pool:
+                slot = n % self.pool
+                if slot >= len(self._cache):
+                    self._cache.append(self._draw(ids))
+                img = self._cache[slot][:len(ids)]
+            else:
+                img = self._draw(ids)
+            yield img, ids

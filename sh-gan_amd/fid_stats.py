@@ -74,7 +74,12 @@ class FidStats:
         """Sum the moments over all ranks (one collective per evaluation)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():     # (a 1-rank group goes through the collective too: same path as N ranks)
-            dist.all_reduce(self.S, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == 'gloo' and self.S.is_cuda:   # ranks sharing one device under gloo: the collective takes host tensors
+                h = self.S.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                self.S.copy_(h)
+            else:
+                dist.all_reduce(self.S, op=dist.ReduceOp.SUM)
         return self
 
     def mean_cov(self, sample_n=None):

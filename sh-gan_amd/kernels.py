@@ -376,14 +376,98 @@ def sum_partials(part):
     return out
 
 
-def fma(a, b, c):
+def _collapse(shape, strides_list):
+    """Drop size-1 dimensions and merge neighbours that every operand walks as one run (stride[i] == stride[i+1] * size[i+1], a
+    broadcast operand has 0 on both): the kernels decompose an index over at most six dimensions."""
+    dims = [(int(n), tuple(int(st[i]) if n > 1 else 0 for st in strides_list)) for i, n in enumerate(shape) if n != 1]
+    out = []
+    for n, st in dims:
+        if out and all(ps == cs * n for ps, cs in zip(out[-1][1], st)):
+            out[-1] = (out[-1][0] * n, st)
+        else:
+            out.append((n, st))
+    return [n for n, _ in out], [[st[k] for _, st in out] for k in range(len(strides_list))]
+
+
+def _larr(v):
+    return (ctypes.c_long * max(len(v), 1))(*v)
+
+
+def _fma_operands(L, ts, names):
+    dt = ts[0].dtype
+    if dt not in (torch.float32, torch.float64):
+        raise _lib.ShgError(f'fma: float32 or float64 operands (got {dt})')
+    for t, name in zip(ts, names):
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise _lib.ShgError(f'{name} must reside on a HIP (cuda) device: libshgan_hip has no CPU path')
+        if t.dtype != dt:
+            raise _lib.ShgError(f'{name} must be {dt} like the first operand (got {t.dtype})')
+        L._own(t, name)
+    return dt
+
+
+def fma(a, b, c=None):
+    """a * b + c with NumPy broadcasting (stylegan_utils/fma.py:15): operands are read through their strides, nothing is expanded.
+    c = None: the product alone (fma.py:41,44).  float32 or float64."""
     L = _Launch()
-    a, b, c = torch.broadcast_tensors(L.req(a, 'a'), L.req(b, 'b'), L.req(c, 'c'))
-    a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
-    y = torch.empty_like(a)
+    dt = _fma_operands(L, (a, b, c), 'abc')
+    ts = [a, b] + ([c] if c is not None else [])
+    shape = torch.broadcast_shapes(*[t.shape for t in ts])
+    ex = [t.expand(shape) for t in ts]
+    y = torch.empty(shape, dtype=dt, device=L.dev)
+    cshape, cst = _collapse(shape, [t.stride() for t in ex])
+    if len(cshape) > 6:
+        ex = [t.contiguous() for t in ex]
+        cshape, cst = [y.numel()], [[1]] * len(ex)
     with L:
-        check(_lib.get_lib().shg_fma_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(y), a.numel(), L.stream()), 'fma')
+        check(_lib.get_lib().shg_fma_bcast(_ptr(a), _ptr(b), _ptr(c), _ptr(y), len(cshape), _larr(cshape), _larr(cst[0]), _larr(cst[1]),
+                                           _larr(cst[2]) if c is not None else None, int(dt == torch.float64), L.stream()), 'fma')
+    del ex
     return y
+
+
+def mul_reduce(g, b, shape):
+    """``_unbroadcast(g * b, shape)`` (fma.py:48-58; b = None: ``_unbroadcast(g, shape)``) in one pass: the product is summed over
+    the dimensions along which an operand of ``shape`` was broadcast to ``g.shape``; returns a tensor of ``shape``."""
+    L = _Launch()
+    dt = _fma_operands(L, (g, b), 'gb')
+    shape = tuple(shape)
+    extra = g.ndim - len(shape)
+    if extra < 0:
+        raise _lib.ShgError('mul_reduce: the gradient has fewer dimensions than the operand')
+    full = (1,) * extra + shape
+    bx = b.expand(g.shape) if b is not None else None
+    red = [i for i in range(g.ndim) if g.shape[i] > 1 and full[i] == 1]
+    for i in range(g.ndim):
+        if full[i] not in (1, g.shape[i]):
+            raise _lib.ShgError(f'mul_reduce: {shape} does not broadcast to {tuple(g.shape)}')
+    out = torch.empty(shape, dtype=dt, device=L.dev)
+    kept = [i for i in range(g.ndim) if i not in red]
+    ops = [g] + ([bx] if bx is not None else [])
+    kshape, kst = _collapse([g.shape[i] for i in kept], [[t.stride(i) for i in kept] for t in ops])
+    rshape, rst = _collapse([g.shape[i] for i in red], [[t.stride(i) for i in red] for t in ops])
+    if len(kshape) + len(rshape) > 6:
+        g = g.contiguous()
+        bx = bx.contiguous() if bx is not None else None
+        ops = [g] + ([bx] if bx is not None else [])
+        kshape, kst = _collapse([g.shape[i] for i in kept], [[t.stride(i) for i in kept] for t in ops])
+        rshape, rst = _collapse([g.shape[i] for i in red], [[t.stride(i) for i in red] for t in ops])
+        if len(kshape) + len(rshape) > 6:
+            raise _lib.ShgError('mul_reduce: more than six non-mergeable dimensions')
+    sg = kst[0] + rst[0]
+    sb = (kst[1] + rst[1]) if bx is not None else None
+    # the fastest-varying dimension of g (smallest non-zero stride): kept -> thread per output, reduced -> workgroup per output
+    def fastest(st):
+        v = [abs(x) for x in st if x]
+        return min(v) if v else float('inf')
+    inner_kept = int(not rshape or (bool(kshape) and fastest(kst[0]) < fastest(rst[0])))
+    with L:
+        check(_lib.get_lib().shg_mul_reduce(_ptr(g), _ptr(bx), _ptr(out), len(kshape) + len(rshape), len(kshape), _larr(kshape + rshape),
+                                            _larr(sg), _larr(sb) if sb is not None else None, inner_kept, int(dt == torch.float64),
+                                            L.stream()), 'mul_reduce')
+    return out
 
 
 def scale_channels(x, s):
@@ -414,12 +498,19 @@ def planes_to_image(mid, lo, out_h, out_w, bias=None):
     return y
 
 
-def composite_u8(x4, img):
+def composite_u8(x4, img, out=None):
+    """shgan_default.py:257-262: uint8 [N,3,H,W]; ``out`` = a caller-owned destination (a slice of a result buffer: the evaluation loop
+    streams every batch into its place instead of concatenating afterwards)."""
     L = _Launch()
     x4 = L.req(x4, 'x')
     img = L.req(img, 'img')
     n, _, h, w = x4.shape
-    out = L.new((n, 3, h, w), torch.uint8)
+    if out is None:
+        out = L.new((n, 3, h, w), torch.uint8)
+    else:
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.uint8 and tuple(out.shape) == (n, 3, h, w) and out.is_contiguous()):
+            raise _lib.ShgError('composite_u8: out must be a contiguous uint8 HIP tensor [N,3,H,W]')
+        L._own(out, 'out')
     with _timed(L, 'composite_u8', 4.0 * (x4.numel() + img.numel()) + out.numel()):
         check(_lib.get_lib().shg_composite_u8(_ptr(x4), _ptr(img), _ptr(out), n, h, w, L.stream()), 'composite_u8')
     return out
@@ -439,17 +530,37 @@ def minibatch_std(x, group_size, num_channels=1):
     return y
 
 
-def assemble_input(real, mask):
-    """real [N,3,H,W] in [-1,1], mask [N,1,H,W] or [N,H,W] in {0,1} -> x [N,4,H,W] = cat([mask-0.5, real*mask])."""
+_U8_LUT = {}
+
+
+def u8_value_table(device):
+    """float value of every uint8 code as the dataset route computes it on the host: ToTensor (/255) then the formatter's ``* 2 - 1``
+    (ds_ffhq.py:318-326,338), evaluated with the same torch CPU float32 operations -- the device hand-off is bit-identical to it."""
+    key = str(device)
+    if key not in _U8_LUT:
+        _U8_LUT[key] = (torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255) * 2 - 1).to(device)
+    return _U8_LUT[key]
+
+
+def assemble_input(real, mask, lut=None):
+    """real [N,3,H,W] in [-1,1] (float32) or decoded uint8 pixels, mask [N,1,H,W] or [N,H,W] in {0,1} -> x [N,4,H,W] =
+    cat([mask-0.5, real*mask]); uint8 pixels take their float value from ``lut`` [256] (default ``u8_value_table``)."""
     L = _Launch()
-    real = L.req(real, 'real')
+    u8 = isinstance(real, torch.Tensor) and real.dtype == torch.uint8
+    real = L.req(real, 'real', dtype=torch.uint8 if u8 else torch.float32)
     mask = L.req(mask, 'mask')
     n, c, h, w = real.shape
     if c != 3 or mask.numel() != n * h * w:
         raise _lib.ShgError('assemble_input: real must be [N,3,H,W] and mask [N,(1,)H,W]')
     x = L.new((n, 4, h, w))
     with L:
-        check(_lib.get_lib().shg_assemble_input_f32(_ptr(real), _ptr(mask), _ptr(x), n, h, w, L.stream()), 'assemble_input')
+        if u8:
+            lut = L.req(u8_value_table(L.dev) if lut is None else lut, 'lut')
+            if lut.numel() != 256:
+                raise _lib.ShgError('assemble_input: lut must hold 256 floats')
+            check(_lib.get_lib().shg_assemble_input_u8(_ptr(real), _ptr(mask), _ptr(lut), _ptr(x), n, h, w, L.stream()), 'assemble_input_u8')
+        else:
+            check(_lib.get_lib().shg_assemble_input_f32(_ptr(real), _ptr(mask), _ptr(x), n, h, w, L.stream()), 'assemble_input')
     return x
 
 

@@ -160,8 +160,9 @@ class InpaintingLoss(StyleGAN2Loss):
       * the generator input is derived from it as the evaluation loop does (``shgan_default.py:268-273``):
         ``x = cat([mask - 0.5, real * mask])``, ``img = G.synthesis(*G.encoder(x), ws)`` with ``ws`` from ``G.mapping`` (style mixing on ``ws``);
       * generated images reach the discriminator as ``cat([mask - 0.5, img])``; R1 differentiates the logits w.r.t. the 4-channel real input;
-      * ``composite_fake`` (default False = the reference's phase algebra on the raw generator output, the mode the reference-autograd
-        fixtures pin): when True the generator's output is composited with the known pixels,
+      * ``composite_fake`` (REQUIRED keyword, no default: the two values are two training objectives and neither may be picked
+        silently; False = the reference's phase algebra on the raw generator output, the mode the reference-autograd fixtures pin;
+        True = the objective to train an inpainting generator with): when True the generator's output is composited with the known pixels,
         ``img * (1 - mask) + real * mask``, before anything downstream sees it -- the critic, and with it the path-length
         regulariser -- as CoModGAN does inside its generator and as the reference's evaluation loop does with this generator
         (``shgan_default.py:259``).  Without it the critic can tell real from fake from the known region alone and the generator is
@@ -171,7 +172,7 @@ class InpaintingLoss(StyleGAN2Loss):
     CoModGAN's optional L1 term on the known region is not part of ``stylegan_default_loss.py`` and is not added.
     ``noise_mode`` is the synthesis noise ('random' in training; tests pin 'const')."""
 
-    def __init__(self, device, G, D, noise_mode='random', composite_fake=False, **kw):
+    def __init__(self, device, G, D, *, composite_fake, noise_mode='random', **kw):
         super().__init__(device, G.mapping, None, D, **kw)
         self.G = G
         self.noise_mode = noise_mode

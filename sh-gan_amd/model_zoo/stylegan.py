@@ -67,9 +67,18 @@ def _add(a, b):
 
 class _ParamCache:
     """Derived device tensors (GEMM-layout weights, host copies of scalars) keyed by the identity and
-    version counter of the parameters they were computed from."""
+    version counter of the parameters they were computed from.
+
+    CONTRACT.  A write the version counter sees refreshes the entry by itself: ``p.copy_()``, ``p.add_()`` ... under ``no_grad``,
+    optimiser steps, ``load_state_dict``, ``.to()`` / ``.half()`` (new storage).  A write THROUGH ``p.data`` (``p.data.copy_(v)``,
+    ``p.data.mul_(b)``: some EMA loops and hand-rolled loaders) has a version counter of its own and is invisible here, as is a HIP
+    graph replay that updates parameters: call ``_ParamCache.invalidate_all()`` (= ``stylegan.invalidate_param_caches()``) after it.
+    ``_ParamCache.guard = True`` (or the environment variable SHGAN_PARAM_GUARD=1) makes every cache hit compare a fingerprint of
+    the parameters' bytes with the one taken when the entry was built and raise on a stale entry -- a synchronising check, meant
+    for bringing up a new training / loading loop, not for the timed path."""
 
     epoch = 0          # bumped by invalidate_all(): a replayed HIP graph changes parameters without touching their version counters
+    guard = os.environ.get('SHGAN_PARAM_GUARD', '0') not in ('', '0')
 
     def __init__(self):
         self.store = {}
@@ -78,16 +87,41 @@ class _ParamCache:
     def invalidate_all(cls):
         cls.epoch += 1
 
+    @staticmethod
+    def _fingerprint(params):
+        """Exact for the guard's purpose: the sum of the raw bit patterns as integers (every changed bit changes it, up to wrap-around)
+        plus the first element -- one small reduction and one host read per parameter."""
+        out = []
+        for p in params:
+            t = p.detach().reshape(-1)
+            if t.numel() == 0:
+                out.append((0, 0))
+                continue
+            bits = t.view(torch.int32 if t.element_size() == 4 else torch.int16 if t.element_size() == 2 else torch.int64)
+            out.append((int(bits.to(torch.int64).sum().item()), int(bits[0].item())))
+        return tuple(out)
+
     def get(self, tag, params, builder):
         key = (_ParamCache.epoch,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         hit = self.store.get(tag)
         if hit is None or hit[0] != key:
-            hit = (key, builder())
+            hit = (key, builder(), self._fingerprint(params) if _ParamCache.guard else None)
             self.store[tag] = hit
+        elif _ParamCache.guard and hit[2] is not None and hit[2] != self._fingerprint(params):
+            raise RuntimeError(
+                f'stale prepared weights for {tag!r}: a parameter was written without its version counter moving (a write through '
+                '`.data`, or a HIP-graph replay). Write with `p.copy_()` under no_grad, or call stylegan.invalidate_param_caches() '
+                'after the write.')
         return hit[1]
 
     def __deepcopy__(self, memo):
         return _ParamCache()
+
+
+def invalidate_param_caches():
+    """Drop every prepared weight of every module (see ``_ParamCache``): after writes through ``.data`` or a HIP-graph replay
+    that updates parameters."""
+    _ParamCache.invalidate_all()
 
 
 def _cache_of(module):
@@ -472,6 +506,8 @@ def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample
         return None
     if up == 2 and not (k == 3 and resample_filter is not None and resample_filter.ndim == 2 and tuple(resample_filter.shape) == (4, 4)):
         return None
+    if weight.shape[0] % 8 and (up == 2 or fused):
+        return None              # the NHWC tail / per-image store passes move 8 channels per lane: narrower outputs take the composed route
     # the weight side (normalisation, sum of squares, operand-order packing) depends on the parameter alone: cached per parameter version
     # when the caller hands its layer cache (the float32 route does the same with `prepped()`)
     def build():

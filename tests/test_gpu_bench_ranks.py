@@ -16,14 +16,14 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-COMMON = ['--steps', '2', '--warmup', '1', '--no-train-step', '--no-second-config', '--no-cpu-baseline', '--profile-steps', '0',
+COMMON = ['--steps', '2', '--warmup', '1', '--no-train-step', '--no-second-config', '--no-cpu-baseline', '--no-eval-loop', '--profile-steps', '0',
           '--resolution', '256', '--batch', '4', '--noise-mode', 'const']
 
 
-def _bench(tmp_path, tag, gpus):
+def _bench(tmp_path, tag, gpus, common=None):
     dig = str(tmp_path / tag)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--digest-out', dig] + COMMON, env=env,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--digest-out', dig] + (common or COMMON), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')][-1])
@@ -63,3 +63,24 @@ def test_bench_two_ranks_share_one_device(tmp_path):
         assert _same_image(img2[0][i], img1[0][i]), f'sample {i}: rank 0 of the two-rank run differs from the single-process run'
     for i in ('1', '3'):
         assert _same_image(img2[1][i], img1[0][i]), f'sample {i}: rank 1 of the two-rank run differs from the single-process run'
+
+
+def test_bench_eight_ranks_oversubscribed_on_one_device(tmp_path):
+    """The launch shape the driver's 8-GPU scaling run uses (``--gpus 8``), oversubscribed on the one device of the test box (256^2, batch 2
+    per rank, gloo): eight spawned ranks rendezvous, the all-reduced rank count is 8, rank r holds the ids r, r + 8 (ds_sampler.py:67), the
+    HIP-graph decision is common to all ranks, every rank reports its own step and host-enqueue time, and -- with ``--eval-loop`` -- the
+    evaluation loop's end-of-run collectives (all-gather of the uint8 results, all-reduce of the FID moments) span the eight ranks."""
+    common = [c for c in COMMON if c != '--no-eval-loop']
+    common[common.index('--batch') + 1] = '2'
+    line, dig, _ = _bench(tmp_path, 'eight', 8, common + ['--eval-loop'])
+    cfg = line['config']
+    assert line['n_gpus'] == 8 and cfg['global_batch'] == 16 and cfg['launcher'] == 'self-spawn'
+    assert cfg['ranks_all_reduced'] == 8 and cfg['ranks_share_devices'] and cfg['collective_backend'] == 'gloo'
+    for key in ('ms_per_step_by_rank', 'host_enqueue_ms_per_step_by_rank'):
+        assert len(cfg[key]['all']) == 8 and all(v > 0 for v in cfg[key]['all']), key
+    g = cfg['hip_graph']
+    assert 'captured_on_all_ranks' in g and isinstance(g['used'], bool)
+    for r in range(8):
+        assert sorted(int(i) for i in dig[r]) == [r, r + 8], (r, dig[r])
+    ev = line['eval_loop']
+    assert ev['n_gpus'] == 8 and ev['result_ok'] and ev['fid_samples_counted'] == 8 * 2 * 2, ev

@@ -177,7 +177,7 @@ def test_config5_batch8_training_iteration_all_phases(fp16):
     def iteration(batch_idx, expect):
         G.load_state_dict(g0); D.load_state_dict(d0)
         torch.manual_seed(7)
-        L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0.9)
+        L = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode='const', style_mixing_prob=0.9)
         phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
         ran = ts.run_phases(real4, 512, phases, batch_idx=batch_idx, loss=L, batch_gpu=8, device=DEV)
         assert ran == expect

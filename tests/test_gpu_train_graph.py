@@ -52,7 +52,7 @@ def test_phase_graphs_follow_the_eager_loop():
     for graphed in (False, True):
         G.load_state_dict(g0); D.load_state_dict(d0)
         torch.manual_seed(11)
-        L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0)
+        L = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode='const', style_mixing_prob=0)
         phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
         pg = ts.PhaseGraphs(phases, L, 4, 64, tuple(real4.shape), DEV) if graphed else None
         ran = []
@@ -362,7 +362,7 @@ def test_dmain_one_critic_pass_over_the_stacked_batch_equals_the_two_passes_of_t
     z, c = torch.randn(8, 64, device=DEV), torch.zeros(8, 0, device=DEV)
     res = []
     for batched in (False, True):
-        L = losses.InpaintingLoss(DEV, G, D, noise_mode='const', style_mixing_prob=0, batch_critic=batched)
+        L = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode='const', style_mixing_prob=0, batch_critic=batched)
         D.requires_grad_(True)
         for p in D.parameters():
             p.grad = None

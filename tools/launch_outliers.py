@@ -31,7 +31,7 @@ elif '--reg' in sys.argv:              # a lazy-regulariser phase (Greg: path le
     real = torch.from_numpy(rs.uniform(-1, 1, size=(8, 3, 512, 512)).astype(np.float32))
     mask = torch.from_numpy((rs.uniform(size=(8, 1, 512, 512)) < 0.7).astype(np.float32))
     real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
-    Lz = losses.InpaintingLoss(DEV, G, D, noise_mode='random', style_mixing_prob=0.9)
+    Lz = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode='random', style_mixing_prob=0.9)
     z, c = torch.randn(8, 512, device=DEV), torch.zeros(8, 0, device=DEV)
     mod = G if phase.startswith('G') else D
 

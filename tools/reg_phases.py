@@ -16,7 +16,7 @@ rs = np.random.RandomState(63)
 real = torch.from_numpy(rs.uniform(-1, 1, size=(8, 3, 512, 512)).astype(np.float32))
 mask = torch.from_numpy((rs.uniform(size=(8, 1, 512, 512)) < 0.7).astype(np.float32))
 real4 = torch.cat([mask - 0.5, real], dim=1).to(DEV)
-L = losses.InpaintingLoss(DEV, G, D, noise_mode='random', style_mixing_prob=0.9)
+L = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode='random', style_mixing_prob=0.9)
 z, c = torch.randn(8, 512, device=DEV), torch.zeros(8, 0, device=DEV)
 names = sys.argv[sys.argv.index('--phases') + 1].split(',') if '--phases' in sys.argv else ['Greg', 'Dreg']
 if '--ab-tail' in sys.argv or '--ab-style' in sys.argv:          # same process, alternating: a closed backward node against the tensor-operator composition
