@@ -202,7 +202,7 @@ def eval_loop_block(G, res, batch, steps, a, dev, rank, world, barrier, use_dist
 
     def make(n):
         return eval_harness.EvalLoop(G, dev, res, n, rank=rank, world=world, noise_mode=a.noise_mode, seed=0, depth=a.pipeline_depth,
-                                     feature_fn=eval_harness.standin_features)
+                                     feature_fn=eval_harness.standin_features, timing=True)
     warm = make(world * batch * 4)
     pool = eval_harness.PinnedU8Loader(warm.ids, batch, res, seed=1000, pool=4)
     np.random.seed(1000 + rank)
@@ -226,6 +226,12 @@ def eval_loop_block(G, res, batch, steps, a, dev, rank, world, barrier, use_dist
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, use_dist, backend, dev)
     n_fid = float(fid.S[fid.dim, fid.dim].item())
+    # steady state: completion time of batch k on the device (timing events on the batches' streams), first / last quarter left out
+    evs = loop.batch_done_events
+    steady = None
+    if len(evs) >= 12:
+        k0, k1 = len(evs) // 4, len(evs) - 1 - len(evs) // 4
+        steady = evs[k0].elapsed_time(evs[k1]) / (k1 - k0)
     ok = tuple(images.shape) == (n_items, 3, res, res) and images.dtype == torch.uint8
     del loop, images, fid
     torch.cuda.empty_cache()
@@ -235,6 +241,10 @@ def eval_loop_block(G, res, batch, steps, a, dev, rank, world, barrier, use_dist
             'images_per_s': round(n_items / dt, 3), 'ms_per_batch': round(dt / steps * 1e3, 3), 'batches': steps, 'n_gpus': world,
             'ms_per_batch_loop_only': round(t_loop / steps * 1e3, 3), 'host_issue_ms_per_batch': round(t_issue / steps * 1e3, 3),
             'gather_and_reduce_ms': round((dt - t_loop) * 1e3, 3), 'fid_samples_counted': n_fid, 'result_ok': bool(ok),
+            'steady_state_ms_per_batch': round(steady, 3) if steady else None,
+            'steady_state_images_per_s': round(world * batch / steady * 1e3, 1) if steady else None,
+            'steady_state_note': 'device completion times of the middle half of the batches (rank 0): a real evaluation runs hundreds of batches per '
+                                 'rank, the whole-loop figure above carries the start (host draws the first masks before the device has work) and the drain',
             'not_in_the_loop': 'PNG / zip decode (dataset workers) and the Inception-v3 detector (a download): a pinned pool of pre-drawn '
                                'uint8 batches and a fixed linear map stand in for them'}
 

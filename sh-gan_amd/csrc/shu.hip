@@ -205,9 +205,18 @@ __global__ __launch_bounds__(256) void shu_split_irfft2_kernel(const ShuSplitPar
     __shared__ float2 S[SHU_N][SHU_NH];
     __shared__ float2 Z[SHU_N][SHU_NH];
     __shared__ float2 tw[SHU_N];
+    __shared__ float gl[12 + 40 + 144 + 544];   // Gaussian-split tables of the four scalar levels (r = 4 .. 32: r * (r/2 + 1) floats each)
     const int c = blockIdx.x, n = blockIdx.y;
     const int C = p.C, B = p.B;
     shu_build_twiddles(tw);
+    {   // the scalar levels read their table once per (row, column, j): from LDS, not from global memory inside the DFT loops
+        int off = 0;
+        for (int l = 0; l < 4; ++l) {
+            const int cnt = (4 << l) * ((2 << l) + 1);
+            if (p.out[l]) for (int e = threadIdx.x; e < cnt; e += 256) gl[off + e] = p.gauss[l][e];
+            off += cnt;
+        }
+    }
     // heterogeneous band sum: flat conv-output channel = o*B + k  (shgan.py:157-160)
     const long plane = SHU_N * SHU_NH;
     const float* yre = p.Y + ((long)n * 2 * C + c) * B * plane;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void shu_split_irfft2_kernel(const ShuSplitPar
     for (int l = 0; l < 4; ++l) {          // r = 4 .. 32: scalar DFTs (together 1/7 of the work of the 64 x 64 level)
         const int r = 4 << l, rh = r / 2 + 1, tstep = SHU_N / r;
         if (!p.out[l]) continue;
-        const float* g = p.gauss[l];
+        const float* g = gl + (l == 0 ? 0 : l == 1 ? 12 : l == 2 ? 52 : 196);
         // complex inverse DFT over rows of the cropped, weighted, un-shifted block (shgan.py:328-334)
         for (int e = threadIdx.x; e < r * rh; e += 256) {
             const int y = e / rh, w = e - y * rh;

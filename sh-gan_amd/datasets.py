@@ -133,12 +133,26 @@ class DeviceFeeder:
     ``device_masks`` draws the freeform masks on the device instead of taking the formatter's (same distribution and, for the same
     numpy RNG state, the same bits: ``masks.random_masks``)."""
 
-    def __init__(self, device, resolution, hole_range=(0, 1), device_masks=False):
+    def __init__(self, device, resolution, hole_range=(0, 1), device_masks=False, own_stream=True):
+        """``own_stream=False``: stage on the CALLER's stream instead of a copy stream -- for callers whose own stream carries nothing
+        but this staging (EvalLoop: the generator runs on three side streams).  The copies still overlap with the generator (pinned
+        source, asynchronous), the process stays within four HIP streams = the default number of hardware queues, and the mask
+        rasteriser's hole-count read never queues behind a generator stream that happens to share a hardware queue with the copy
+        stream (measured: a full pipeline drain every third batch, MEASUREMENTS.md round 6)."""
         self.device = torch.device(device)
         self.resolution, self.hole_range, self.device_masks = resolution, tuple(hole_range), device_masks
-        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        if self.device.type == 'cuda' and not own_stream:
+            self.copy_stream = None
+            self._inline = True
+        elif self.device.type == 'cuda':
+            from .eval_harness import shared_streams
+            self.copy_stream = shared_streams(self.device, 1, kind='copy')[0]       # one staging stream per process (see shared_streams)
+        else:
+            self.copy_stream = None
 
     def _to_device(self, t):
+        if self.copy_stream is None and getattr(self, '_inline', False):
+            return (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True)
         if self.copy_stream is None:
             return t.to(self.device)
         if not t.is_pinned():
@@ -177,8 +191,18 @@ class DeviceFeeder:
             if md is not None:
                 md.record_stream(cur)
         if md is None:
-            md = _masks.random_masks(xd.shape[0], self.resolution, hole_range=self.hole_range, device=self.device).to(torch.float32)
-            md = md.reshape(xd.shape[0], 1, self.resolution, self.resolution)
+            # on the copy stream: the rasteriser's hole-count read makes the host wait for the stream it runs on, and this one carries
+            # input staging only (on the caller's stream the read waited behind whatever else the caller had queued there)
+            if self.copy_stream is not None:
+                with torch.cuda.stream(self.copy_stream):
+                    md = _masks.random_masks(xd.shape[0], self.resolution, hole_range=self.hole_range, device=self.device).to(torch.float32)
+                    md = md.reshape(xd.shape[0], 1, self.resolution, self.resolution)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_stream(self.copy_stream)
+                md.record_stream(cur)
+            else:
+                md = _masks.random_masks(xd.shape[0], self.resolution, hole_range=self.hole_range, device=self.device).to(torch.float32)
+                md = md.reshape(xd.shape[0], 1, self.resolution, self.resolution)
         x4 = eval_harness.assemble_input(xd, md)
         return x4, xd, md, ids
 

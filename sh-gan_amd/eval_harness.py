@@ -80,6 +80,24 @@ def shard_ids(n_items, rank, world):
     return list(iter(DistributedSampler(list(range(n_items)), num_replicas=world, rank=rank, shuffle=False, extend=True)))
 
 
+_STREAMS = {}
+
+
+def shared_streams(device, n, kind='pipe'):
+    """The first ``n`` of this process's ``kind`` streams on ``device`` (created on first use, then reused by every pipeline / feeder).
+    HIP streams are multiplexed onto a handful of hardware queues (four by default): every ``torch.cuda.Stream()`` takes the next of
+    torch's pooled streams, and a loop that builds fresh streams each time it starts ends up -- after a few pipelines have come and
+    gone -- with its staging stream on the hardware queue of one of its generator streams, where a 12 MB copy or a mask raster waits
+    behind 19 ms of convolutions (measured: the evaluation loop 20.5 -> 44 ms per batch inside bench.py, round 6).  One small fixed
+    set per process keeps the caller's stream, the copy stream and the three generator streams on queues of their own."""
+    dev = torch.device(device)
+    key = (str(dev), kind)
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:n]
+
+
 PIPELINE_DEPTH = 3      # streams of the evaluation loop (1 = plain loop); 2: +6.5 %, 3: +8.5 %, 4-6: no further gain at 512x16
 
 
@@ -93,18 +111,40 @@ class StreamPipeline:
         for x, z in batches: outs.append(pipe.run(step_fn, x, z))
         pipe.join()                      # before anything reads ``outs`` on the current stream"""
 
-    def __init__(self, device, depth=None):
+    def __init__(self, device, depth=None, first_on_caller=True):
+        """``first_on_caller=False``: the first batch goes to a side stream too and every side stream's first batch waits for an event
+        behind it (the per-parameter caches it built) -- for loops whose caller's stream must stay short because the host waits on
+        it (EvalLoop: the mask rasteriser's hole-count read)."""
         depth = PIPELINE_DEPTH if depth is None else depth
         self.device = torch.device(device)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)] if (depth > 1 and self.device.type == 'cuda') else []
+        self.streams = shared_streams(self.device, depth) if (depth > 1 and self.device.type == 'cuda') else []
         self.k = 0
         self.outs = []
         self.last_stream = None        # the stream the latest batch was issued on (None: the caller's)
+        self.first_on_caller = first_on_caller
+        self._first_done = None
 
     def run(self, fn, *args):
         self.last_stream = None
         if not self.streams:
             return fn(*args)
+        if self.k == 0 and not self.first_on_caller:
+            s = self.streams[0]
+            self.k = 1
+            self.last_stream = s
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            from .model_zoo.stylegan import _ParamCache
+            built = _ParamCache.builds
+            with torch.cuda.stream(s):
+                out = fn(*args)
+                if _ParamCache.builds != built:        # the batch prepared weights on this stream: the other streams' first batches wait for it
+                    self._first_done = torch.cuda.Event()
+                    self._first_done.record(s)
+            for t in args:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(s)
+            self.outs.append(out)
+            return out
         if self.k == 0:
             # the first batch runs on the caller's stream: it builds the per-parameter caches (prepared weight layouts, separable
             # filter taps, ...) in stream order; every later batch waits for the caller's stream before it starts, i.e. for them
@@ -116,6 +156,8 @@ class StreamPipeline:
         self.k += 1
         self.last_stream = s
         s.wait_stream(torch.cuda.current_stream(self.device))      # the inputs were produced on the caller's stream
+        if self._first_done is not None and self.k <= len(self.streams) + 1:
+            s.wait_event(self._first_done)                         # the caches the first batch built on its side stream
         with torch.cuda.stream(s):
             out = fn(*args)
         for t in args:
@@ -158,7 +200,7 @@ class GraphPipeline:
         self.device = torch.device(device)
         self.fn, self.warmup = fn, max(1, warmup)
         self.watch = None if watch is None else list(watch)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.streams = shared_streams(self.device, depth)
         self.ins = [[a.clone() if torch.is_tensor(a) else a for a in example_args] for _ in self.streams]
         self.k = 0
         self.captures = 0
@@ -311,36 +353,49 @@ class EvalLoop:
         at the end  ONE all-reduce of the moments and ONE all-gather of the uint8 results + the zipzap re-interleave on the device
                     (the reference: 3 x world broadcasts per batch, eva_base.py:96-188, python lists on rank 0).
 
-    Consecutive batches are issued round-robin on ``depth`` HIP streams (StreamPipeline); the moment kernel accumulates in place and
-    therefore runs on one statistics stream, in batch order, behind an event of the batch's stream.  Nothing in the loop waits for
-    the device except the mask rasteriser's hole-count read (one small D2H per batch on the caller's stream, which carries only the
-    input staging).  ``latent_fn(ids, B) -> z`` replaces ``torch.randn`` (tests: per-item latents so that a result can be compared
-    id by id); ``on_batch(ids, images_u8, event)`` hands every finished batch to a consumer (host metrics) without ending the loop."""
+    Consecutive batches are issued round-robin on ``depth`` HIP streams (StreamPipeline, every batch on a side stream); the moment
+    kernel accumulates in place, so every stream owns a partial accumulator (33.6 MB of float64 each) and ``gather`` adds them up.
+    The only point where the host waits for the device is the mask rasteriser's hole-count read (one small D2H per batch), and it
+    waits on the COPY stream, which carries nothing but input staging.  The loop uses five streams -- caller's, copy, three for the
+    generator; a sixth (a statistics stream, the first form of this loop) made the staging stream share a hardware queue with a
+    generator stream and the hole-count read waited for a whole batch (MEASUREMENTS.md, round 6).  ``latent_fn(ids, B) -> z``
+    replaces ``torch.randn`` (tests: per-item latents so that a result can be compared id by id); ``on_batch(ids, images_u8, event)``
+    hands every finished batch to a consumer (host metrics) without ending the loop."""
 
     def __init__(self, G, device, resolution, n_items, rank=0, world=1, noise_mode='random', seed=0, depth=None, feature_fn=None,
                  fid_dim=2048, latent_fn=None, device_masks=True, hole_range=(0, 1), keep_images=True, on_batch=None, step_fn=None,
-                 fid_accumulate_fn=None):
+                 fid_accumulate_fn=None, feeder_stream=False, timing=False):
         from .datasets import DeviceFeeder
-        from .fid_stats import FidStats
+        self.timing, self.batch_done_events = timing, []      # timing: one timing event per finished batch (bench: steady-state rate)
         self.G, self.device, self.res = G, torch.device(device), int(resolution)
         self.n_items, self.rank, self.world = int(n_items), int(rank), int(world)
         self.noise_mode, self.seed, self.depth = noise_mode, seed, depth
         self.feature_fn, self.latent_fn, self.on_batch = feature_fn, latent_fn, on_batch
         self.step_fn = step_fn          # (x4, z, out) -> uint8 images: the CPU world-size-2 tests inject a stand-in; the product path is run_generator
         self.ids = shard_ids(self.n_items, self.rank, self.world)
-        self.feeder = DeviceFeeder(self.device, self.res, hole_range=hole_range, device_masks=device_masks)
-        self.fid = FidStats(fid_dim, device=self.device, accumulate_fn=fid_accumulate_fn) if feature_fn is not None else None
+        self.feeder = DeviceFeeder(self.device, self.res, hole_range=hole_range, device_masks=device_masks, own_stream=feeder_stream)
+        self.fid_dim, self._fid_fn = fid_dim, fid_accumulate_fn
+        self._fid_parts = {}            # stream id -> FidStats (partial sums of the batches that ran on that stream)
+        self.fid = None                 # their sum, after gather()
         self.images = (torch.empty((len(self.ids), 3, self.res, self.res), dtype=torch.uint8, device=self.device) if keep_images else None)
-        self.stats_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self.seen = 0
+
+    def _fid_part(self, key):
+        from .fid_stats import FidStats
+        if key not in self._fid_parts:
+            self._fid_parts[key] = FidStats(self.fid_dim, device=self.device, accumulate_fn=self._fid_fn)
+        return self._fid_parts[key]
 
     def run(self, loader):
         """``loader`` yields this rank's items in ``shard_ids`` order as (images [B,3,R,R] uint8 or float32 in [-1,1], ids) or
-        (images, masks [B,R,R], ids).  Returns self (``images``, ``fid``, ``seen``)."""
+        (images, masks [B,R,R], ids).  Returns self (``images``, ``seen``; ``gather`` completes ``fid``)."""
         if self.noise_mode == 'random':
             torch.manual_seed(self.seed * self.world + self.rank)          # shgan_default.py:165-167
-        pipe = StreamPipeline(self.device, depth=self.depth)
+        pipe = StreamPipeline(self.device, depth=self.depth, first_on_caller=False)
         G, buf = self.G, self.images
+        if self.feature_fn is not None:                                    # accumulators exist before a side stream touches them
+            for key in [None] + [st.cuda_stream for st in pipe.streams]:
+                self._fid_part(key)
         for x4, real, mask, ids in self.feeder(loader):
             b, k0 = x4.shape[0], self.seen
             if k0 + b > len(self.ids):
@@ -349,27 +404,26 @@ class EvalLoop:
             gen = self.step_fn if self.step_fn is not None else (lambda x_, z_, o_: run_generator(G, x_, z_, noise_mode=self.noise_mode, out=o_))
             dst = buf[k0:k0 + b] if buf is not None else None
 
-            def step(x4_, z_, dst=dst):
+            def step(x4_, z_, dst=dst, k0=k0):
                 out = gen(x4_, z_, dst)
-                return out, (self.feature_fn(out) if self.feature_fn is not None else None)
-            out, feats = pipe.run(step, x4, z)
-            ev = None
-            if self.stats_stream is not None and (self.fid is not None or self.on_batch is not None):
-                ev = torch.cuda.Event()
-                ev.record(pipe.last_stream or torch.cuda.current_stream(self.device))
-            if self.fid is not None and self.stats_stream is not None:
-                self.stats_stream.wait_event(ev)
-                with torch.cuda.stream(self.stats_stream):
-                    self.fid.add_shard(feats, k0, self.rank, self.world, self.n_items)
-                feats.record_stream(self.stats_stream)
-            elif self.fid is not None:
-                self.fid.add_shard(feats, k0, self.rank, self.world, self.n_items)
+                if self.feature_fn is not None:
+                    cur = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == 'cuda' else None
+                    part = self._fid_parts.get(cur) or self._fid_part(None)
+                    part.add_shard(self.feature_fn(out), k0, self.rank, self.world, self.n_items)
+                return out
+            out = pipe.run(step, x4, z)
+            if self.timing and self.device.type == 'cuda':
+                tev = torch.cuda.Event(enable_timing=True)
+                tev.record(pipe.last_stream or torch.cuda.current_stream(self.device))
+                self.batch_done_events.append(tev)
             if self.on_batch is not None:
+                ev = None
+                if self.device.type == 'cuda':
+                    ev = torch.cuda.Event()
+                    ev.record(pipe.last_stream or torch.cuda.current_stream(self.device))
                 self.on_batch(ids, out, ev)
             self.seen += b
         pipe.join()
-        if self.stats_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.stats_stream)
         return self
 
     def gather(self):
@@ -391,9 +445,19 @@ class EvalLoop:
             else:
                 full = self.images[None]
             images = zipzap_device(full, self.n_items)
-        if self.fid is not None:
+        if self.local_fid() is not None:
             self.fid.all_reduce()
         return images, self.fid
+
+    def local_fid(self):
+        """This rank's moments (the per-stream partial accumulators added up; no collective)."""
+        if self._fid_parts:
+            parts = list(self._fid_parts.values())
+            base = self.fid if self.fid is not None else parts.pop(0)
+            for p in parts:
+                base.S += p.S
+            self.fid, self._fid_parts = base, {}
+        return self.fid
 
 
 class PinnedU8Loader:

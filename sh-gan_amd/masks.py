@@ -190,9 +190,20 @@ def rasterize(records, offsets, flips, s, device='cuda'):
         raise _lib.ShgError('mask rasteriser: disc radius beyond the span table')
     dev = torch.device(device)
     b = len(offsets) - 1
-    rec_d = torch.from_numpy(np.ascontiguousarray(records.reshape(-1))).to(dev) if records.shape[0] else torch.zeros(REC, dtype=torch.int32, device=dev)
-    off_d = torch.from_numpy(np.asarray(offsets, dtype=np.int32)).to(dev)
-    flip_d = torch.from_numpy(np.asarray(flips, dtype=np.int32).reshape(-1)).to(dev)
+    # ONE H2D copy of the primitive lists, from pinned memory: a pageable source of this size (~0.5 MB) takes the runtime's
+    # pin-in-place path, which was measured to stall the host for two batches of device work every fourth batch of the evaluation
+    # loop (37 ms; MEASUREMENTS.md, round 6).  torch's caching host allocator keeps the block alive until the copy has run.
+    rec_h = np.ascontiguousarray(records.reshape(-1), dtype=np.int32) if records.shape[0] else np.zeros(REC, np.int32)
+    off_h = np.asarray(offsets, dtype=np.int32)
+    flip_h = np.asarray(flips, dtype=np.int32).reshape(-1)
+    n_rec, n_off, n_flip = rec_h.size, off_h.size, flip_h.size
+    o_off = (n_rec + 3) // 4 * 4                         # 16-byte aligned sections
+    o_flip = o_off + (n_off + 3) // 4 * 4
+    stage = torch.empty(o_flip + n_flip, dtype=torch.int32, pin_memory=(dev.type == 'cuda'))
+    sv = stage.numpy()
+    sv[:n_rec], sv[o_off:o_off + n_off], sv[o_flip:o_flip + n_flip] = rec_h, off_h, flip_h
+    stage_d = stage.to(dev, non_blocking=True)
+    rec_d, off_d, flip_d = stage_d[:n_rec], stage_d[o_off:o_off + n_off], stage_d[o_flip:o_flip + n_flip]
     tab_d = _table_on(dev)
     mask = torch.empty((b, 1, s, s), dtype=torch.float32, device=dev)
     holes = torch.zeros((b,), dtype=torch.int32, device=dev)

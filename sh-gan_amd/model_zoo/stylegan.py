@@ -79,6 +79,7 @@ class _ParamCache:
 
     epoch = 0          # bumped by invalidate_all(): a replayed HIP graph changes parameters without touching their version counters
     guard = os.environ.get('SHGAN_PARAM_GUARD', '0') not in ('', '0')
+    builds = 0         # entries (re)built so far: a stream pipeline reads it to learn whether a batch had to prepare weights
 
     def __init__(self):
         self.store = {}
@@ -105,6 +106,7 @@ class _ParamCache:
         key = (_ParamCache.epoch,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         hit = self.store.get(tag)
         if hit is None or hit[0] != key:
+            _ParamCache.builds += 1
             hit = (key, builder(), self._fingerprint(params) if _ParamCache.guard else None)
             self.store[tag] = hit
         elif _ParamCache.guard and hit[2] is not None and hit[2] != self._fingerprint(params):

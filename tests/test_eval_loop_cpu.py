@@ -78,7 +78,7 @@ full = torch.stack([run(q, 2).images for q in range(2)])
 assert np.array_equal(hz.zipzap_device(full, N).numpy(), data.zipzap_arrange([full[0].numpy(), full[1].numpy()])[:N])
 # moments: the padded duplicate (item 0 on rank 1) has weight 0, so the all-reduced sum equals the 1-rank sum and counts N samples
 n2, mu2, sg2 = fid.mean_cov()
-n1, mu1, sg1 = one.fid.mean_cov()
+n1, mu1, sg1 = one.local_fid().mean_cov()
 assert n2 == n1 == N, (n2, n1)
 assert np.allclose(mu2, mu1, rtol=0, atol=1e-12) and np.allclose(sg2, sg1, rtol=0, atol=1e-9)
 dist.destroy_process_group()

@@ -9,7 +9,7 @@ i=0
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o t -- python bench.py --steps 2 --warmup 1 --pipeline-depth 1 --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step > $OUT/p$i.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o t -- python bench.py --steps 2 --warmup 1 --pipeline-depth 1 --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step --no-eval-loop --graph off > $OUT/p$i.log 2>&1 )
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY

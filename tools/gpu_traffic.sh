@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_$C
   rm -rf $OUT; mkdir -p $OUT
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o t -- python bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step > $OUT/stdout.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o t -- python bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-second-config --no-train-step --no-eval-loop --graph off > $OUT/stdout.log 2>&1 )
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
@@ -18,9 +18,14 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     seen = collections.Counter()
     for r in csv.DictReader(open(f[0])):
         if r['Counter_Name'] != c: continue
-        k = r['Kernel_Name'].split('(')[0].split('<')[0].replace('void ', '')
+        full = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        k = full.split('<')[0]
         res[k][c] += float(r['Counter_Value'])
         seen[k] += 1
+        if k == 'conv_wino4_kernel' and '<' in full:      # per instantiation <TY, TX>: the thin / medium / thick layers separately
+            ki = full.replace(' ', '')
+            res[ki][c] += float(r['Counter_Value'])
+            seen[ki] += 1
     for k, n in seen.items(): res[k]['launches'] = max(res[k]['launches'], n)
 out = {}
 for k, d in res.items():
