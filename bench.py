@@ -66,6 +66,20 @@ def pmc_traffic_classes(resolution, batch, kernels_=('conv_wino4_kernel', 'conv_
                 'write_GB_per_launch': round(d[k]['write_bytes_per_launch'] / 1e9, 4)} for k in kernels_ if k in d}
 
 
+def shu_floors():
+    """Per-stage floor of the Spectral Hint Unit's launches from the committed probe ``profiles/r06_shu_floor.txt`` (tools/shu_floor.py: the
+    product kernel beside a no-arithmetic skeleton of the same grid / workgroup / LDS footprint / global loads and stores, 400 launches back to
+    back): {stage: (product_us, skeleton_us, empty_launch_us)}.  Constants of that profile (the skeleton kernels are study code, not product)."""
+    path = os.path.join(ROOT, 'profiles', 'r06_shu_floor.txt')
+    out = {}
+    if os.path.exists(path):
+        for ln in open(path):
+            f = ln.split()
+            if len(f) == 5 and f[0] in ('shu_rfft2', 'shu_spectral', 'shu_irfft2'):
+                out[f[0]] = (float(f[1]), float(f[2]), float(f[3]))
+    return out
+
+
 def cpu_model():
     try:
         for ln in open('/proc/cpuinfo'):
@@ -322,7 +336,9 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     mask = (torch.rand(b, 1, res, res, device=dev) < 0.7).float()
     real4 = torch.cat([mask - 0.5, real], dim=1)
     L = losses.InpaintingLoss(dev, G, D, composite_fake=True, noise_mode='random', style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_weight=2)
-    use_graph = world == 1 and a.graph != 'off'           # phases as HIP graphs (train_stage.PhaseGraphs); eager loop timed beside it
+    # phases as HIP graphs (train_stage.PhaseGraphs); eager loop timed beside it.  N > 1: two graphs per phase around the host-side bucket
+    # all-reduce (the eager loop overlaps the reduction with backward instead); the faster form is taken, on all ranks together
+    use_graph = a.graph != 'off'
     kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=use_graph, fused=True)     # one multi-tensor kernel per optimiser step
     phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16)
     pg = ts.PhaseGraphs(phases, L, b, 512, tuple(real4.shape), dev) if use_graph else None
@@ -348,9 +364,6 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
     ms_greg = timed([4, 4])                               # Gmain + Greg + Dmain (batch_idx % 4 == 0, % 16 != 0)
     ms_all = timed([0])                                   # Gmain + Greg + Dmain + Dreg
     graph_info = {'used': False}
-    if world > 1 and a.graph != 'off':
-        graph_info['reason'] = ('train_stage.PhaseGraphs is single-process (it raises on an active BucketedAllReduce: a captured phase cannot hold '
-                                'the hook-launched RCCL all-reduces that overlap with backward); with N > 1 ranks the step is the eager loop')
     if use_graph:
         eager = (ms_main, ms_greg, ms_all)
         try:
@@ -361,10 +374,16 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             g_main = timed([1 + (k % 3) for k in range(a.train_steps)])
             g_greg = timed([4, 4])
             g_all = timed([0])
-            graph_info = {'used': True, 'eager_ms_per_step': round(eager[0], 2), 'eager_ms_iteration_with_both_lazy_regularisers': round(eager[2], 2),
+            # (the times are max-over-ranks already: every rank sees the same numbers and takes the same branch)
+            faster = world == 1 or g_main <= eager[0]
+            graph_info = {'used': bool(faster), 'eager_ms_per_step': round(eager[0], 2), 'eager_ms_iteration_with_both_lazy_regularisers': round(eager[2], 2),
+                          'graph_ms_per_step': round(g_main, 2), 'split_around_all_reduce': bool(pg.split),
                           'note': 'every phase captured once as a HIP graph (train_stage.PhaseGraphs) and replayed; the eager loop '
-                                  '(Python + autograd + ctypes enqueue of ~4 500 launches per step) timed beside it'}
-            ms_main, ms_greg, ms_all = g_main, g_greg, g_all
+                                  '(Python + autograd + ctypes enqueue of ~4 500 launches per step) timed beside it'
+                                  + ('; N > 1: two graphs per phase with the bucket all-reduce between them (no overlap with backward), the faster of '
+                                     'the two forms reported' if pg.split else '')}
+            if faster:
+                ms_main, ms_greg, ms_all = g_main, g_greg, g_all
         except Exception as e:
             graph_info = {'used': False, 'error': repr(e)[:400]}
             ms_main, ms_greg, ms_all = eager
@@ -641,6 +660,7 @@ def worker(local_rank, a, spawned_world=None, port=None):
             # chains per 64x64 plane (row DFT, column DFT as MFMA passes with a barrier between) on a few MB -- latency-bound: their time
             # is the figure, the byte rate is listed only to show they are nowhere near HBM
             st = {}
+            floors = shu_floors()
             for name, kind in (('shu_rfft2', 'latency'), ('shu_spectral', 'mfma'), ('shu_irfft2', 'latency')):
                 d = tsum.get(name)
                 if not d or d['ms'] <= 0:
@@ -651,10 +671,17 @@ def worker(local_rank, a, spawned_world=None, port=None):
                     e.update(executed_tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / PEAK_FP32_MFMA_TFLOPS, 4))
                 else:
                     e['algorithmic_GBps'] = round(d['work'] / (d['ms'] * 1e-3) / 1e9, 1)
+                if name in floors:
+                    pr, sk, em = floors[name]
+                    e.update(floor_us=sk, empty_launch_us=em, back_to_back_us=pr, frac_of_floor=round(sk / pr, 3))
                 st[name] = e
             if not st:
                 return None
-            return {'ms_per_step': round(sum(v['us_per_step'] for v in st.values()) / 1e3, 4), 'stages': st}
+            return {'ms_per_step': round(sum(v['us_per_step'] for v in st.values()) / 1e3, 4), 'stages': st,
+                    'floor_source': 'profiles/r06_shu_floor.txt' if floors else None,
+                    'floor_note': 'floor_us = a skeleton launch of the same grid / LDS / load-store footprint without arithmetic, back_to_back_us = the product '
+                                  'kernel in the same probe (no per-launch events), frac_of_floor = floor / product there; us_per_step is this run\'s '
+                                  'HIP-event time inside the generator (launch gaps included)' if floors else None}
         shu = shu_block()
         conv_ms = sum(tsum[k]['ms'] for k in tsum if k.startswith('conv_'))
         conv_exec = sum(tsum[k]['executed'] for k in tsum if k.startswith('conv_'))

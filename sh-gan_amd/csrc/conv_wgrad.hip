@@ -31,10 +31,18 @@ struct WgradParams {
 
 // ROWS = 2 (stride 1, OW == 32): a chunk is TWO whole output rows of 32 pixels (the same 64 operand columns; a one-row chunk would leave half
 // of them empty: 990 us for the 512-channel 32^2 layers) -- the window is then KH + 1 rows of 34 columns, a staging line = two window rows.
-template <int KH, int KW, int S, int ROWS = 1>
+//
+// FULL (host-checked: pad == 0, I and O multiples of 64, OW a multiple of the chunk width, every window row and column inside x -- the
+// FIR-padded stride-2 layers and the 1x1 layers of the training step): no element of a chunk needs a mask.  The masked form's selects
+// (`ok ? v : 0`) were scheduled -- with the `s_waitcnt vmcnt(0)` they need -- BEFORE the MFMA loop (ISA of round 5: the software pipeline
+// described below did not exist in the binary; 39 % of the wave cycles parked).  Here the loads are unconditional, addressed as a
+// wave-uniform line pointer + one lane offset, their values are first touched by the LDS writes of the next iteration, and the k-steps of
+// a chunk are unrolled so that the operand reads of a step are issued under the MFMAs of the step before.
+template <int KH, int KW, int S, int ROWS = 1, bool FULL = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, RW = PX / ROWS, XW = RW * S + KW - 1, WROWS = KH + ROWS - 1, CP = 65;    // CP: channel pitch (odd)
     static_assert(ROWS == 1 || S == 1, "two-row chunks are a stride-1 form");
+    static_assert(!FULL || ROWS == 1, "the unmasked form is a one-row form");
     __shared__ float Gs[PX * CP];                                // [pixel][o]
     __shared__ float Xs[WROWS * XW * CP];                        // [row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -56,16 +64,42 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     // (Tried and slower: keeping the loaded values raw and masking them when they are written to LDS, 68 vs 77 TFLOP/s at
     // 512 channels; an explicit LDS-operand prefetch in the MFMA loop, 64.)
     constexpr int NLINE = 64 * WROWS / ROWS, LPW = NLINE / 8;    // x lines (ROWS window rows each), per wave
-    constexpr int HC = XW - RW * S;                              // halo columns of a window row (KW - 1)
+    constexpr int HC = FULL ? (KW > S ? KW - S : 0) : XW - RW * S;   // halo columns of a window row (KW - 1; FULL: only those a tap reads, KW - S)
     constexpr int NHE = 64 * WROWS * HC, NHT = (NHE + 511) / 512;   // halo elements, per thread
     constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (a 64-lane instruction = 64 / PX lines)
     static_assert(RW * S * ROWS == 64, "a staging line is 64 columns (+ halo)");
     float rg[GL], rx[LPW + (NHT ? NHT : 1)];
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned hoff[NHT ? NHT : 1];                                // FULL: a thread's halo elements, fixed for the launch (offset from the chunk's window origin / LDS slot)
+    int hdst[NHT ? NHT : 1];
+    if constexpr (FULL) {
+#pragma unroll
+        for (int t = 0; t < NHT; ++t) {
+            const int e = min(tid + 512 * t, NHE - 1);
+            const int L = e / (HC ? HC : 1), hc = RW * S + e - L * (HC ? HC : 1), i = L / WROWS, r = L - i * WROWS;
+            hoff[t] = (unsigned)i * (unsigned)xplane + (unsigned)r * (unsigned)p.W + (unsigned)hc;
+            hdst[t] = (r * XW + hc) * CP + i;
+        }
+    }
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int cx = ROWS == 1 ? c % p.chunks_x : 0;
         const int oy = ROWS == 1 ? (c / p.chunks_x) % p.OH : ROWS * (c % (p.OH / ROWS)), n = ROWS == 1 ? c / (p.chunks_x * p.OH) : c / (p.OH / ROWS);
         const int ox0 = cx * PX;                                 // (ROWS = 2: the chunk's 64 pixels are rows oy, oy + 1 -- contiguous in g)
+        if constexpr (FULL) {
+            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0;           // wave-uniform
+            const unsigned goff = (unsigned)(lane / PX) * (unsigned)gplane + (unsigned)(lane % PX);
+#pragma unroll
+            for (int j = 0; j < GL; ++j) rg[j] = (gp + (long)((wv + 8 * j) * (64 / PX)) * gplane)[goff];
+            const float* xb = p.x + ((long)n * p.I + i0) * xplane + (long)(oy * S) * p.W + ox0 * S;   // wave-uniform: window row 0, column 0, channel i0
+#pragma unroll
+            for (int j = 0; j < LPW; ++j) {
+                const int L = wv + 8 * j, i = L / WROWS, r = L - i * WROWS;
+                rx[j] = (xb + (long)i * xplane + (long)r * p.W)[lane];
+            }
+#pragma unroll
+            for (int t = 0; t < NHT; ++t) rx[LPW + t] = xb[hoff[t]];
+            return;
+        }
         {
             const int gpx = lane % PX, gsub = lane / PX;         // pixel, line within the instruction
             const bool pok = ROWS > 1 || ox0 + gpx < p.OW;      // (ROWS = 2: pixel gpx of rows oy, oy + 1 -- 64 contiguous floats)
@@ -102,6 +136,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         }
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
+        if constexpr (FULL) {
+            const int gpx = lane % PX, gsub = lane / PX;
+#pragma unroll
+            for (int j = 0; j < GL; ++j) Gs[gpx * CP + (wv + 8 * j) * (64 / PX) + gsub] = rg[j];
+#pragma unroll
+            for (int j = 0; j < LPW; ++j) {
+                const int L = wv + 8 * j, i = L / WROWS, r = L - i * WROWS;
+                Xs[(r * XW + lane) * CP + i] = rx[j];
+            }
+#pragma unroll
+            for (int t = 0; t < NHT; ++t) Xs[hdst[t]] = rx[LPW + t];           // (threads past the last halo element repeat it: same value, no mask)
+            return;
+        }
         {
             const int gpx = lane % PX, gsub = lane / PX;
 #pragma unroll
@@ -126,6 +173,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         store_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);
+        if constexpr (FULL) {
+            const float* ga = Gs + (2 * grp + half) * CP + mo * 32 + l31;
+            const float* xa = Xs + (2 * grp + half) * S * CP + nt * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < PX / 4; ++j) {                       // k = 2 (grp + 2 j) + half: constant offsets from the two lane bases
+                const float a = ga[4 * j * CP];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[((t / KW) * XW + 4 * j * S + (t % KW)) * CP], acc[t], 0, 0, 0);
+            }
+        } else
         for (int ks = grp; ks < PX / 2; ks += 2) {               // the two wave groups take alternate k-steps
             const int k = 2 * ks + half;                         // pixel of this lane's operand row
             const float a = Gs[k * CP + mo * 32 + l31];
@@ -449,6 +507,10 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
     const bool packed = wgrad_packed(OW, OH, W, kh, stride, pad);
     const bool two_rows = !packed && kh == 3 && stride == 1 && OW == 32 && (OH % 2) == 0 && W == 32 + 2 - 2 * pad;      // 32-pixel rows: two per chunk
+    // the unmasked form: every line, halo column and channel of every chunk inside the tensors (FIR-padded stride-2 layers, 1x1 layers)
+    const int px = stride == 1 ? 64 : 32;
+    const bool full = !packed && !two_rows && pad == 0 && I % 64 == 0 && O % 64 == 0 && OW % px == 0 && (OH - 1) * stride + kh - 1 < H &&
+                      (OW - px) * stride + 63 + (kw > stride ? kw - stride : 0) < W && 64L * H * W < (1L << 31) && 2L * OH * OW < (1L << 31);
     p.chunks_x = shg_cdiv(OW, stride == 1 ? 64 : 32);
     p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : (two_rows ? NB * (OH / 2) : NB * OH * p.chunks_x);
     p.nslice = wgrad_slices(NB, I, O, OH, OW, kh * kw);
@@ -461,6 +523,8 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     if (packed && stride == 1) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (packed) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (two_rows) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 2>), grid, dim3(512), 0, s, p);
+    else if (full && kh == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 1, true>), grid, dim3(512), 0, s, p);
+    else if (full && kh == 1 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, true>), grid, dim3(512), 0, s, p);
     else if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);

@@ -38,6 +38,7 @@ class BucketedAllReduce:
         self._touched = set()      # id(param) of the parameters that received a gradient since zero_grad()
         self._armed = False        # True only inside the LAST backward pass of a phase (arm())
         self._armed_once = False   # arm() seen since zero_grad()
+        self.defer = False         # True: hooks never launch a collective (the backward is being captured / replayed as a HIP graph); reduce_all() does
         cap = max(int(bucket_bytes) // 4, 1)
         cur, cur_n = [], 0
         groups = []
@@ -78,7 +79,7 @@ class BucketedAllReduce:
         if not self._armed:                      # an earlier backward of the phase: accumulate only
             return
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.reduce:
+        if self._pending[bi] == 0 and self.reduce and not self.defer:
             self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     # -- per step ------------------------------------------------------------------------------------------------------
@@ -115,14 +116,25 @@ class BucketedAllReduce:
         them (``zero_grad(set_to_none=True)`` semantics: no moment decay, no step) gets ``p.grad = None`` for these."""
         return [p for p in self.params if id(p) not in self._touched]
 
-    def finish(self):
+    def reduce_all(self):
+        """Every bucket now, between two graph replays (train_stage.PhaseGraphs with more than one rank: the backward passes of a phase are
+        one HIP graph, no hook runs on the host while it replays, so nothing can be launched bucket by bucket under it).  All buckets are
+        in flight together (RCCL: its own stream; the calling stream waits for them); follow with ``finish(reduced=True)``."""
+        if not self.reduce:
+            return
+        hs = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self.buckets]
+        for h in hs:
+            h.wait()
+
+    def finish(self, reduced=False):
         """Wait for the reductions launched by the armed backward pass; average, sanitise.  Buckets that were not launched (a
-        parameter the armed pass did not reach, or no armed pass at all) are reduced here, synchronously."""
+        parameter the armed pass did not reach, or no armed pass at all) are reduced here, synchronously.  ``reduced=True``: the caller
+        has run ``reduce_all()`` -- only the averaging and the sanitisation are left (this part can be captured in a graph)."""
         launched = {bi for bi, _ in self._handles}
         for bi, h in self._handles:
             h.wait()
         for bi, flat in enumerate(self.buckets):
-            if self.reduce and bi not in launched:
+            if self.reduce and not reduced and bi not in launched:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
                 flat.div_(self.world)

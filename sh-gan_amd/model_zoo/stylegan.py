@@ -508,8 +508,9 @@ def _modulated_conv2d_half_infer(x, weight, styles, noise, up, padding, resample
         return None
     if up == 2 and not (k == 3 and resample_filter is not None and resample_filter.ndim == 2 and tuple(resample_filter.shape) == (4, 4)):
         return None
-    if weight.shape[0] % 8 and (up == 2 or fused):
-        return None              # the NHWC tail / per-image store passes move 8 channels per lane: narrower outputs take the composed route
+    if weight.shape[0] % 8 and up == 2:
+        return None              # the NHWC tail pass after the FIR (modtail) moves 8 channels per lane: narrower outputs take the composed route
+                                 # (up = 1 stores any width: toRGB's 3 channels run fused, tests/test_gpu_fp16.py)
     # the weight side (normalisation, sum of squares, operand-order packing) depends on the parameter alone: cached per parameter version
     # when the caller hands its layer cache (the float32 route does the same with `prepped()`)
     def build():

@@ -109,8 +109,9 @@ def run_phases(real_img, z_dim, phases, batch_idx, loss, batch_gpu, effective_ba
 SINGLE_THREADED_BACKWARD = os.environ.get('SHG_ENGINE_THREADS', '0') != '1'
 
 
-def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
-    """One phase of an iteration on given tensors: the inner block of ``run_phases`` (stylegan_default.py:141-166)."""
+def _phase_backward(phase, loss, real_img, real_c, gen_z, gen_c, eff):
+    """First half of a phase (stylegan_default.py:141-158): zero the gradients, open the phase's module, run the loss's forward and
+    backward passes over the rounds.  Bucket all-reduces are launched from the backward hooks (eager loop) unless ``phase.sync.defer``."""
     if phase.sync is not None:
         phase.sync.zero_grad()                       # gradients live in the all-reduce buckets
     else:
@@ -126,15 +127,26 @@ def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
     phase.module.requires_grad_(False)
     if hasattr(loss, 'grad_sync'):
         loss.grad_sync = None
+
+
+def _phase_step(phase, loss=None, reduced=False):
+    """Second half (stylegan_default.py:159-166): gradients averaged over the ranks and sanitised, optimiser step.  ``reduced``: the
+    buckets were all-reduced by ``phase.sync.reduce_all()`` already (split-graph form)."""
     if phase.sync is not None:
-        if phase.sync.reduce and not phase.sync.was_armed():
+        if phase.sync.reduce and not reduced and not phase.sync.was_armed():
             _warn_unarmed(loss, phase)               # correct, but every bucket is reduced synchronously in finish(): no overlap
-        phase.sync.finish()                          # waits for the bucket all-reduces, averages, nan_to_num
+        phase.sync.finish(reduced=reduced)           # waits for the bucket all-reduces, averages, nan_to_num
         for p in phase.sync.untouched():             # as after zero_grad(set_to_none=True): the optimiser skips them
             p.grad = None
     else:
         sanitize_(phase.module.parameters())
     phase.opt.step()
+
+
+def _phase_body(phase, loss, real_img, real_c, gen_z, gen_c, eff):
+    """One phase of an iteration on given tensors: the inner block of ``run_phases`` (stylegan_default.py:141-166)."""
+    _phase_backward(phase, loss, real_img, real_c, gen_z, gen_c, eff)
+    _phase_step(phase, loss)
 
 
 class PhaseGraphs:
@@ -149,8 +161,14 @@ class PhaseGraphs:
     from static buffers that ``run`` fills first.
 
     Parameter-derived caches (prepared weight layouts of no-grad passes) are keyed on version counters, which a replay does not
-    advance: the caches are invalidated around captures and after every replay.  Single process only (a captured RCCL
-    all-reduce is not exercised here): with more than one rank use ``run_phases``."""
+    advance: the caches are invalidated around captures and after every replay.
+
+    More than one rank (an active ``BucketedAllReduce``): a phase is TWO graphs with the collective between them on the host side --
+    graph A = zero_grad -> forward(s) -> backward(s) into the buckets (hooks deferred: no collective is captured), then
+    ``sync.reduce_all()`` (every bucket in flight at once over RCCL), then graph B = average + sanitise + optimiser step.  What is given
+    up against the eager loop is the overlap of the reduction with backward (G: 5 buckets of 64 MiB, D: 4; about 2 ms of ring
+    all-reduce per phase on xGMI), what is gained is the host enqueue of ~2 000 launches per phase; ``bench.py`` times both forms and
+    takes the faster one on all ranks together."""
 
     def __init__(self, phases, loss, batch_gpu, z_dim, real_shape, device, effective_batch_gpu=None, warmup=2):
         self.phases, self.loss, self.b, self.z_dim = phases, loss, batch_gpu, z_dim
@@ -165,10 +183,8 @@ class PhaseGraphs:
         self.warmup = warmup
         if warmup < 1:
             raise ValueError('PhaseGraphs: warmup >= 1 (lazily built constants, Adam state and allocator pools must exist before the capture)')
+        self.split = any(ph.sync is not None and ph.sync.reduce for ph in phases)      # more than one rank: two graphs per phase
         for ph in phases:
-            if ph.sync is not None and ph.sync.reduce:
-                raise ValueError('PhaseGraphs is single-process: a captured RCCL all-reduce (async handles, untouched()) is not supported; '
-                                 'with more than one rank use run_phases')
             for g in ph.opt.param_groups:
                 if not g.get('capturable', False):
                     raise ValueError('PhaseGraphs: build the optimisers with capturable=True (the step counter must live on the device)')
@@ -192,13 +208,41 @@ class PhaseGraphs:
                 self.seen[ph.name] += 1
                 _phase_body(ph, self.loss, self.real, self.real_c, self.z[ph.name], self.gen_c, self.eff)
             else:
-                if g is None:
+                if g is None and not self.split:
                     self._invalidate()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         _phase_body(ph, self.loss, self.real, self.real_c, self.z[ph.name], self.gen_c, self.eff)
                     self.graphs[ph.name] = g
-                g.replay()
+                elif g is None:
+                    # two graphs around the host-side collective.  Nothing is reduced while capturing; whether the capture worked is agreed
+                    # between the ranks BEFORE the first collective of the replay (a rank that failed alone would leave the others
+                    # waiting in reduce_all): all ranks raise together and the caller falls back to run_phases together.
+                    self._invalidate()
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    err = None
+                    ph.sync.defer = True
+                    try:
+                        with torch.cuda.graph(ga):
+                            _phase_backward(ph, self.loss, self.real, self.real_c, self.z[ph.name], self.gen_c, self.eff)
+                        ph.sync.defer = False
+                        with torch.cuda.graph(gb, pool=ga.pool()):
+                            _phase_step(ph, self.loss, reduced=True)
+                    except Exception as e:              # noqa: BLE001 -- reported below, on every rank
+                        err = e
+                    finally:
+                        ph.sync.defer = False
+                    ok = torch.tensor([0.0 if err is not None else 1.0], device=self.device if torch.distributed.get_backend(ph.sync.group) == 'nccl' else 'cpu')
+                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=ph.sync.group)
+                    if float(ok.item()) < 1.0:
+                        raise RuntimeError(f'PhaseGraphs: capture of phase {ph.name} failed on ' + ('this rank: ' + repr(err) if err is not None else 'another rank'))
+                    g = self.graphs[ph.name] = (ga, gb)
+                if self.split:
+                    g[0].replay()
+                    ph.sync.reduce_all()
+                    g[1].replay()
+                else:
+                    g.replay()
                 self._invalidate()
             ran.append(ph.name)
         return ran

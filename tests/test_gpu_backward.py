@@ -34,6 +34,9 @@ CONV_CASES = [
     (2, 32, 32, 33, 33, 3, 2, 0), (3, 16, 24, 8, 8, 3, 2, 1),
     # 32-pixel output rows: two rows per chunk of the weight-gradient kernel (pad 1 and pad 0), and an odd row count (one-row chunks)
     (2, 24, 40, 34, 34, 3, 1, 0), (3, 70, 64, 32, 32, 3, 1, 1), (2, 16, 24, 33, 32, 3, 1, 1),
+    # the unmasked form of the weight gradient (round 6): channels in whole 64-blocks, rows in whole chunks, no padding -- the FIR-padded
+    # stride-2 layers (65 -> 32, 129 -> 64 with two chunks per row, non-square) and 1x1 layers; one row more than the valid extent needs
+    (2, 64, 128, 65, 65, 3, 2, 0), (1, 128, 64, 33, 129, 3, 2, 0), (2, 64, 64, 66, 66, 3, 2, 0), (2, 64, 128, 16, 64, 1, 1, 0), (1, 128, 64, 8, 128, 1, 1, 0),
 ]
 
 

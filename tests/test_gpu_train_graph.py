@@ -656,3 +656,65 @@ def test_closed_tail_backward_node_vs_tensor_operators(half, with_d):
     tol = 4e-3 if half else 2e-5
     for a, bb in zip(res[True], res[False]):
         assert rel_err(a.detach().cpu().numpy(), bb.detach().cpu().numpy()) < tol or float(bb.abs().max()) == 0.0
+
+
+def test_phase_graphs_two_ranks_split_around_the_all_reduce():
+    """More than one rank: a phase is two HIP graphs with the bucket all-reduce between them on the host side (train_stage.PhaseGraphs,
+    ``split``).  Two ranks share the test box's one device (gloo; RCCL wants a device per rank), each with its own data: after seven
+    iterations the split-graph form has the parameters of the eager loop (hook-launched reductions under backward) to round-off, and the
+    two ranks hold bit-identical parameters in both forms (same averaged gradients, same optimiser arithmetic)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import copy, os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SHG_ROOT"], "tests"))
+import shgan_amd
+from shgan_amd import losses, train_stage as ts
+from test_gpu_train_graph import small_networks, real_batch, DEV
+r = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"], rank=r, world_size=2)
+G, D = small_networks(5)
+g0, d0 = copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict())
+init = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone()
+real4 = real_batch(4, 60 + r)                          # per-rank data
+kw = dict(lr=0.002, betas=(0.0, 0.99), eps=1e-8, capturable=True)
+order = [0, 1, 2, 4, 5, 8, 9]
+out = []
+for graphed in (False, True):
+    G.load_state_dict(g0); D.load_state_dict(d0)
+    torch.manual_seed(11 + r)
+    L = losses.InpaintingLoss(DEV, G, D, composite_fake=True, noise_mode="const", style_mixing_prob=0)
+    phases = ts.make_phases(G, D, kw, kw, g_reg_interval=4, d_reg_interval=16, bucket_bytes=1 << 16)
+    assert all(ph.sync is not None and ph.sync.reduce and len(ph.sync.buckets) > 1 for ph in phases)
+    pg = ts.PhaseGraphs(phases, L, 4, 64, tuple(real4.shape), DEV) if graphed else None
+    assert pg is None or pg.split
+    for idx in order:
+        pg.run(real4, idx) if graphed else ts.run_phases(real4, 64, phases, batch_idx=idx, loss=L, batch_gpu=4, device=DEV)
+    torch.cuda.synchronize()
+    if graphed:
+        assert set(pg.graphs) == {"Gmain", "Greg", "Dmain"} and all(isinstance(g, tuple) and len(g) == 2 for g in pg.graphs.values())
+    out.append(torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone())
+    for ph in phases:
+        ph.sync.remove()
+worst = float(((out[0] - out[1]).abs().max() / out[0].abs().max()))
+moved = float((out[1] - init).abs().max())
+for form in out:                                       # both ranks hold the same parameters, bit for bit
+    both = [torch.zeros_like(form.cpu()) for _ in range(2)]
+    dist.all_gather(both, form.cpu())
+    assert torch.equal(both[0], both[1]), "ranks diverged"
+assert torch.isfinite(out[1]).all() and worst < 1e-4 and moved > 0, (worst, moved)
+dist.destroy_process_group()
+print("rank", r, "ok", "worst %.2e" % worst)
+'''
+    port = str(38500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=root, SHG_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        o, _ = p.communicate(timeout=1200)
+        assert p.returncode == 0 and f'rank {rank} ok'.encode() in o, o.decode()[-3000:]
+        print(o.decode().strip().splitlines()[-1])

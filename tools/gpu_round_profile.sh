@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 # with the default three-stream pipeline (kernels of different batches overlap: longer individual durations, shorter wall time)
 for MODE in single pipelined; do
   D=1; [ $MODE = pipelined ] && D=3
-  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --graph off --no-cpu-baseline --no-second-config --no-train-step > $OUT/prof_stdout_$MODE.log 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 2 --pipeline-depth $D --profile-steps 0 --graph off --no-cpu-baseline --no-second-config --no-train-step --no-eval-loop > $OUT/prof_stdout_$MODE.log 2>&1 )
   cd $GRAFT_REPO_ROOT
   F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   SUF=""; [ $MODE = pipelined ] && SUF="_pipelined"
