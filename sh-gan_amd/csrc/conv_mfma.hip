@@ -713,6 +713,149 @@ static int launch_conv(ConvParams& p, void* workspace, size_t ws_bytes, hipStrea
     return SHG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolutions as a plain GEMM (round 6): y[n, o, P] = epilogue(sum_i W[o, i] x[n, i, P]) for the critic's skip branches and their
+// input gradients (stylegan.py:413-421 via conv2d_resample.py:108-113: FIR-decimate, then a 1x1 layer).  The tap-list kernel above served
+// them with register-staged 4-byte patch loads into a pixel-major LDS image at 2 - 2.6 x the larger of their HBM and MFMA floors
+// (tools/conv1x1_bench.py).  Here both operands arrive by 16-byte LDS-DMA in the layouts the MFMA reads: the weight chunk [64-block][k][64 o]
+// (the prepped tensor's own order: 1 KiB = four rows per wave instruction) and the activations [k][pixel] (a channel's pixels are contiguous
+// in NCHW: 1 KiB = 256 pixels of one channel or 128 of two) -- no staging registers, no LDS writes, two stages, one barrier per chunk, and
+// the operands of k-step j + 1 are read before the MFMAs of step j issue.  Workgroup = 4 waves of 64 x 64 outputs: 128 o x 128 px, or
+// 64 o x 256 px for 64 output channels.  Eligible: whole tiles (O % BO, pixels % BP, I % KC == 0), no style / noise operands.
+// ---------------------------------------------------------------------------------------------
+template <int WO, int WP, int KC>
+__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const ConvParams p) {
+    constexpr int BO = 64 * WO, BP = 64 * WP, WSZ = KC * BO, XSZ = KC * BP;
+    static_assert(WO * WP == 4 && KC % 4 == 0, "four waves");
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+    float* Ws = c1_lds;                       // [2][WO][KC][64]
+    float* Xs = c1_lds + 2 * WSZ;             // [2][KC][BP]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wo = wave / WP, wp = wave % WP;
+    const int P = p.H * p.W, ptiles = P / BP, otiles = p.O / BO;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int ot = t % otiles; t /= otiles;
+    const int pt = t % ptiles, n = t / ptiles;
+    const int o0 = ot * BO, p0 = pt * BP;
+    const float* xn = p.x + ((long)n * p.I) * P + p0;
+    const float* wb = p.wt + (long)(o0 >> 6) * p.IPK * 64;
+    // DMA requests of a chunk: weights 4 rows (of one 64-block) per request, activations 256 pixels per request
+    constexpr int WREQ = WO * KC / 4, XREQ = KC * BP / 256, RPW = (WREQ + XREQ) / 4;
+    static_assert((WREQ + XREQ) % 4 == 0, "requests divide over the four waves");
+    auto issue = [&](int i0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int rq = wave + 4 * k;                                  // wave-uniform
+            if (rq < WREQ) {
+                const int b = rq / (KC / 4), r4 = rq % (KC / 4);
+                const float* src = wb + ((long)b * p.IPK + i0 + r4 * 4 + (lane >> 4)) * 64 + (lane & 15) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Ws + buf * WSZ + (b * KC + r4 * 4) * 64), 16, 0, 0);
+            } else {
+                const int xr = rq - WREQ;                                 // 256 pixels: BP = 128 -> rows 2 xr, 2 xr + 1; BP = 256 -> row xr
+                const int row = BP == 128 ? 2 * xr + (lane >> 5) : xr, px = BP == 128 ? (lane & 31) * 4 : lane * 4;
+                const float* src = xn + (long)(i0 + row) * P + px;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Xs + buf * XSZ + xr * 256), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    issue(0, 0);
+    int buf = 0;
+    for (int i0 = 0; i0 < p.I; i0 += KC, buf ^= 1) {
+        __syncthreads();                                                   // chunk i0 landed (vmcnt(0) before the barrier); the other stage is free
+        if (i0 + KC < p.I) issue(i0 + KC, buf ^ 1);
+        const float* wa = Ws + buf * WSZ + (wo * KC + half) * 64 + l31;
+        const float* xa = Xs + buf * XSZ + half * BP + wp * 64 + l31;
+        float a_cur[2] = {wa[0], wa[32]}, b_cur[2] = {xa[0], xa[32]};
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) {
+            float a_nxt[2] = {0.f, 0.f}, b_nxt[2] = {0.f, 0.f};
+            if (j + 1 < KC / 2) {
+                a_nxt[0] = wa[(2 * j + 2) * 64]; a_nxt[1] = wa[(2 * j + 2) * 64 + 32];
+                b_nxt[0] = xa[(2 * j + 2) * BP]; b_nxt[1] = xa[(2 * j + 2) * BP + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a], b_cur[b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+        }
+    }
+    // epilogue: register r of tile (a, b) = channel o0 + wo 64 + a 32 + (r & 3) + 8 (r >> 2) + 4 half, pixel p0 + wp 64 + b 32 + l31.  Stored from
+    // the registers a store instruction would write 2 x 128 bytes of 2 channels; the wave's 64 x 64 block therefore goes through LDS (its own
+    // 16 KiB of the stages, 16 channels at a time in the padded form [16][68]) and leaves as 16-byte pieces: 256 contiguous bytes per channel row.
+    __syncthreads();                                                       // every wave is done reading the stages
+    float* tr = c1_lds + wave * (16 * 68);
+    const ShgAct act = shg_act_make(p.act, p.alpha, p.gain, p.clamp);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                                   // 16 channels: registers r = 8 hb .. 8 hb + 7 of both pixel blocks
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * hb + rr, cl = (rr & 3) + 8 * (rr >> 2) + 4 * half;      // channel within the 16: (r & 3) + 8 ((r >> 2) & 1) + 4 half
+                    tr[cl * 68 + b * 32 + l31] = acc[a][b][r];
+                }
+            // (a wave's own region: no barrier, the LDS pipe returns in order)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                  // 16 channels x 16 pieces = 256 pieces over 64 lanes
+                const int e = lane + 64 * k, cl = e >> 4, pc = e & 15;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(tr + cl * 68 + pc * 4);
+                const int o = o0 + wo * 64 + a * 32 + 16 * hb + cl;
+                const long idx = ((long)n * p.O + o) * P + p0 + wp * 64 + pc * 4;
+                const float osc = p.out_scale ? p.out_scale[n * p.O + o] : 1.f, bs = p.bias ? p.bias[o] : 0.f;
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                if (p.residual) rs = *reinterpret_cast<const f32x4*>(p.residual + idx);
+                f32x4 out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = v4[q] * osc + bs;
+                    v = p.act ? shg_lrelu_agc(v, p.alpha, p.gain, p.clamp) : v * p.gain;   // (same expression as conv_epilogue: identical bits)
+                    out[q] = v + rs[q];
+                }
+                *reinterpret_cast<f32x4*>(p.y + idx) = out;
+            }
+        }
+    (void)act;
+}
+
+// the GEMM form applies: stride-1 1x1 without style / noise operands, whole tiles, enough of them to fill the chip
+static bool conv1x1_gemm_ok(const ConvParams& p, int* narrow) {
+    const long P = (long)p.H * p.W;
+    if (p.wgroups != 1 || p.in_scale || p.noise_mode || p.OHt != p.H || p.OWt != p.W) return false;
+    if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.wt) & 15)) return false;
+    const bool nar = p.O % 128 != 0;
+    *narrow = nar;
+    const int BO = nar ? 64 : 128, BP = nar ? 256 : 128, KC = 16;
+    if (p.O % BO || P % BP || p.I % KC) return false;
+    return (long)p.NB * (P / BP) * (p.O / BO) >= conv_cu_count();          // (at least one tile per CU: below that the split-K tap-list kernel fills the chip better)
+}
+
+static int launch_conv1x1_gemm(ConvParams& p, int narrow, hipStream_t s) {
+    const long P = (long)p.H * p.W;
+    if (narrow) {
+        constexpr int lds = 2 * (16 * 64 + 16 * 256) * 4;
+        hipLaunchKernelGGL((conv1x1_gemm_kernel<1, 4, 16>), dim3((unsigned)(p.NB * (P / 256) * (p.O / 64))), dim3(256), lds, s, p);
+    } else {
+        constexpr int lds = 2 * (16 * 128 + 16 * 128) * 4;            // 32 KiB: four workgroups per CU
+        hipLaunchKernelGGL((conv1x1_gemm_kernel<2, 2, 16>), dim3((unsigned)(p.NB * (P / 128) * (p.O / 128))), dim3(256), lds, s, p);
+    }
+    SHG_CHECK_LAUNCH();
+    return SHG_OK;
+}
+
 static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, size_t ws_bytes, hipStream_t s) {
     const bool narrow = p.O <= 64;    // 64 x 256 tile instead of 128 x 128
     // SHG_CONV_VARIANT (tuning knob, bit flags): 1 = force the single-buffer 4-wave kernels; 2 / 4 / 8 = try the 8-wave
@@ -758,6 +901,8 @@ static int conv_dispatch(ConvParams& p, int K, int S, bool up, void* workspace, 
         return narrow ? launch_conv<9, 8, 2, 2, 1, 4, 5, false, false, 2>(p, workspace, ws_bytes, s)
                       : launch_conv<9, 8, 2, 2, 2, 2, 3, false, false, 2>(p, workspace, ws_bytes, s);
     }
+    int c1_narrow = 0;
+    if (K == 1 && S == 1 && !(variant & 64) && conv1x1_gemm_ok(p, &c1_narrow)) return launch_conv1x1_gemm(p, c1_narrow, s);
     if (K == 1 && S == 1) return narrow ? launch_conv<1, 32, 2, 2, 1, 4, 1, false, false, 3>(p, workspace, ws_bytes, s)
                                         : launch_conv<1, 32, 2, 2, 2, 2, 1, false, false, 3>(p, workspace, ws_bytes, s);
     shg_set_error("conv2d: 1x1 stride-2 convolution is not implemented (decimate with upfirdn2d first)");

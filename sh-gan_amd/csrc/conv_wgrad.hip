@@ -31,18 +31,10 @@ struct WgradParams {
 
 // ROWS = 2 (stride 1, OW == 32): a chunk is TWO whole output rows of 32 pixels (the same 64 operand columns; a one-row chunk would leave half
 // of them empty: 990 us for the 512-channel 32^2 layers) -- the window is then KH + 1 rows of 34 columns, a staging line = two window rows.
-//
-// FULL (host-checked: pad == 0, I and O multiples of 64, OW a multiple of the chunk width, every window row and column inside x -- the
-// FIR-padded stride-2 layers and the 1x1 layers of the training step): no element of a chunk needs a mask.  The masked form's selects
-// (`ok ? v : 0`) were scheduled -- with the `s_waitcnt vmcnt(0)` they need -- BEFORE the MFMA loop (ISA of round 5: the software pipeline
-// described below did not exist in the binary; 39 % of the wave cycles parked).  Here the loads are unconditional, addressed as a
-// wave-uniform line pointer + one lane offset, their values are first touched by the LDS writes of the next iteration, and the k-steps of
-// a chunk are unrolled so that the operand reads of a step are issued under the MFMAs of the step before.
-template <int KH, int KW, int S, int ROWS = 1, bool FULL = false>
+template <int KH, int KW, int S, int ROWS = 1>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, RW = PX / ROWS, XW = RW * S + KW - 1, WROWS = KH + ROWS - 1, CP = 65;    // CP: channel pitch (odd)
     static_assert(ROWS == 1 || S == 1, "two-row chunks are a stride-1 form");
-    static_assert(!FULL || ROWS == 1, "the unmasked form is a one-row form");
     __shared__ float Gs[PX * CP];                                // [pixel][o]
     __shared__ float Xs[WROWS * XW * CP];                        // [row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -64,42 +56,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     // (Tried and slower: keeping the loaded values raw and masking them when they are written to LDS, 68 vs 77 TFLOP/s at
     // 512 channels; an explicit LDS-operand prefetch in the MFMA loop, 64.)
     constexpr int NLINE = 64 * WROWS / ROWS, LPW = NLINE / 8;    // x lines (ROWS window rows each), per wave
-    constexpr int HC = FULL ? (KW > S ? KW - S : 0) : XW - RW * S;   // halo columns of a window row (KW - 1; FULL: only those a tap reads, KW - S)
+    constexpr int HC = XW - RW * S;                              // halo columns of a window row (KW - 1)
     constexpr int NHE = 64 * WROWS * HC, NHT = (NHE + 511) / 512;   // halo elements, per thread
     constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (a 64-lane instruction = 64 / PX lines)
     static_assert(RW * S * ROWS == 64, "a staging line is 64 columns (+ halo)");
     float rg[GL], rx[LPW + (NHT ? NHT : 1)];
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    unsigned hoff[NHT ? NHT : 1];                                // FULL: a thread's halo elements, fixed for the launch (offset from the chunk's window origin / LDS slot)
-    int hdst[NHT ? NHT : 1];
-    if constexpr (FULL) {
-#pragma unroll
-        for (int t = 0; t < NHT; ++t) {
-            const int e = min(tid + 512 * t, NHE - 1);
-            const int L = e / (HC ? HC : 1), hc = RW * S + e - L * (HC ? HC : 1), i = L / WROWS, r = L - i * WROWS;
-            hoff[t] = (unsigned)i * (unsigned)xplane + (unsigned)r * (unsigned)p.W + (unsigned)hc;
-            hdst[t] = (r * XW + hc) * CP + i;
-        }
-    }
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int cx = ROWS == 1 ? c % p.chunks_x : 0;
         const int oy = ROWS == 1 ? (c / p.chunks_x) % p.OH : ROWS * (c % (p.OH / ROWS)), n = ROWS == 1 ? c / (p.chunks_x * p.OH) : c / (p.OH / ROWS);
         const int ox0 = cx * PX;                                 // (ROWS = 2: the chunk's 64 pixels are rows oy, oy + 1 -- contiguous in g)
-        if constexpr (FULL) {
-            const float* gp = p.g + ((long)n * p.O + o0) * gplane + (long)oy * p.OW + ox0;           // wave-uniform
-            const unsigned goff = (unsigned)(lane / PX) * (unsigned)gplane + (unsigned)(lane % PX);
-#pragma unroll
-            for (int j = 0; j < GL; ++j) rg[j] = (gp + (long)((wv + 8 * j) * (64 / PX)) * gplane)[goff];
-            const float* xb = p.x + ((long)n * p.I + i0) * xplane + (long)(oy * S) * p.W + ox0 * S;   // wave-uniform: window row 0, column 0, channel i0
-#pragma unroll
-            for (int j = 0; j < LPW; ++j) {
-                const int L = wv + 8 * j, i = L / WROWS, r = L - i * WROWS;
-                rx[j] = (xb + (long)i * xplane + (long)r * p.W)[lane];
-            }
-#pragma unroll
-            for (int t = 0; t < NHT; ++t) rx[LPW + t] = xb[hoff[t]];
-            return;
-        }
         {
             const int gpx = lane % PX, gsub = lane / PX;         // pixel, line within the instruction
             const bool pok = ROWS > 1 || ox0 + gpx < p.OW;      // (ROWS = 2: pixel gpx of rows oy, oy + 1 -- 64 contiguous floats)
@@ -136,19 +102,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         }
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
-        if constexpr (FULL) {
-            const int gpx = lane % PX, gsub = lane / PX;
-#pragma unroll
-            for (int j = 0; j < GL; ++j) Gs[gpx * CP + (wv + 8 * j) * (64 / PX) + gsub] = rg[j];
-#pragma unroll
-            for (int j = 0; j < LPW; ++j) {
-                const int L = wv + 8 * j, i = L / WROWS, r = L - i * WROWS;
-                Xs[(r * XW + lane) * CP + i] = rx[j];
-            }
-#pragma unroll
-            for (int t = 0; t < NHT; ++t) Xs[hdst[t]] = rx[LPW + t];           // (threads past the last halo element repeat it: same value, no mask)
-            return;
-        }
         {
             const int gpx = lane % PX, gsub = lane / PX;
 #pragma unroll
@@ -173,17 +126,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         store_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);
-        if constexpr (FULL) {
-            const float* ga = Gs + (2 * grp + half) * CP + mo * 32 + l31;
-            const float* xa = Xs + (2 * grp + half) * S * CP + nt * 32 + l31;
-#pragma unroll
-            for (int j = 0; j < PX / 4; ++j) {                       // k = 2 (grp + 2 j) + half: constant offsets from the two lane bases
-                const float a = ga[4 * j * CP];
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[((t / KW) * XW + 4 * j * S + (t % KW)) * CP], acc[t], 0, 0, 0);
-            }
-        } else
         for (int ks = grp; ks < PX / 2; ks += 2) {               // the two wave groups take alternate k-steps
             const int k = 2 * ks + half;                         // pixel of this lane's operand row
             const float a = Gs[k * CP + mo * 32 + l31];
@@ -224,6 +166,159 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, i = i0 + nt * 32 + l31;
             if (o < p.O && i < p.I) dst[((long)o * p.I + i) * TAPS + t] = acc[t][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The unmasked form (round 6).  Host-checked: pad == 0, I and O multiples of 64, OW a multiple of the chunk width, every window row and
+// column inside x -- the FIR-padded stride-2 layers and the 1x1 layers of the training step: no element of a chunk needs a mask.
+// What the ISA of the masked kernel above showed (tools/isa_flow.py): its selects (`ok ? v : 0`) were scheduled, with the `s_waitcnt
+// vmcnt(0)` they need, BEFORE the MFMA loop -- the register pipeline described there did not exist in the binary (39 % of the wave cycles
+// parked, profiles/r05_wgrad_pmc_summary.txt) -- and every operand was read from LDS right before its MFMA.  Here
+//   * loads are unconditional (a wave-uniform line pointer + one lane offset); their values are first touched by LDS writes that are
+//     issued in the SECOND half of the chunk's MFMA stream, into the other of two LDS stages: one barrier per chunk, the writes and
+//     their address arithmetic in the shadow of the matrix pipe;
+//   * the k-steps of a chunk are unrolled and the operands of step j + 1 are read before the MFMAs of step j issue.
+// 1 047 -> 846 us (loads only) -> see MEASUREMENTS.md for the two-stage form, 128 -> 256 channels at 257^2 x 8.
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradParams p) {
+    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, XW = PX * S + KW - 1, CP = 65;
+    constexpr int HC = KW > S ? KW - S : 0;                      // halo columns a tap reads (window column PX * S + hc)
+    constexpr int GSZ = PX * CP, XSZ = KH * XW * CP;
+    __shared__ float Gs[2][GSZ];                                 // [stage][pixel][o]
+    __shared__ float Xs[2][XSZ];                                 // [stage][row][col][i]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int grp = wave >> 2, mo = (wave >> 1) & 1, nt = wave & 1;
+    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, slice = blockIdx.z;
+    const int per = (p.nchunk + p.nslice - 1) / p.nslice;
+    const int c_begin = slice * per, c_end = min(p.nchunk, c_begin + per);
+    wg_f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const long gplane = (long)p.OH * p.OW, xplane = (long)p.H * p.W;
+    constexpr int LPW = 64 * KH / 8;                             // x lines (one window row of one channel: 64 columns) per wave
+    constexpr int NHE = 64 * KH * HC, NHT = (NHE + 511) / 512;   // halo elements, per thread
+    constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (one = 64 / PX channel lines)
+    constexpr int NST = GL + LPW + NHT;                          // staged values per thread
+    float rg[GL], rx[LPW + (NHT ? NHT : 1)];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned hoff[NHT ? NHT : 1];                                // a thread's halo elements: offset from the chunk's window origin / LDS slot
+    int hdst[NHT ? NHT : 1];
+#pragma unroll
+    for (int t = 0; t < NHT; ++t) {
+        const int e = min(tid + 512 * t, NHE - 1);               // (threads past the last element repeat it: same value, no mask)
+        const int L = e / (HC ? HC : 1), hc = PX * S + e - L * (HC ? HC : 1), i = L / KH, r = L - i * KH;
+        hoff[t] = (unsigned)i * (unsigned)xplane + (unsigned)r * (unsigned)p.W + (unsigned)hc;
+        hdst[t] = (r * XW + hc) * CP + i;
+    }
+    // Wave w stages channels 8 w .. 8 w + 7 of both tensors: a line's address is the previous line's plus a plane (scalar adds, no division
+    // by the row count), its LDS slot an immediate offset from one lane base.  The chunk coordinates advance incrementally.
+    constexpr int CPI = 64 / PX;                                 // g channels per wave instruction
+    static_assert(GL * CPI == 8 && LPW == 8 * KH, "eight channels per wave");
+    const unsigned goff = (unsigned)(lane / PX) * (unsigned)gplane + (unsigned)(lane % PX);
+    const int gdst = (lane % PX) * CP + wv * 8 + lane / PX, xdst = lane * CP + wv * 8;
+    int ncx = c_begin % p.chunks_x, noy = (c_begin / p.chunks_x) % p.OH, nn = c_begin / (p.chunks_x * p.OH);      // the chunk load_next() fetches
+    auto load_next = [&](bool advance) __attribute__((always_inline)) {
+        const int ox0 = ncx * PX;
+        const float* gp = p.g + ((long)nn * p.O + o0 + wv * 8) * gplane + (long)noy * p.OW + ox0;            // wave-uniform
+#pragma unroll
+        for (int j = 0; j < GL; ++j) rg[j] = (gp + (long)(j * CPI) * gplane)[goff];
+        const float* xb = p.x + ((long)nn * p.I + i0) * xplane + (long)(noy * S) * p.W + ox0 * S;            // window row 0, column 0, channel i0
+        const float* xw = xb + (long)(wv * 8) * xplane;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int r = 0; r < KH; ++r) rx[jj * KH + r] = (xw + (long)jj * xplane + (long)r * p.W)[lane];
+#pragma unroll
+        for (int t = 0; t < NHT; ++t) rx[LPW + t] = xb[hoff[t]];
+        if (advance) {
+            if (++ncx == p.chunks_x) {
+                ncx = 0;
+                if (++noy == p.OH) { noy = 0; ++nn; }
+            }
+        }
+    };
+    // staged value q of this thread -> LDS stage b (q is a compile-time constant wherever this is called)
+    auto store_item = [&](int q, int b) __attribute__((always_inline)) {
+        if (q < GL) Gs[b][gdst + q * CPI] = rg[q];
+        else if (q < GL + LPW) {
+            const int jj = (q - GL) / KH, r = (q - GL) - jj * KH;
+            Xs[b][xdst + r * XW * CP + jj] = rx[q - GL];
+        } else Xs[b][hdst[q - GL - LPW]] = rx[q - GL];
+    };
+    constexpr int NJ = PX / 4, H0 = NJ / 2, NH = NJ - H0;        // k-steps per wave and chunk; the stores ride on steps H0 .. NJ - 1
+    if (c_begin < c_end) {
+        load_next(c_begin + 1 < c_end);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) store_item(q, 0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int b = (c - c_begin) & 1;
+        load_next(c + 2 < c_end);                                // chunk c + 1 (the last chunk loads itself again: no branch around the loads)
+        const float* ga = Gs[b] + (2 * grp + half) * CP + mo * 32 + l31;
+        const float* xa = Xs[b] + (2 * grp + half) * S * CP + nt * 32 + l31;
+        float a_cur = ga[0], b_cur[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) b_cur[t] = xa[((t / KW) * XW + (t % KW)) * CP];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {                           // k = 2 (grp + 2 j) + half: constant offsets from the two lane bases
+            float a_nxt = 0.f, b_nxt[TAPS];
+            if (j + 1 < NJ) {
+                a_nxt = ga[4 * (j + 1) * CP];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) b_nxt[t] = xa[((t / KW) * XW + 4 * (j + 1) * S + (t % KW)) * CP];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            if (j >= H0) {                                       // this step's share of the next chunk's values -> the other stage
+#pragma unroll
+                for (int q = (j - H0) * NST / NH; q < (j - H0 + 1) * NST / NH; ++q) store_item(q, b ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < NJ) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) b_cur[t] = b_nxt[t];
+            }
+        }
+        __syncthreads();
+    }
+    // the second wave group hands its partial sums to the first through LDS (three taps at a time: 48 KB over the window stages)
+    float* red = &Xs[0][0];
+    constexpr int TB = 2 * XSZ >= 4 * 3 * 1024 ? (TAPS < 3 ? TAPS : 3) : 1;
+    static_assert(2 * XSZ >= 4 * TB * 1024, "reduction buffer");
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TB) {
+        if (t0) __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+                if (t0 + tt < TAPS)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane] = acc[t0 + tt][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+                if (t0 + tt < TAPS)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t0 + tt][r] += red[(((wave & 3) * TB + tt) * 16 + r) * 64 + lane];
+        }
+    }
+    if (grp == 1) return;
+    float* dst = p.out + (p.nslice > 1 ? (long)slice * p.O * p.I * TAPS : 0);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, i = i0 + nt * 32 + l31;
+            dst[((long)o * p.I + i) * TAPS + t] = acc[t][r];
         }
 }
 
@@ -523,8 +618,8 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     if (packed && stride == 1) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (packed) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (two_rows) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 2>), grid, dim3(512), 0, s, p);
-    else if (full && kh == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 1, true>), grid, dim3(512), 0, s, p);
-    else if (full && kh == 1 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, true>), grid, dim3(512), 0, s, p);
+    else if (full && kh == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_full_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
+    else if (full && kh == 1 && stride == 1) hipLaunchKernelGGL((conv_wgrad_full_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);

@@ -223,6 +223,32 @@ def test_mfma_conv_vs_torch_cpu(mods, n, ci, co, h, w, k, mode, pad):
     assert rel_err(c(y), ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('n,ci,co,h,w', [(8, 64, 128, 128, 128), (8, 128, 64, 128, 128), (16, 256, 512, 64, 64), (2, 512, 512, 128, 64)])
+def test_conv1x1_gemm_form_vs_torch_cpu(mods, n, ci, co, h, w):
+    """The 1x1 layers on the GEMM kernel of round 6 (conv1x1_gemm_kernel: both operands by LDS-DMA; taken for whole 128 x 128 or 64 x 256
+    tiles that fill the chip -- the critic's skip branches and their input gradients): plain, with the whole store-pass tail (per-sample
+    output scale, bias, lrelu_agc, gain, skip), and bit-identical to the tap-list kernel's arithmetic order is NOT claimed (another K order):
+    both against torch CPU."""
+    import torch.nn.functional as F
+    kk, orc = mods['kernels'], mods['orc']
+    rs = np.random.RandomState(n + ci + co + h)
+    x = torch.from_numpy(rs.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = torch.from_numpy(rs.standard_normal((co, ci, 1, 1)).astype(np.float32))
+    s_out = torch.from_numpy(rs.rand(n, co).astype(np.float32) + 0.5)
+    bias = torch.from_numpy(rs.standard_normal(co).astype(np.float32))
+    res = torch.from_numpy(rs.standard_normal((n, co, h, w)).astype(np.float32))
+    pw = kk.conv_weight_prep(wt.to(DEV), gain=0.1)
+    y = kk.conv2d(x.to(DEV), pw, mode=0, pad=0, gain=0.5)
+    assert rel_err(c(y), (F.conv2d(x, wt * 0.1) * 0.5).numpy()) < 2e-5
+    y = kk.conv2d(x.to(DEV), pw, mode=0, pad=0, out_scale=s_out.to(DEV), bias=bias.to(DEV), act=True, gain=0.5, residual=res.to(DEV))
+    ref = orc.lrelu_agc(F.conv2d(x, wt * 0.1) * s_out[:, :, None, None] + bias.view(1, -1, 1, 1), gain=0.5) + res
+    assert rel_err(c(y), ref.numpy()) < 2e-5
+    # a view that is not 16-byte aligned falls back to the tap-list kernel: same answer
+    xo = torch.zeros(x.numel() + 1, device=DEV)[1:].view_as(x).copy_(x.to(DEV))
+    assert xo.data_ptr() % 16 != 0
+    assert rel_err(c(kk.conv2d(xo, pw, mode=0, pad=0, gain=0.5)), (F.conv2d(x, wt * 0.1) * 0.5).numpy()) < 2e-5
+
+
 WINO_CASES = [
     # n, ci, co, h, w : ragged channel counts (I % 8, O % 64), odd extents, several tiles per image, one-chunk K
     (2, 64, 64, 32, 32), (1, 13, 70, 33, 36), (3, 8, 3, 40, 64), (2, 72, 130, 35, 68), (1, 128, 64, 64, 96), (2, 5, 5, 32, 44),
