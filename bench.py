@@ -147,6 +147,9 @@ def parse():
                          'measures the headline and nothing can stand between it and its JSON line)')
     ap.add_argument('--train-batch', type=int, default=8)
     ap.add_argument('--train-steps', type=int, default=3)
+    ap.add_argument('--watchdog', type=int, default=0,
+                    help='seconds: every rank dumps the Python stacks of all its threads to stderr every so often (faulthandler) -- says where a '
+                         'multi-rank run is waiting; 0 = off')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='headline loop as HIP-graph replays (eval_harness.GraphPipeline) instead of eager launches; auto = on when it '
                          'captures and is not slower than the eager loop in a short trial')
@@ -394,12 +397,14 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
             pass
     finite = all(bool(torch.isfinite(v).all()) for v in L.stats.values())
     cls = {}
+    # the instrumented iteration runs on EVERY rank (its gradient all-reduce is a collective: until round 6 only rank 0 ran it and waited
+    # for the others, who stood in the barrier below -- found on the test box with `--gpus 2 --all-blocks --watchdog 120`); only rank 0 times
+    timer = kernels.KernelTimer() if rank == 0 else None
+    kernels.set_timer(timer)
+    iteration(1)
+    torch.cuda.synchronize()
+    kernels.set_timer(None)
     if rank == 0:
-        timer = kernels.KernelTimer()
-        kernels.set_timer(timer)
-        iteration(1)
-        torch.cuda.synchronize()
-        kernels.set_timer(None)
         for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]['ms']):
             if v['ms'] <= 0:
                 continue
@@ -444,6 +449,9 @@ def train_block(a, dev, rank, world, barrier, use_dist, backend, fp16=False):
 def worker(local_rank, a, spawned_world=None, port=None):
     """One rank.  ``spawned_world`` is set when this process was started by bench.py's own spawn."""
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / device-memory sharing across processes needs it on this driver
+    if a.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(a.watchdog, repeat=True, file=sys.stderr)
     import torch
     import torch.distributed as dist
     import shgan_amd  # noqa: F401

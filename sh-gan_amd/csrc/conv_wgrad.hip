@@ -181,11 +181,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
 //   * the k-steps of a chunk are unrolled and the operands of step j + 1 are read before the MFMAs of step j issue.
 // 1 047 -> 846 us (loads only) -> see MEASUREMENTS.md for the two-stage form, 128 -> 256 channels at 257^2 x 8.
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int S>
+// ROWS > 1 (stride 2, narrow images: OW = 32 / ROWS = 16 or 8 with W = 2 OW + 1, the FIR-padded width): a chunk is ROWS WHOLE output rows.
+// Its window -- (2 ROWS + 1) whole input rows -- is then ONE contiguous span of at most 192 floats per channel (5 x 33 = 165, 9 x 17 = 153):
+// three 64-lane lines per channel, the same 24 loads per wave as the three window rows of the wide form, no halo; LDS position = offset in the
+// span, so pixel (ry, rx) and tap (ky, kx) read position (2 ry + ky) W + 2 rx + kx.  (These layers ran on the masked kernel with half or
+// three quarters of every chunk's operand columns empty: 35 TFLOP/s at 512 channels, 33^2 -> 16^2.)
+template <int KH, int KW, int S, int ROWS = 1>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradParams p) {
-    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, XW = PX * S + KW - 1, CP = 65;
-    constexpr int HC = KW > S ? KW - S : 0;                      // halo columns a tap reads (window column PX * S + hc)
-    constexpr int GSZ = PX * CP, XSZ = KH * XW * CP;
+    constexpr int TAPS = KH * KW, PX = S == 1 ? 64 : 32, RW = PX / ROWS, CP = 65;
+    static_assert(ROWS == 1 || (S == 2 && KH == 3 && KW == 3), "several rows per chunk: the stride-2 3x3 form");
+    constexpr int XW = ROWS == 1 ? PX * S + KW - 1 : S * RW + KW - S;          // window pitch (ROWS > 1: the image width itself)
+    constexpr int HC = ROWS > 1 ? 0 : (KW > S ? KW - S : 0);     // halo columns a tap reads (window column PX * S + hc)
+    constexpr int SPAN = (S * (ROWS - 1) + KH) * XW, LPC = ROWS == 1 ? KH : (SPAN + 63) / 64;     // ROWS > 1: floats / 64-lane lines per channel
+    constexpr int GSZ = PX * CP, XSZ = (ROWS == 1 ? KH * XW : LPC * 64) * CP;
     __shared__ float Gs[2][GSZ];                                 // [stage][pixel][o]
     __shared__ float Xs[2][XSZ];                                 // [stage][row][col][i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const long gplane = (long)p.OH * p.OW, xplane = (long)p.H * p.W;
-    constexpr int LPW = 64 * KH / 8;                             // x lines (one window row of one channel: 64 columns) per wave
+    constexpr int LPW = 8 * LPC;                                 // x lines (64 floats of one channel) per wave
     constexpr int NHE = 64 * KH * HC, NHT = (NHE + 511) / 512;   // halo elements, per thread
     constexpr int GL = 64 * PX / 64 / 8;                         // g: wave-instructions per wave (one = 64 / PX channel lines)
     constexpr int NST = GL + LPW + NHT;                          // staged values per thread
@@ -217,27 +225,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
     // Wave w stages channels 8 w .. 8 w + 7 of both tensors: a line's address is the previous line's plus a plane (scalar adds, no division
     // by the row count), its LDS slot an immediate offset from one lane base.  The chunk coordinates advance incrementally.
     constexpr int CPI = 64 / PX;                                 // g channels per wave instruction
-    static_assert(GL * CPI == 8 && LPW == 8 * KH, "eight channels per wave");
+    static_assert(GL * CPI == 8, "eight channels per wave");
     const unsigned goff = (unsigned)(lane / PX) * (unsigned)gplane + (unsigned)(lane % PX);
+    const unsigned xlast = (unsigned)min((LPC - 1) * 64 + lane, SPAN - 1);      // ROWS > 1: the span's last line stops at its end (no read past the tensor)
     const int gdst = (lane % PX) * CP + wv * 8 + lane / PX, xdst = lane * CP + wv * 8;
-    int ncx = c_begin % p.chunks_x, noy = (c_begin / p.chunks_x) % p.OH, nn = c_begin / (p.chunks_x * p.OH);      // the chunk load_next() fetches
+    const int rows_c = ROWS == 1 ? p.OH : p.OH / ROWS;           // chunk rows per image
+    int ncx = c_begin % p.chunks_x, noy = (c_begin / p.chunks_x) % rows_c, nn = c_begin / (p.chunks_x * rows_c);      // the chunk load_next() fetches
     auto load_next = [&](bool advance) __attribute__((always_inline)) {
-        const int ox0 = ncx * PX;
-        const float* gp = p.g + ((long)nn * p.O + o0 + wv * 8) * gplane + (long)noy * p.OW + ox0;            // wave-uniform
+        const int ox0 = ncx * PX, oy = noy * ROWS;
+        const float* gp = p.g + ((long)nn * p.O + o0 + wv * 8) * gplane + (long)oy * p.OW + ox0;            // wave-uniform (ROWS > 1: ROWS whole rows = PX contiguous pixels)
 #pragma unroll
         for (int j = 0; j < GL; ++j) rg[j] = (gp + (long)(j * CPI) * gplane)[goff];
-        const float* xb = p.x + ((long)nn * p.I + i0) * xplane + (long)(noy * S) * p.W + ox0 * S;            // window row 0, column 0, channel i0
+        const float* xb = p.x + ((long)nn * p.I + i0) * xplane + (long)(oy * S) * p.W + ox0 * S;            // window row 0, column 0, channel i0
         const float* xw = xb + (long)(wv * 8) * xplane;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
-            for (int r = 0; r < KH; ++r) rx[jj * KH + r] = (xw + (long)jj * xplane + (long)r * p.W)[lane];
+            for (int r = 0; r < LPC; ++r) {
+                if constexpr (ROWS == 1) rx[jj * LPC + r] = (xw + (long)jj * xplane + (long)r * p.W)[lane];
+                else rx[jj * LPC + r] = r + 1 < LPC ? (xw + (long)jj * xplane + r * 64)[lane] : (xw + (long)jj * xplane)[xlast];
+            }
 #pragma unroll
         for (int t = 0; t < NHT; ++t) rx[LPW + t] = xb[hoff[t]];
         if (advance) {
             if (++ncx == p.chunks_x) {
                 ncx = 0;
-                if (++noy == p.OH) { noy = 0; ++nn; }
+                if (++noy == rows_c) { noy = 0; ++nn; }
             }
         }
     };
@@ -245,10 +258,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
     auto store_item = [&](int q, int b) __attribute__((always_inline)) {
         if (q < GL) Gs[b][gdst + q * CPI] = rg[q];
         else if (q < GL + LPW) {
-            const int jj = (q - GL) / KH, r = (q - GL) - jj * KH;
-            Xs[b][xdst + r * XW * CP + jj] = rx[q - GL];
+            const int jj = (q - GL) / LPC, r = (q - GL) - jj * LPC;
+            Xs[b][xdst + r * (ROWS == 1 ? XW : 64) * CP + jj] = rx[q - GL];
         } else Xs[b][hdst[q - GL - LPW]] = rx[q - GL];
     };
+    // LDS position (in pixels of the window image) of k-step j's first pixel, tap t: pixel k = 4 j + c (c = 2 grp + half < 4 stays inside a row)
+    auto xpos = [](int j, int t) constexpr { return (S * ((4 * j) / RW) + t / KW) * XW + S * ((4 * j) % RW) + t % KW; };
     constexpr int NJ = PX / 4, H0 = NJ / 2, NH = NJ - H0;        // k-steps per wave and chunk; the stores ride on steps H0 .. NJ - 1
     if (c_begin < c_end) {
         load_next(c_begin + 1 < c_end);
@@ -263,14 +278,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
         const float* xa = Xs[b] + (2 * grp + half) * S * CP + nt * 32 + l31;
         float a_cur = ga[0], b_cur[TAPS];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) b_cur[t] = xa[((t / KW) * XW + (t % KW)) * CP];
+        for (int t = 0; t < TAPS; ++t) b_cur[t] = xa[xpos(0, t) * CP];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {                           // k = 2 (grp + 2 j) + half: constant offsets from the two lane bases
             float a_nxt = 0.f, b_nxt[TAPS];
             if (j + 1 < NJ) {
                 a_nxt = ga[4 * (j + 1) * CP];
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) b_nxt[t] = xa[((t / KW) * XW + 4 * (j + 1) * S + (t % KW)) * CP];
+                for (int t = 0; t < TAPS; ++t) b_nxt[t] = xa[xpos(j + 1, t) * CP];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -600,14 +615,27 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     }
     WgradParams p{};
     p.x = x; p.g = g; p.NB = NB; p.I = I; p.O = O; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
-    const bool packed = wgrad_packed(OW, OH, W, kh, stride, pad);
+    // the unmasked forms (conv_wgrad_full_kernel): every line, halo column and channel of every chunk inside the tensors.
+    //   * narrow FIR-padded stride-2 layers (OW = 16 / 8, W = 2 OW + 1): 2 / 4 whole output rows per chunk;
+    //   * 1x1 layers: an image is one row of H W pixels (x and g have the same extent, nothing couples neighbouring pixels);
+    //   * FIR-padded stride-2 layers with rows of whole 32-pixel chunks.
+    const bool chan64 = pad == 0 && I % 64 == 0 && O % 64 == 0 && 64L * H * W < (1L << 31) && 2L * OH * OW < (1L << 31);
+    int full_rows = 0;
+    if (chan64 && kh == 3 && stride == 2 && (OW == 16 || OW == 8) && W == 2 * OW + 1 && (OH - 1) * 2 + 2 < H && OH % (32 / OW) == 0) full_rows = 32 / OW;
+    if (chan64 && kh == 1 && stride == 1 && H == OH && W == OW && ((long)H * W) % 64 == 0) {
+        p.H = p.OH = 1;
+        p.W = p.OW = H * W;
+        H = OH = 1;
+        W = OW = p.W;
+    }
+    const bool packed = !full_rows && wgrad_packed(OW, OH, W, kh, stride, pad);
     const bool two_rows = !packed && kh == 3 && stride == 1 && OW == 32 && (OH % 2) == 0 && W == 32 + 2 - 2 * pad;      // 32-pixel rows: two per chunk
-    // the unmasked form: every line, halo column and channel of every chunk inside the tensors (FIR-padded stride-2 layers, 1x1 layers)
     const int px = stride == 1 ? 64 : 32;
-    const bool full = !packed && !two_rows && pad == 0 && I % 64 == 0 && O % 64 == 0 && OW % px == 0 && (OH - 1) * stride + kh - 1 < H &&
-                      (OW - px) * stride + 63 + (kw > stride ? kw - stride : 0) < W && 64L * H * W < (1L << 31) && 2L * OH * OW < (1L << 31);
-    p.chunks_x = shg_cdiv(OW, stride == 1 ? 64 : 32);
-    p.nchunk = packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : (two_rows ? NB * (OH / 2) : NB * OH * p.chunks_x);
+    const bool full = !packed && !two_rows && !full_rows && chan64 && OW % px == 0 && (OH - 1) * stride + kh - 1 < H &&
+                      (OW - px) * stride + 63 + (kw > stride ? kw - stride : 0) < W;
+    p.chunks_x = full_rows ? 1 : shg_cdiv(OW, stride == 1 ? 64 : 32);
+    p.nchunk = full_rows ? NB * (OH / full_rows)
+                         : (packed ? shg_cdiv(NB * OH * OW, stride == 1 ? 64 : 32) : (two_rows ? NB * (OH / 2) : NB * OH * p.chunks_x));
     p.nslice = wgrad_slices(NB, I, O, OH, OW, kh * kw);
     if (p.nslice > p.nchunk) p.nslice = p.nchunk;
     const size_t need = p.nslice > 1 ? (size_t)p.nslice * O * I * kh * kw * sizeof(float) : 0;
@@ -618,6 +646,8 @@ extern "C" int shg_conv2d_wgrad_f32(const float* x, const float* g, float* dw, i
     if (packed && stride == 1) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);
     else if (packed) hipLaunchKernelGGL((conv_wgrad_packed_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (two_rows) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 2>), grid, dim3(512), 0, s, p);
+    else if (full_rows == 2) hipLaunchKernelGGL((conv_wgrad_full_kernel<3, 3, 2, 2>), grid, dim3(512), 0, s, p);
+    else if (full_rows == 4) hipLaunchKernelGGL((conv_wgrad_full_kernel<3, 3, 2, 4>), grid, dim3(512), 0, s, p);
     else if (full && kh == 3 && stride == 2) hipLaunchKernelGGL((conv_wgrad_full_kernel<3, 3, 2>), grid, dim3(512), 0, s, p);
     else if (full && kh == 1 && stride == 1) hipLaunchKernelGGL((conv_wgrad_full_kernel<1, 1, 1>), grid, dim3(512), 0, s, p);
     else if (kh == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1>), grid, dim3(512), 0, s, p);

@@ -37,6 +37,10 @@ CONV_CASES = [
     # the unmasked form of the weight gradient (round 6): channels in whole 64-blocks, rows in whole chunks, no padding -- the FIR-padded
     # stride-2 layers (65 -> 32, 129 -> 64 with two chunks per row, non-square) and 1x1 layers; one row more than the valid extent needs
     (2, 64, 128, 65, 65, 3, 2, 0), (1, 128, 64, 33, 129, 3, 2, 0), (2, 64, 64, 66, 66, 3, 2, 0), (2, 64, 128, 16, 64, 1, 1, 0), (1, 128, 64, 8, 128, 1, 1, 0),
+    # ... its narrow stride-2 forms (two / four whole output rows per chunk: 33 -> 16, 17 -> 8; three images so that a slice boundary falls inside
+    # an image) and 1x1 layers whose rows are shorter than a chunk (an image = one row of H W pixels: 8 x 8, 16 x 32, 4 x 16)
+    (3, 64, 128, 33, 33, 3, 2, 0), (3, 128, 64, 17, 17, 3, 2, 0), (5, 64, 64, 33, 33, 3, 2, 0), (2, 64, 128, 8, 8, 1, 1, 0), (2, 128, 64, 16, 32, 1, 1, 0),
+    (4, 64, 64, 4, 16, 1, 1, 0),
 ]
 
 
