@@ -84,3 +84,23 @@ def test_bench_eight_ranks_oversubscribed_on_one_device(tmp_path):
         assert sorted(int(i) for i in dig[r]) == [r, r + 8], (r, dig[r])
     ev = line['eval_loop']
     assert ev['n_gpus'] == 8 and ev['result_ok'] and ev['fid_samples_counted'] == 8 * 2 * 2, ev
+
+
+def test_bench_two_ranks_training_blocks(tmp_path):
+    """``--gpus 2 --all-blocks``: the config-5 blocks with an active gradient all-reduce (gloo here, two ranks on the one device).  Guards
+    two things round 6 found on this very command: the instrumented iteration must run on EVERY rank (rank 0 alone stood in its all-reduce
+    while rank 1 waited in the next barrier: the run hung until its timeout), and the HIP-graph form with more than one rank -- two graphs
+    per phase around the host-side bucket all-reduce -- is captured, timed beside the eager loop and the faster one reported."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--all-blocks', '--train-steps', '1', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-second-config', '--no-eval-loop', '--profile-steps', '0', '--watchdog', '600'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['ranks_all_reduced'] == 2
+    for blk in (line['train_step'], line['train_step']['fp16_blocks']):
+        assert blk['n_gpus'] == 2 and blk['grad_all_reduce'] == 'gloo' and blk['losses_finite']
+        g = blk['hip_graph']
+        assert g.get('split_around_all_reduce') is True and g['eager_ms_per_step'] > 0 and g['graph_ms_per_step'] > 0, g
+        assert blk['ms_per_step'] == pytest.approx(min(g['eager_ms_per_step'], g['graph_ms_per_step']), rel=1e-3)
+        assert blk['kernel_classes_one_step_rank0']

@@ -307,3 +307,22 @@ def test_channel_sum_and_channel_bias_node_on_cpu():
             res.append((out.detach(), gy.detach(), gb.detach(), ggy, ggb))
     for got, want in zip(*res):
         assert torch.allclose(got.double(), want.double(), rtol=1e-6, atol=1e-6)
+
+
+def test_bench_reads_its_committed_profiles():
+    """bench.py attaches constants of committed profiles to its JSON line (PMC traffic per kernel class, the SHU floor probe): the parsers
+    must find what the files under profiles/ hold (a renamed file or a reformatted table would silently drop the fields)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('shg_bench_for_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fl = bench.shu_floors()
+    assert set(fl) == {'shu_rfft2', 'shu_spectral', 'shu_irfft2'}
+    for product, skeleton, empty in fl.values():
+        assert product > skeleton > empty > 0
+    gb, src = bench.pmc_traffic(512, 16)
+    assert gb and gb > 0.5 and src == os.path.join('profiles', 'traffic_512x16.json')
+    cls = bench.pmc_traffic_classes(512, 16)
+    assert 'conv_wino4_kernel' in cls and cls['conv_wino4_kernel']['read_GB_per_launch'] > 0
