@@ -26,7 +26,7 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))
     gui = d.get('GRBM_GUI_ACTIVE', 0) / 2.0 if 'SQ_ACTIVE_INST_VALU' in d and 'SQ_WAVE_CYCLES' in d else d.get('GRBM_GUI_ACTIVE', 0)
     if gui < 1e5: continue
     wc = d.get('SQ_WAVE_CYCLES', 0) or 1
-    lines.append(f"{k:48s} launches={n[k]:4d} gui_cycles={gui:.3e} mfma_busy/gui/1024={d.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/gui/1024:.3f} "
+    lines.append(f"{k:48s} launches={n[k]:4d} gui_cycles={gui:.3e} mfma_busy={d.get("SQ_VALU_MFMA_BUSY_CYCLES",0)/gui/128:.3f} "
                  f"mops_f32={d.get('SQ_INSTS_VALU_MFMA_MOPS_F32',0):.3e} wait_any/wave={d.get('SQ_WAIT_ANY',0)/wc:.3f} wait_inst/wave={d.get('SQ_WAIT_INST_ANY',0)/wc:.3f} "
                  f"active/wave={d.get('SQ_ACTIVE_INST_ANY',0)/wc:.3f} valu/wave={d.get('SQ_ACTIVE_INST_VALU',0)/wc:.3f} lds/wave={d.get('SQ_ACTIVE_INST_LDS',0)/wc:.3f} "
                  f"wait_lds/wave={d.get('SQ_WAIT_INST_LDS',0)/wc:.3f} bank_conf/lds_active={d.get('SQ_LDS_BANK_CONFLICT',0)/max(d.get('SQ_LDS_IDX_ACTIVE',0),1):.3f} "

@@ -3,6 +3,9 @@ on batch / 2 = 4 images).  us per launch and direct-form TFLOP/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, shgan_amd
+from shgan_amd import _lib
+if os.environ.get('SHG_VARIANT'):
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_variants', 'libshgan_hip_%s.so' % os.environ['SHG_VARIANT']))
 from shgan_amd import kernels
 from shgan_amd.model_zoo.stylegan_utils import upfirdn2d as ufd
 
@@ -22,7 +25,7 @@ def t(fn, reps=20):
 w = torch.randn(512, 512, 3, 3, device='cuda') / 68.0
 pw = kernels.conv_weight_prep(w)
 pwt = kernels.conv_weight_prep(w.transpose(0, 1).contiguous())
-for res in (64, 32, 16, 8, 4):
+for res in ((16, 8, 4) if '--small' in sys.argv else (64, 32, 16, 8, 4)):
     for n in (2, 4, 8, 16):
         x = torch.randn(n, 512, res, res, device='cuda')
         xs2 = torch.randn(n, 512, res + 1, res + 1, device='cuda')
