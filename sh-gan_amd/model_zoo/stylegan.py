@@ -58,6 +58,9 @@ def _act_generic(y, ak):
     return y * g if g != 1.0 else y
 
 
+FUSE_BLOCK_SUM = os.environ.get('SHG_FUSE_BLOCK_SUM', '1') == '1'       # (A/B switch: 0 = the residual blocks' sum as an elementwise pass)
+
+
 def _add(a, b):
     """a + b: one fused kernel on the inference path, a differentiable tensor op on the training path."""
     if grad_ops.generic_route(a, b):
@@ -622,8 +625,18 @@ class conv2d_layer(nn.Module):
         return _cache_of(self).get('w', [self.weight], lambda: kernels.conv_weight_prep(
             self.weight.detach(), gain=self.weight_gain))
 
-    def _forward_train(self, x, gain=1):
-        """Differentiable composition (training rows): convolution / FIR / bias + activation through their autograd forms."""
+    def _forward_train(self, x, gain=1, residual=None):
+        """Differentiable composition (training rows): convolution / FIR / bias + activation through their autograd forms.  ``residual``: the
+        other branch of a residual block, added in the store pass of this (linear) layer where that form exists, by ``_add`` otherwise."""
+        if residual is not None:
+            ak = _act_kwargs(self.activation, gain)
+            if (FUSE_BLOCK_SUM and self.activation is None and self.up == 1 and self.down == 2 and self.padding == 0 and self.weight.shape[2] == 1
+                    and self.bias is None and self.resample_filter is not None and tuple(self.resample_filter.shape) == (4, 4) and ak is not None
+                    and not ak.get('act') and conv2d_gradfix.conv_bias_act_supported(x, self.weight, ak) and residual.dtype == x.dtype):
+                xd = upfirdn2d.upfirdn2d(x=x, f=self.resample_filter, down=2, padding=[1, 1, 1, 1])
+                if tuple(residual.shape) == (x.shape[0], self.weight.shape[0], xd.shape[2], xd.shape[3]):
+                    return conv2d_gradfix.conv2d_bias_act(xd, grad_ops.scaled_weight(self.weight, self.weight_gain, x.dtype), None, 0, residual=residual, **ak)
+            return _add(residual, self._forward_train(x, gain))
         ak = _act_kwargs(self.activation, gain)
         if self.up == 1 and self.down == 1 and conv2d_gradfix.conv_bias_act_supported(x, self.weight, ak):
             # 3x3 stride-1 layers: convolution + bias + activation as one node on one forward kernel
@@ -663,7 +676,11 @@ class conv2d_layer(nn.Module):
             return kernels_f16.conv2d(y, w, b, 2, 0, **ak)
         return None
 
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, residual=None):
+        if residual is not None:                  # (training rows of the critic's residual blocks; elsewhere the plain sum)
+            if layer_route(self, x, self.weight, self.bias) == 'generic':
+                return self._forward_train(x, gain, residual=residual)
+            return _add(residual, self.forward(x, gain))
         route = layer_route(self, x, self.weight, self.bias)
         if route == 'f16_fused':
             y = self._forward_half_infer(x, gain)
@@ -1022,8 +1039,8 @@ class discrim_block(nn.Module):
                 with grad_ops.InputGradJoin.consumer(join):
                     h = self.conv0(x)
                 h = self.conv1(h, gain=np.sqrt(0.5))
-                y = self.skip(grad_ops.stash_input_grad(x, join), gain=np.sqrt(0.5))
-                return _add(h, y), None
+                # (the block's sum h + skip(x) in the store pass of the skip's 1x1 GEMM: round 6)
+                return self.skip(grad_ops.stash_input_grad(x, join), gain=np.sqrt(0.5), residual=h), None
             y = self.skip(x, gain=np.sqrt(0.5))
             x = self.conv1(self.conv0(x), gain=np.sqrt(0.5))
             x = _add(x, y)

@@ -219,13 +219,17 @@ class _ConvBiasActFn(torch.autograd.Function):
     from the same differentiable pieces as the two nodes it replaces, so R1 differentiates it twice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, cfg):
+    def forward(ctx, x, weight, bias, stride, padding, cfg, residual=None):
         act, gain, alpha, act_gain, clamp = cfg
         b = None if bias is None else bias.detach()
+        if residual is not None and act:
+            raise NotImplementedError('_ConvBiasActFn: a residual is added in the store pass of LINEAR layers only (the backward pass reads the '
+                                      "activation's slope from the saved output)")
+        res = None if residual is None else residual.detach()
         if x.dtype == torch.float16:
             y = kernels_f16.conv2d(x.detach(), weight.detach().to(torch.float16), None if b is None else b.to(torch.float32), stride, padding, act=act,
-                                   gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp)
-        elif (THIN_1X1 and weight.shape[2] == 1 and stride == 1 and padding == 0 and weight.shape[1] <= 8 and (x.shape[2] * x.shape[3]) % 4 == 0
+                                   gain=gain, alpha=alpha, act_gain=act_gain, clamp=clamp, residual=res)
+        elif (residual is None and THIN_1X1 and weight.shape[2] == 1 and stride == 1 and padding == 0 and weight.shape[1] <= 8 and (x.shape[2] * x.shape[3]) % 4 == 0
               and x.shape[0] <= 65535):
             # fromrgb (4 -> 64): the HBM-bound pointwise kernel, bias + activation in the same pass
             y = kernels.conv1x1_thin_in(x.detach().contiguous(), weight.detach().reshape(weight.shape[0], weight.shape[1]), b, act=act, gain=gain,
@@ -233,7 +237,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         else:
             pw = kernels.conv_weight_prep(weight.detach())
             y = kernels.conv2d(x.detach().contiguous(), pw, mode=kernels.MODE_SAME if stride == 1 else kernels.MODE_DOWN2, pad=padding, bias=b, act=act, gain=gain, alpha=alpha,
-                               act_gain=act_gain, clamp=clamp)
+                               act_gain=act_gain, clamp=clamp, residual=None if res is None else res.contiguous())
         ctx.save_for_backward(x, weight, y)
         ctx.cfg, ctx.padding, ctx.stride = cfg, padding, stride
         ctx.bias_dtype = None if bias is None else bias.dtype
@@ -253,7 +257,8 @@ class _ConvBiasActFn(torch.autograd.Function):
             raise RuntimeError('InputGradJoin: a gradient was stashed for a convolution whose input needs none')
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             gw = _WgradFn.apply(gz, x, weight.shape[2], ctx.stride, ctx.padding)
-        return gx, gw, gb, None, None, None
+        # (a residual added in the store pass of a linear layer: y = conv * gain + r, dL/dr = dL/dy)
+        return gx, gw, gb, None, None, None, (gy if len(ctx.needs_input_grad) > 6 and ctx.needs_input_grad[6] else None)
 
 
 FUSED_CONV_ACT = os.environ.get('SHG_FUSED_CONV_ACT', '1') == '1'        # (A/B switch: 0 = convolution and bias / activation as two nodes)
@@ -265,9 +270,11 @@ def conv_bias_act_supported(x, weight, act_kwargs):
             and _wants_grad(x, weight))
 
 
-def conv2d_bias_act(x, weight, bias, padding, stride=1, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0):
-    """lrelu_agc(conv2d(x, weight, stride, padding) + bias) for 3x3 (stride 1 | 2) and 1x1 (stride 1) layers under autograd (see _ConvBiasActFn)."""
-    return _ConvBiasActFn.apply(x, weight, bias, int(stride), int(padding), (bool(act), float(gain), float(alpha), float(act_gain), clamp))
+def conv2d_bias_act(x, weight, bias, padding, stride=1, act=True, gain=1.0, alpha=0.2, act_gain=kernels.SQRT2, clamp=256.0, residual=None):
+    """lrelu_agc(conv2d(x, weight, stride, padding) + bias) for 3x3 (stride 1 | 2) and 1x1 (stride 1) layers under autograd (see _ConvBiasActFn).
+    ``residual`` (linear layers only, ``act=False``): (conv + bias) * gain + residual in the same store pass -- the sum of a residual block's two
+    branches (stylegan.py:676-680: ``x = y.add_(x)``) without an elementwise pass of its own; its gradient is the output gradient."""
+    return _ConvBiasActFn.apply(x, weight, bias, int(stride), int(padding), (bool(act), float(gain), float(alpha), float(act_gain), clamp), residual)
 
 
 class _ConvTranspose2dFn(torch.autograd.Function):
