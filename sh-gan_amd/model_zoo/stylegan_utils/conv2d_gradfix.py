@@ -248,19 +248,31 @@ class _ConvBiasActFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         need_b = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
-        gz, gb = grad_ops.bias_act_grads(_dense(gy), y, ctx.cfg, need_b, ctx.bias_dtype)
+        act, gain = ctx.cfg[0], ctx.cfg[1]
+        if not act and LINEAR_GAIN_ON_WEIGHTS:
+            # a linear layer, y = (conv(x, w) + b) * gain [+ r]: dL/dz = gain * dL/dy needs no pass over the activation gradient -- the gain
+            # goes onto the (small) weight for the input gradient and onto the (small) weight / bias gradients (the critic's skip branches:
+            # 14 whole-tensor passes per training step)
+            gz, wz = _dense(gy), weight * gain
+            gb = (grad_ops.channel_sum(gz) * gain).to(ctx.bias_dtype) if need_b else None
+        else:
+            gz, gb = grad_ops.bias_act_grads(_dense(gy), y, ctx.cfg, need_b, ctx.bias_dtype)
+            wz, gain = weight, None
         other = ctx.join.take() if ctx.join is not None else None
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv_input_grad(gz, weight, x.shape, ctx.stride, ctx.padding, residual=other)
+            gx = _conv_input_grad(gz, wz, x.shape, ctx.stride, ctx.padding, residual=other)
         elif other is not None:
             raise RuntimeError('InputGradJoin: a gradient was stashed for a convolution whose input needs none')
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             gw = _WgradFn.apply(gz, x, weight.shape[2], ctx.stride, ctx.padding)
+            if gain is not None:
+                gw = gw * gain
         # (a residual added in the store pass of a linear layer: y = conv * gain + r, dL/dr = dL/dy)
         return gx, gw, gb, None, None, None, (gy if len(ctx.needs_input_grad) > 6 and ctx.needs_input_grad[6] else None)
 
 
+LINEAR_GAIN_ON_WEIGHTS = os.environ.get('SHG_LINEAR_GAIN_ON_WEIGHTS', '1') == '1'      # (A/B switch: 0 = dz = gain * dy as an elementwise pass)
 FUSED_CONV_ACT = os.environ.get('SHG_FUSED_CONV_ACT', '1') == '1'        # (A/B switch: 0 = convolution and bias / activation as two nodes)
 
 
