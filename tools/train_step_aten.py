@@ -1,11 +1,13 @@
-"""ATen operators (the glue around the HIP kernels) of one G + D training step, by device time.  usage: python tools/train_step_aten.py [--fp16]"""
+"""ATen operators (the glue around the HIP kernels) of one G + D training step, by device time.  usage: python tools/train_step_aten.py [--fp16]   (SHG_ATEN_STACKS=1: call sites)
+SHG_ATEN_STACKS=1: for the largest (operator, shapes) groups the innermost frames of this repository that issued them."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import runpy, torch
 from torch.profiler import profile, ProfilerActivity
 ns = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'train_step_bench.py'), run_name='bench')
 g_phase, d_phase = ns['g_phase'], ns['d_phase']
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+STACKS = bool(os.environ.get('SHG_ATEN_STACKS'))
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACKS) as prof:
     g_phase(); d_phase()
     torch.cuda.synchronize()
 ev = prof.key_averages(group_by_input_shape=True)
@@ -21,3 +23,17 @@ for k, (t, c) in sorted(byop.items(), key=lambda kv: -kv[1][0])[:25]:
 print('largest (op, shapes):')
 for t, c, k, s in rows[:70]:
     print(f'  {t / 1e3:8.3f} ms {c:5d}x {k:28s} {s}')
+
+if STACKS:
+    import collections
+    print('by call site (frames inside this repository, innermost first):')
+    sites = collections.defaultdict(lambda: [0.0, 0])
+    for e in prof.events():
+        if not e.name.startswith('aten::') or e.self_device_time_total <= 0:
+            continue
+        fr = [f for f in (e.stack or []) if 'sh-gan_amd' in f or 'bench' in f or 'losses' in f][:3]
+        key = (e.name, str(e.input_shapes)[:60], ' <- '.join(f.split('sh-gan_amd/')[-1][:70] for f in fr))
+        sites[key][0] += e.self_device_time_total
+        sites[key][1] += 1
+    for (name, shp, where), (t, c) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:45]:
+        print(f'  {t / 1e3:7.3f} ms {c:4d}x {name:18s} {shp:60s} {where}')
