@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const ConvParams p
 static bool conv1x1_gemm_ok(const ConvParams& p, int* narrow) {
     const long P = (long)p.H * p.W;
     if (p.wgroups != 1 || p.in_scale || p.noise_mode || p.OHt != p.H || p.OWt != p.W) return false;
-    if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.wt) & 15)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.wt) | reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.residual)) & 15) return false;   // 16-byte DMA / vector accesses
     const bool nar = p.O % 128 != 0;
     *narrow = nar;
     const int BO = nar ? 64 : 128, BP = nar ? 256 : 128, KC = 16;

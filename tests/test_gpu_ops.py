@@ -247,6 +247,9 @@ def test_conv1x1_gemm_form_vs_torch_cpu(mods, n, ci, co, h, w):
     xo = torch.zeros(x.numel() + 1, device=DEV)[1:].view_as(x).copy_(x.to(DEV))
     assert xo.data_ptr() % 16 != 0
     assert rel_err(c(kk.conv2d(xo, pw, mode=0, pad=0, gain=0.5)), (F.conv2d(x, wt * 0.1) * 0.5).numpy()) < 2e-5
+    ro = torch.zeros(res.numel() + 1, device=DEV)[1:].view_as(res).copy_(res.to(DEV))          # ... and so does an unaligned skip tensor
+    y = kk.conv2d(x.to(DEV), pw, mode=0, pad=0, gain=0.5, residual=ro)
+    assert rel_err(c(y), (F.conv2d(x, wt * 0.1) * 0.5 + res).numpy()) < 2e-5
 
 
 WINO_CASES = [

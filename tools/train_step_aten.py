@@ -25,15 +25,14 @@ for t, c, k, s in rows[:70]:
     print(f'  {t / 1e3:8.3f} ms {c:5d}x {k:28s} {s}')
 
 if STACKS:
-    import collections
-    print('by call site (frames inside this repository, innermost first):')
-    sites = collections.defaultdict(lambda: [0.0, 0])
-    for e in prof.events():
-        if not e.name.startswith('aten::') or e.self_device_time_total <= 0:
+    print('by call site (innermost frames of this repository):')
+    ev2 = prof.key_averages(group_by_input_shape=True, group_by_stack_n=24)
+    rows2 = []
+    for e in ev2:
+        if not e.key.startswith('aten::') or e.self_device_time_total <= 0:
             continue
-        fr = [f for f in (e.stack or []) if 'sh-gan_amd' in f or 'bench' in f or 'losses' in f][:3]
-        key = (e.name, str(e.input_shapes)[:60], ' <- '.join(f.split('sh-gan_amd/')[-1][:70] for f in fr))
-        sites[key][0] += e.self_device_time_total
-        sites[key][1] += 1
-    for (name, shp, where), (t, c) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:45]:
-        print(f'  {t / 1e3:7.3f} ms {c:4d}x {name:18s} {shp:60s} {where}')
+        fr = [f for f in (e.stack or []) if ('sh-gan_amd' in f or 'losses' in f or 'train_step_bench' in f) and 'profiler' not in f][:3]
+        rows2.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:48], ' <- '.join(f.split('sh-gan_amd/')[-1][:80] for f in fr)))
+    rows2.sort(reverse=True)
+    for t, c, k, shp, where in rows2[:60]:
+        print(f'  {t / 1e3:7.3f} ms {c:4d}x {k:16s} {shp:48s} {where}')
