@@ -273,7 +273,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int b = (c - c_begin) & 1;
-        load_next(c + 2 < c_end);                                // chunk c + 1 (the last chunk loads itself again: no branch around the loads)
         const float* ga = Gs[b] + (2 * grp + half) * CP + mo * 32 + l31;
         const float* xa = Xs[b] + (2 * grp + half) * S * CP + nt * 32 + l31;
         float a_cur = ga[0], b_cur[TAPS];
@@ -290,6 +289,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_full_kernel(const WgradPara
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            // the loads of chunk c + 1 (and their scalar address arithmetic) are issued in the shadow of the first k-step's MFMAs, not between
+            // the barrier and them (the last chunk loads itself again: no branch around the loads)
+            if (j == 0) load_next(c + 2 < c_end);
             if (j >= H0) {                                       // this step's share of the next chunk's values -> the other stage
 #pragma unroll
                 for (int q = (j - H0) * NST / NH; q < (j - H0 + 1) * NST / NH; ++q) store_item(q, b ^ 1);
