@@ -227,6 +227,55 @@ print("rank", r, "ok")
         assert p.returncode == 0, out.decode()
 
 
+def test_gloo_world2_deferred_reduction_of_the_split_graph_form():
+    """``train_stage.PhaseGraphs`` with more than one rank replays the backward passes as a HIP graph: no hook runs on the host, so the
+    buckets are reduced afterwards -- ``defer`` keeps the armed hooks from launching a collective (what a capture needs), ``reduce_all()``
+    puts every bucket in flight, ``finish(reduced=True)`` only averages and sanitises.  Same result as the hook-launched form, and a
+    NaN / inf in one rank's gradient is sanitised after the reduction exactly as there."""
+    script = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SHG_ROOT"])
+import shgan_amd
+from shgan_amd.grad_sync import BucketedAllReduce
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SHG_PORT"], rank=int(os.environ["RANK"]), world_size=2)
+r = dist.get_rank()
+w = torch.nn.Parameter(torch.zeros(3)); v = torch.nn.Parameter(torch.zeros(2000)); u = torch.nn.Parameter(torch.zeros(4))
+sync = BucketedAllReduce([w, v, u], bucket_bytes=4096)
+assert len(sync.buckets) >= 2
+out = {}
+for form in ("hooks", "deferred"):
+    sync.zero_grad()
+    sync.defer = form == "deferred"
+    a, b = (1.0, 2.0) if r == 0 else (10.0, 20.0)
+    ((w.sum() + v.sum()) * a).backward()
+    sync.arm()
+    ((w.sum() + v.sum()) * b + (v[:1].sum() * float("inf") if r == 1 else 0.0)).backward()
+    if form == "deferred":
+        assert not sync._handles                         # the armed pass launched nothing
+        sync.defer = False
+        sync.reduce_all()
+        sync.finish(reduced=True)
+    else:
+        assert sync._handles
+        sync.finish()
+    out[form] = torch.cat([w.grad.reshape(-1), v.grad.reshape(-1), u.grad.reshape(-1)]).clone()
+    assert [id(p) for p in sync.untouched()] == [id(u)]
+assert torch.equal(out["hooks"], out["deferred"]), (out["hooks"][:5], out["deferred"][:5])
+want = (1.0 + 2.0 + 10.0 + 20.0) / 2
+assert torch.allclose(out["hooks"][:3], torch.full((3,), want)) and float(out["hooks"][3]) == 1e5      # v[0]: inf -> nan_to_num(posinf=1e5)
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+    port = str(39500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), SHG_ROOT=ROOT, SHG_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
+
+
 def test_stream_pipeline_is_a_plain_loop_without_a_gpu():
     import torch
     from shgan_amd import eval_harness as hz
